@@ -1,0 +1,146 @@
+"""Functional fp32 CPU restatement of the reference network.  TEST INFRASTRUCTURE ONLY.
+
+  Deeplabv2.forward (PPM branch)  <- regda/models/Encoder.py:129,145-155
+  PPMBilinear.forward             <- regda/models/Encoder.py:43-55
+  ResNetEncoder.forward (OS16)    <- regda/resnet.py:140-166,192-207
+  Bottleneck.forward              <- regda/_resnets.py:92-112
+
+It works on a plain dict in the reference's state_dict layout (688 keys for
+ResNet-101) so the same weights can be fed to the
+reference model, to this oracle and to the HIP path.
+"""
+import torch
+import torch.nn.functional as F
+
+LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3)}
+POOL_SCALES = (1, 2, 3, 6)
+
+
+def layer_specs(resnet_type='resnet101'):
+    """[(prefix, inplanes, planes, stride, dilation, has_downsample)] for every
+    Bottleneck at output_stride 16 (layer4: stride 2 -> 1; first block conv2
+    dilation 1, later blocks dilation 2; resnet.py:62-63,192-207)."""
+    specs = []
+    inpl = 64
+    for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), LAYERS[resnet_type]), start=1):
+        for bi in range(nblk):
+            stride = 2 if (bi == 0 and li in (2, 3)) else 1
+            dil = 2 if (li == 4 and bi > 0) else 1
+            ds = bi == 0
+            specs.append((f'encoder.resnet.layer{li}.{bi}', inpl, planes, stride, dil, ds))
+            inpl = planes * 4
+    return specs
+
+
+def init_state_dict(resnet_type='resnet101', num_classes=6, seed=0, dtype=torch.float32):
+    """Seeded random weights in the reference layout: conv kaiming_normal(fan_out)
+    (_resnets.py:164-169), BN gamma ~ U(0.5,1.5), beta ~ N(0,0.1) (non-trivial on
+    purpose so affine terms are exercised), running stats (0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, co, ci, k, bias=False):
+        std = (2.0 / (co * k * k)) ** 0.5
+        sd[name + '.weight'] = torch.randn(co, ci, k, k, generator=g, dtype=dtype) * std
+        if bias:
+            sd[name + '.bias'] = torch.randn(co, generator=g, dtype=dtype) * 0.1
+
+    def bn(name, c):
+        sd[name + '.weight'] = torch.rand(c, generator=g, dtype=dtype) + 0.5
+        sd[name + '.bias'] = torch.randn(c, generator=g, dtype=dtype) * 0.1
+        sd[name + '.running_mean'] = torch.zeros(c, dtype=dtype)
+        sd[name + '.running_var'] = torch.ones(c, dtype=dtype)
+        sd[name + '.num_batches_tracked'] = torch.zeros((), dtype=torch.int64)
+
+    conv('encoder.resnet.conv1', 64, 3, 7)
+    bn('encoder.resnet.bn1', 64)
+    for p, inpl, planes, stride, dil, ds in layer_specs(resnet_type):
+        conv(p + '.conv1', planes, inpl, 1); bn(p + '.bn1', planes)
+        conv(p + '.conv2', planes, planes, 3); bn(p + '.bn2', planes)
+        conv(p + '.conv3', planes * 4, planes, 1); bn(p + '.bn3', planes * 4)
+        if ds:
+            conv(p + '.downsample.0', planes * 4, inpl, 1); bn(p + '.downsample.1', planes * 4)
+    for head in ('layer5', 'layer6'):
+        for i in range(4):
+            conv(f'{head}.ppm.{i}.1', 512, 2048, 1); bn(f'{head}.ppm.{i}.2', 512)
+        conv(f'{head}.conv_last.0', 512, 2048 + 4 * 512, 3); bn(f'{head}.conv_last.1', 512)
+        conv(f'{head}.conv_last.4', num_classes, 512, 1, bias=True)
+    return sd
+
+
+def _bn(x, sd, name, training, new_stats):
+    w, b = sd[name + '.weight'], sd[name + '.bias']
+    rm, rv = sd[name + '.running_mean'], sd[name + '.running_var']
+    if training:
+        rm2, rv2 = rm.detach().clone(), rv.detach().clone()
+        y = F.batch_norm(x, rm2, rv2, w, b, True, 0.1, 1e-5)
+        if new_stats is not None:
+            new_stats[name + '.running_mean'] = rm2
+            new_stats[name + '.running_var'] = rv2
+            new_stats[name + '.num_batches_tracked'] = sd[name + '.num_batches_tracked'] + 1
+        return y
+    return F.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5)
+
+
+def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_stats=None,
+            taps=None):
+    """Train: (x1, x2, feat).  Eval: per-pixel class probabilities at input size.
+
+    drop_masks: optional (m5, m6), each (b,512) of {0,1}: the Dropout2d(0.1)
+    channel keep-masks of the two heads (Encoder.py:39); kept channels are
+    scaled by 1/0.9.  None -> no dropout (identity), which is what eval does.
+    new_stats: dict that receives updated BN buffers (train mode).
+    taps: optional dict that receives named intermediate activations.
+    """
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t
+        return t
+
+    y = F.conv2d(x, sd['encoder.resnet.conv1.weight'], None, 2, 3)
+    y = F.relu(_bn(y, sd, 'encoder.resnet.bn1', training, new_stats))
+    tap('stem', y)
+    y = F.max_pool2d(y, 3, 2, 1)
+    tap('pool', y)
+    for p, inpl, planes, stride, dil, ds in layer_specs(resnet_type):
+        idt = y
+        o = F.conv2d(y, sd[p + '.conv1.weight'])
+        o = F.relu(_bn(o, sd, p + '.bn1', training, new_stats))
+        o = F.conv2d(o, sd[p + '.conv2.weight'], None, stride, dil, dil)
+        o = F.relu(_bn(o, sd, p + '.bn2', training, new_stats))
+        o = F.conv2d(o, sd[p + '.conv3.weight'])
+        o = _bn(o, sd, p + '.bn3', training, new_stats)
+        if ds:
+            idt = F.conv2d(y, sd[p + '.downsample.0.weight'], None, stride)
+            idt = _bn(idt, sd, p + '.downsample.1', training, new_stats)
+        y = F.relu(o + idt)
+        tap(p, y)
+    feat = F.instance_norm(y, eps=1e-5)                       # Encoder.py:123,146-147
+    tap('feat', feat)
+    outs = []
+    for hi, head in enumerate(('layer5', 'layer6')):
+        size = feat.shape[-2:]
+        parts = [feat]
+        for i, s in enumerate(POOL_SCALES):
+            q = F.adaptive_avg_pool2d(feat, s)
+            q = F.conv2d(q, sd[f'{head}.ppm.{i}.1.weight'])
+            q = F.relu(_bn(q, sd, f'{head}.ppm.{i}.2', training, new_stats))
+            parts.append(F.interpolate(q, size, mode='bilinear', align_corners=False))
+        cat = torch.cat(parts, 1)
+        o = F.conv2d(cat, sd[f'{head}.conv_last.0.weight'], None, 1, 1)
+        o = F.relu(_bn(o, sd, f'{head}.conv_last.1', training, new_stats))
+        if training and drop_masks is not None:
+            o = o * (drop_masks[hi].to(o.dtype) / 0.9)[:, :, None, None]
+        tap(head + '.hidden', o)
+        o = F.conv2d(o, sd[f'{head}.conv_last.4.weight'], sd[f'{head}.conv_last.4.bias'])
+        outs.append(o)
+    if training:
+        return outs[0], outs[1], feat
+    x1 = F.interpolate(outs[0], x.shape[-2:], mode='bilinear', align_corners=True)
+    x2 = F.interpolate(outs[1], x.shape[-2:], mode='bilinear', align_corners=True)
+    return (x1.softmax(dim=1) + x2.softmax(dim=1)) / 2
+
+
+def param_names(sd):
+    """Keys that are nn.Parameters in the reference (everything but BN buffers)."""
+    return [k for k in sd if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]

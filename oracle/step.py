@@ -1,0 +1,78 @@
+"""One full SSL iteration on CPU fp32 (stock PyTorch autograd).  TEST INFRASTRUCTURE ONLY.
+
+Restates tools/train_ssl_reg.py:198-241: two train-mode forwards, label_refine,
+pseudo_selection, LRH, update_prototype, 2x loss_calc, backward,
+clip_grad_norm_(32), SGD(momentum .9, wd 5e-4).  Used by tests as the end-to-end
+checker and by bench.py's `cpu_baseline` leg (kind "port").
+"""
+import torch
+
+from . import labels, labelpath, model
+
+
+class CpuStep:
+    def __init__(self, sd, prototypes, resnet_type='resnet101', class_num=6, ignore_label=-1,
+                 lr=1e-2, momentum=0.9, weight_decay=5e-4, max_norm=32.0,
+                 cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996,
+                 refine_temp=2.0, sam_refine=True):
+        self.sd = {k: v.clone() for k, v in sd.items()}
+        self.names = model.param_names(self.sd)
+        for k in self.names:
+            self.sd[k].requires_grad_(True)
+        self.mom = {k: None for k in self.names}
+        self.prototypes = prototypes.clone()
+        self.rt = resnet_type
+        self.C, self.ig = class_num, ignore_label
+        self.lr, self.m, self.wd, self.max_norm = lr, momentum, weight_decay, max_norm
+        self.top, self.low, self.percent = cutoff_top, cutoff_low, percent
+        self.pdecay, self.temp, self.sam = proto_decay, refine_temp, sam_refine
+
+    def step(self, images_s, label_s, images_t, soft_t, regs_t, drop_masks_s=None, drop_masks_t=None,
+             lr=None, phases=None):
+        import time
+        t0 = time.time()
+        sd = self.sd
+        ns = {}
+        s1, s2, feat_s = model.forward(sd, images_s, True, drop_masks_s, self.rt, ns)
+        for k, v in ns.items():
+            sd[k] = v
+        ns = {}
+        t1, t2, feat_t = model.forward(sd, images_t, True, drop_masks_t, self.rt, ns)
+        for k, v in ns.items():
+            sd[k] = v
+        t_fwd = time.time()
+        with torch.no_grad():
+            soft = labelpath.label_refine(feat_t, self.prototypes, [t1, t2], soft_t, True, 'all', self.temp)
+            hard = torch.from_numpy(labels.pseudo_selection(soft.numpy(), self.top, self.low, self.ig))
+            if self.sam:
+                hard = torch.from_numpy(labels.homogenize(hard.numpy(), regs_t.squeeze(1).numpy(),
+                                                          self.percent, self.C, self.ig))
+            self.prototypes, _ = labelpath.update_prototype(feat_s, label_s, self.prototypes,
+                                                            self.pdecay, self.C, self.ig)
+        loss_s = labelpath.loss_calc([s1, s2], label_s, self.ig)
+        loss_t = labelpath.loss_calc([t1, t2], hard, self.ig)
+        loss = loss_s + loss_t
+        t_lab = time.time()
+        params = [sd[k] for k in self.names]
+        grads = torch.autograd.grad(loss, params)
+        t_bwd = time.time()
+        with torch.no_grad():
+            total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+            coef = torch.clamp(self.max_norm / (total + 1e-6), max=1.0)   # clip_grad_norm_
+            lr = self.lr if lr is None else lr
+            for k, g in zip(self.names, grads):
+                g = g * coef
+                p = sd[k]
+                d = g + self.wd * p
+                if self.mom[k] is None:
+                    self.mom[k] = d.clone()
+                else:
+                    self.mom[k].mul_(self.m).add_(d)
+                p.sub_(lr * self.mom[k])
+        t_opt = time.time()
+        if phases is not None:
+            phases.update(fwd=t_fwd - t0, label=t_lab - t_fwd, bwd=t_bwd - t_lab, opt=t_opt - t_bwd)
+        return dict(loss=float(loss.detach()), loss_source=float(loss_s.detach()), loss_target=float(loss_t.detach()),
+                    grad_norm=float(total), hard=hard, soft=soft, grads=dict(zip(self.names, grads)),
+                    preds=(s1.detach(), s2.detach(), t1.detach(), t2.detach()),
+                    feats=(feat_s.detach(), feat_t.detach()))

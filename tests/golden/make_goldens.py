@@ -1,0 +1,309 @@
+"""Mint golden vectors from the reference's OWN Python (imported behind stubs).
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_goldens.py
+Writes small .npz / .json fixtures next to this file.  The fixtures are data
+(inputs + the reference's outputs); no reference source is copied.  The
+reference ships no tests or known-answer vectors for this path, so
+these are what pins the oracle (oracle/*.py) and, through it, the HIP path.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import _refstubs  # noqa: E402
+
+_refstubs.install()
+
+from regda.utils.local_region_homog import Homogenizer  # noqa: E402
+from regda.gast.pseudo_generation import pseudo_selection  # noqa: E402
+from regda.gast.alignment import Aligner, DownscaleLabel  # noqa: E402
+from regda.gast.balance import CrossEntropy, ClassBalance  # noqa: E402
+from regda.utils.tools import loss_calc, adjust_learning_rate  # noqa: E402
+from regda.utils.ema import ExponentialMovingAverage  # noqa: E402
+from regda.models.Encoder import Deeplabv2  # noqa: E402
+
+from oracle import model as omodel  # noqa: E402  (only for the seeded weight generator)
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(HERE, name), **arrs)
+    print('wrote', name, {k: getattr(v, 'shape', None) for k, v in arrs.items()})
+
+
+class _Log:
+    def info(self, *a, **k):
+        pass
+
+
+def random_regions(rng, b, h, w, nreg, zero_frac=0.2):
+    """Random rectangles painted over a zero background, later over earlier
+    (mirrors local_region_homog.py:51-56)."""
+    regs = np.zeros((b, h, w), np.int64)
+    for i in range(b):
+        for r in range(1, nreg + 1):
+            y0, x0 = rng.integers(0, h), rng.integers(0, w)
+            hh, ww = rng.integers(1, max(2, h // 2)), rng.integers(1, max(2, w // 2))
+            if rng.random() > zero_frac:
+                regs[i, y0:y0 + hh, x0:x0 + ww] = r
+    return regs
+
+
+def gold_lrh():
+    rng = np.random.default_rng(2333)
+    out = {}
+    cases = []
+    # random cases
+    for ci, (b, h, w, nreg, pct) in enumerate([(2, 64, 64, 40, 0.5), (3, 48, 80, 25, 0.9),
+                                                (1, 33, 17, 7, 0.5), (2, 64, 64, 300, 0.5)]):
+        lab = rng.integers(-1, 6, size=(b, h, w)).astype(np.int64)
+        # make regions label-correlated so that some regions do homogenise
+        regs = random_regions(rng, b, h, w, nreg)
+        for r in range(1, nreg + 1, 2):
+            lab[(regs == r) & (rng.random((b, h, w)) < 0.7)] = r % 6
+        cases.append((lab, regs, pct))
+    # tie cases: one region of n pixels, exactly half class 4 and half class 2
+    for n in [2, 4, 100, 128, 200, 254, 256, 258, 400, 512, 2000, 262144]:
+        side = int(np.ceil(np.sqrt(n)))
+        lab = np.full((1, side, side + 1), 3, np.int64)
+        regs = np.zeros((1, side, side + 1), np.int64)
+        flat_l, flat_r = lab.reshape(-1), regs.reshape(-1)
+        flat_r[:n] = 1
+        flat_l[:n // 2] = 4
+        flat_l[n // 2:n] = 2
+        cases.append((lab, regs, 0.5))
+    # all-ignored region, region 0 only, sparse ids (max id >> count)
+    lab = rng.integers(0, 6, size=(1, 16, 16)).astype(np.int64)
+    regs = np.ones((1, 16, 16), np.int64)
+    lab[:] = -1
+    cases.append((lab.copy(), regs.copy(), 0.5))
+    lab = rng.integers(-1, 6, size=(2, 16, 16)).astype(np.int64)
+    cases.append((lab.copy(), np.zeros((2, 16, 16), np.int64), 0.5))
+    regs = np.zeros((1, 16, 16), np.int64)
+    regs[0, :8] = 1000
+    regs[0, 8:, :8] = 7
+    lab = np.where(rng.random((1, 16, 16)) < 0.8, 1, 5).astype(np.int64)
+    cases.append((lab, regs, 0.5))
+    for i, (lab, regs, pct) in enumerate(cases):
+        h = Homogenizer(percent=pct, class_num=6, ignore_label=-1)
+        res = h(torch.from_numpy(lab.copy()), torch.from_numpy(regs.copy())).numpy()
+        out[f'lab{i}'] = lab.astype(np.int8)
+        out[f'reg{i}'] = regs.astype(np.int32)
+        out[f'pct{i}'] = np.float64(pct)
+        out[f'out{i}'] = res.astype(np.int8)
+    out['n'] = np.int64(len(cases))
+    save('lrh.npz', **out)
+
+
+def gold_pseudo():
+    rng = np.random.default_rng(7)
+    out = {}
+    cases = []
+    for (b, h, w, sharp) in [(2, 32, 32, 3.0), (1, 17, 9, 8.0), (2, 16, 16, 0.5)]:
+        logits = rng.normal(size=(b, 6, h, w)).astype(np.float32) * sharp
+        p = torch.softmax(torch.from_numpy(logits), 1).numpy()
+        cases.append(p)
+    # the toy from SURVEY Appendix B + exact-threshold equality + class never above 0.6
+    toy = np.zeros((1, 4, 1, 4), np.float32)
+    toy[0, :, 0, 0] = [0.9, 0.05, 0.03, 0.02]
+    toy[0, :, 0, 1] = [0.7, 0.2, 0.05, 0.05]
+    toy[0, :, 0, 2] = [0.5, 0.3, 0.1, 0.1]
+    toy[0, :, 0, 3] = [0.34, 0.33, 0.2, 0.13]
+    cases.append(toy)
+    eq = np.zeros((1, 3, 1, 4), np.float32)
+    eq[0, :, 0, 0] = [1.0, 0.0, 0.0]
+    eq[0, :, 0, 1] = [np.float32(1.0) * np.float32(0.8), 0.1, 0.1]   # exactly at the threshold -> rejected
+    eq[0, :, 0, 2] = [np.nextafter(np.float32(0.8), np.float32(1)), 0.1, 0.05]
+    eq[0, :, 0, 3] = [0.3, 0.61, 0.09]                                # class 1 max .61 -> t=.6 -> .61 passes
+    cases.append(eq)
+    two = np.zeros((1, 2, 1, 2), np.float32)                          # two classes pass -> ambiguous
+    two[0, :, 0, 0] = [0.7, 0.7]
+    two[0, :, 0, 1] = [0.65, 0.1]
+    cases.append(two)
+    for i, p in enumerate(cases):
+        res = pseudo_selection(torch.from_numpy(p.copy()), 0.8, 0.6, 'tensor', -1).numpy()
+        out[f'in{i}'] = p
+        out[f'out{i}'] = res.astype(np.int8)
+    out['n'] = np.int64(len(cases))
+    save('pseudo.npz', **out)
+
+
+def gold_downscale():
+    rng = np.random.default_rng(11)
+    lab = rng.integers(-1, 6, size=(2, 64, 96)).astype(np.int64)
+    # block-constant regions so some blocks pass 0.75
+    blk = rng.integers(-1, 6, size=(2, 4, 6)).astype(np.int64)
+    big = np.kron(blk, np.ones((16, 16), np.int64))
+    lab = np.where(rng.random(lab.shape) < 0.8, big, lab)
+    # exact cases in image 0, block (0,0): exactly 192/256 class 2 (kept); block (0,1): 191/256 (-> -1)
+    b00 = np.full(256, 5, np.int64); b00[:192] = 2
+    lab[0, :16, :16] = b00.reshape(16, 16)
+    b01 = np.full(256, 5, np.int64); b01[:191] = 2
+    lab[0, :16, 16:32] = b01.reshape(16, 16)
+    b02 = np.full(256, 1, np.int64); b02[:128] = 3      # 50/50 tie -> -1
+    lab[0, :16, 32:48] = b02.reshape(16, 16)
+    b03 = np.full(256, -1, np.int64); b03[:10] = 3      # mostly ignored -> -1
+    lab[0, :16, 48:64] = b03.reshape(16, 16)
+    ds = DownscaleLabel(scale_factor=16, n_classes=6, ignore_label=-1, min_ratio=0.75)
+    res = ds(torch.from_numpy(lab.copy())).numpy()
+    save('downscale.npz', lab=lab.astype(np.int8), out=res.astype(np.int8))
+
+
+def gold_refine():
+    torch.manual_seed(5)
+    b, k, h, w, C = 2, 64, 4, 4, 6
+    al = Aligner(logger=_Log(), feat_channels=k, class_num=C, ignore_label=-1, decay=0.996, resume=None)
+    protos = torch.randn(C, k)
+    al.prototypes = protos.clone()
+    feat_t = torch.randn(b, k, h, w)
+    feat_t[0, :, 0, 0] = protos[2]          # 1/pearson ~ 1e7 case
+    p1, p2 = torch.randn(b, C, h, w) * 2, torch.randn(b, C, h, w) * 2
+    soft = torch.softmax(torch.randn(b, C, 64, 64) * 3, 1)
+    out = al.label_refine(None, feat_t, [p1, p2], soft, refine=True, mode='all', temp=2.0)
+    dist = al._pearson_dist(feat_t.permute(0, 2, 3, 1).reshape(-1, k), protos)
+    feat_s = torch.randn(b, k, h, w)
+    lab_s = torch.from_numpy(np.kron(np.random.default_rng(3).integers(-1, 6, size=(b, 4, 4)),
+                                     np.ones((16, 16), np.int64)))
+    lab_s[0, :16, :16] = torch.from_numpy(np.random.default_rng(4).integers(-1, 6, size=(16, 16)))
+    ds = al.update_prototype(feat_s, lab_s)
+    # class absent from the batch keeps its old prototype
+    save('refine.npz', feat_t=feat_t.numpy(), protos=protos.numpy(), p1=p1.numpy(), p2=p2.numpy(),
+         soft=soft.numpy(), out=out.numpy(), dist=dist.numpy(), feat_s=feat_s.numpy(),
+         lab_s=lab_s.numpy().astype(np.int8), ds=ds.numpy().astype(np.int8),
+         protos_new=al.prototypes.numpy())
+
+
+def gold_loss():
+    torch.manual_seed(9)
+    b, C = 2, 6
+    p1 = (torch.randn(b, C, 4, 4) * 2).requires_grad_(True)
+    p2 = (torch.randn(b, C, 4, 4) * 2).requires_grad_(True)
+    lab = torch.randint(-1, C, (b, 64, 64))
+    lab[0, :32] = -1                                   # many ignored pixels: checks the mean-over-all denominator
+    ce = CrossEntropy(ignore_label=-1, class_balancer=None)
+    loss = loss_calc([p1, p2], lab, loss_fn=ce, multi=True)
+    loss.backward()
+    # class-balanced variant (--bcs 1): ClassBalance decay .99, temperature 2.0
+    cb = ClassBalance(class_num=C, ignore_label=-1, decay=0.99, temperature=2.0)
+    ceb = CrossEntropy(ignore_label=-1, class_balancer=cb)
+    q1, q2 = p1.detach().clone().requires_grad_(True), p2.detach().clone().requires_grad_(True)
+    lossb = loss_calc([q1, q2], lab, loss_fn=ceb, multi=True)
+    lossb.backward()
+    save('loss.npz', p1=p1.detach().numpy(), p2=p2.detach().numpy(), lab=lab.numpy().astype(np.int8),
+         loss=loss.detach().numpy(), g1=p1.grad.numpy(), g2=p2.grad.numpy(),
+         lossb=lossb.detach().numpy(), gb1=q1.grad.numpy(), gb2=q2.grad.numpy(),
+         freq=cb.freq.numpy())
+
+
+def gold_lr_ema():
+    class Cfg:
+        LEARNING_RATE = 1e-2
+        POWER = 0.9
+        NUM_STEPS = 6000 * 1.5
+        PREHEAT_STEPS = int(6000 / 20)
+
+    class Opt:
+        param_groups = [dict(lr=0.0)]
+    its = [0, 1, 299, 300, 301, 3000, 5999]
+    lrs = [adjust_learning_rate(Opt(), i, Cfg) for i in its]
+    lin = torch.nn.Linear(3, 2)
+    bn = torch.nn.BatchNorm1d(2)
+    m = torch.nn.Sequential(lin, bn)
+    ema = ExponentialMovingAverage(m, 0.99)
+    ema.register()
+    w0 = lin.weight.detach().clone().numpy()
+    with torch.no_grad():
+        lin.weight.add_(1.0)
+    ema.update()
+    save('lr_ema.npz', its=np.array(its), lrs=np.array(lrs, np.float64), w0=w0,
+         w1=lin.weight.detach().numpy(), shadow=ema.shadow['0.weight'].numpy(),
+         shadow_keys=np.array(sorted(ema.shadow.keys())))
+
+
+def build_ref_model(resnet_type='resnet101'):
+    return Deeplabv2(dict(backbone=dict(resnet_type=resnet_type, output_stride=16, pretrained=False),
+                          multi_layer=True, cascade=False, use_ppm=True,
+                          ppm=dict(num_classes=6, use_aux=False, fc_dim=2048),
+                          inchannels=2048, num_classes=6, is_ins_norm=True))
+
+
+def gold_model():
+    """ResNet-101 DeepLabV2(PPM) at 2x3x64x64, seeded weights (oracle.model.init_state_dict(seed=1)),
+    one full SSL step composed exactly like tools/train_ssl_reg.py:198-241."""
+    m = build_ref_model()
+    manifest = [(k, list(v.shape), str(v.dtype).replace('torch.', '')) for k, v in m.state_dict().items()]
+    with open(os.path.join(HERE, 'state_dict_manifest.json'), 'w') as f:
+        json.dump(manifest, f)
+    sd = omodel.init_state_dict('resnet101', 6, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    masks = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            i, o = inp[0].detach(), out.detach()
+            keep = ((o != 0).flatten(2).any(-1) | (i == 0).flatten(2).all(-1))
+            masks.setdefault(name, []).append(keep.numpy().astype(np.uint8))
+        return fn
+    m.layer5.conv_last[3].register_forward_hook(hook('m5'))
+    m.layer6.conv_last[3].register_forward_hook(hook('m6'))
+    g = torch.Generator().manual_seed(2333)
+    b = 2
+    xs = torch.randn(b, 3, 64, 64, generator=g)
+    xt = torch.randn(b, 3, 64, 64, generator=g).clamp(max=1.0)
+    rng = np.random.default_rng(2333)
+    lab_s = torch.from_numpy(np.kron(rng.integers(-1, 6, size=(b, 4, 4)), np.ones((16, 16), np.int64)))
+    soft_t = torch.softmax(torch.randn(b, 6, 64, 64, generator=g) * 3, 1)
+    regs = torch.from_numpy(random_regions(rng, b, 64, 64, 12))[:, None]
+    protos = torch.randn(6, 2048, generator=g)
+    al = Aligner(logger=_Log(), feat_channels=2048, class_num=6, ignore_label=-1, decay=0.996, resume=None)
+    al.prototypes = protos.clone()
+    hom = Homogenizer(percent=0.5, class_num=6, ignore_label=-1)
+    ce = CrossEntropy(ignore_label=-1, class_balancer=None)
+    torch.manual_seed(2333)
+    s1, s2, fs = m(xs)
+    t1, t2, ft = m(xt)
+    soft2 = al.label_refine(None, ft, [t1, t2], soft_t, refine=True, mode='all', temp=2.0)
+    hard = pseudo_selection(soft2, 0.8, 0.6, 'tensor', -1)
+    hard2 = hom(hard, regs.squeeze(1))
+    al.update_prototype(fs, lab_s)
+    ls = loss_calc([s1, s2], lab_s, loss_fn=ce, multi=True)
+    lt = loss_calc([t1, t2], hard2, loss_fn=ce, multi=True)
+    loss = ls + lt
+    loss.backward()
+    named = dict(m.named_parameters())
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values())).item()
+    sel = ['encoder.resnet.conv1.weight', 'encoder.resnet.bn1.weight', 'encoder.resnet.bn1.bias',
+           'layer5.conv_last.4.weight', 'layer5.conv_last.4.bias', 'layer6.conv_last.1.weight',
+           'encoder.resnet.layer4.2.bn3.bias', 'layer5.ppm.0.2.weight', 'layer6.ppm.3.2.bias']
+    grads = {('grad:' + k): named[k].grad.numpy() for k in sel}
+    grads['grad:layer3.10.conv2.weight[:2]'] = named['encoder.resnet.layer3.10.conv2.weight'].grad[:2].numpy()
+    grads['grad:layer5.conv_last.0.weight[:1,:64]'] = named['layer5.conv_last.0.weight'].grad[:1, :64].numpy()
+    sdn = m.state_dict()
+    # eval-mode teacher output with the (twice updated) running stats
+    m.eval()
+    with torch.no_grad():
+        probs = m(xt)
+    save('model_small.npz', xs=xs.numpy(), xt=xt.numpy(), lab_s=lab_s.numpy().astype(np.int8),
+         soft_t=soft_t.numpy(), regs=regs.numpy().astype(np.int32), protos=protos.numpy(),
+         m5=np.stack(masks['m5']), m6=np.stack(masks['m6']),
+         s1=s1.detach().numpy(), s2=s2.detach().numpy(), t1=t1.detach().numpy(), t2=t2.detach().numpy(),
+         feat_s=fs.detach().numpy()[:, :32], feat_t=ft.detach().numpy()[:, :32],
+         soft2=soft2.detach().numpy(), hard=hard.numpy().astype(np.int8), hard2=hard2.numpy().astype(np.int8),
+         protos_new=al.prototypes.numpy(), loss_s=ls.detach().numpy(), loss_t=lt.detach().numpy(),
+         grad_norm=np.float64(gn),
+         bn1_rm=sdn['encoder.resnet.bn1.running_mean'].numpy(), bn1_rv=sdn['encoder.resnet.bn1.running_var'].numpy(),
+         l5bn_rm=sdn['layer5.conv_last.1.running_mean'].numpy(), l5bn_rv=sdn['layer5.conv_last.1.running_var'].numpy(),
+         nbt=sdn['encoder.resnet.bn1.num_batches_tracked'].numpy(), probs=probs.numpy(), **grads)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model']
+    for w in which:
+        globals()['gold_' + w]()

@@ -1,0 +1,162 @@
+"""CPU: the oracle (oracle/*.py) against the golden vectors minted from the
+reference's own Python (tests/golden/make_goldens.py).  Integer paths must be
+bit-exact; float paths carry an explicit tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import labels, labelpath, model, step
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_lrh_bit_exact(gold):
+    g = gold('lrh.npz')
+    n = int(g['n'])
+    assert n >= 19
+    for i in range(n):
+        out = labels.homogenize(g[f'lab{i}'].astype(np.int64), g[f'reg{i}'].astype(np.int64),
+                                float(g[f'pct{i}']), 6, -1)
+        assert np.array_equal(out, g[f'out{i}'].astype(np.int64)), f'case {i}'
+
+
+def test_lrh_tie_contract(gold):
+    """exact 50/50 ties are homogenised (to the LOWEST tied id) only when n >= 256."""
+    g = gold('lrh.npz')
+    for i, n in zip(range(4, 16), [2, 4, 100, 128, 200, 254, 256, 258, 400, 512, 2000, 262144]):
+        lab, out = g[f'lab{i}'].reshape(-1)[:n], g[f'out{i}'].reshape(-1)[:n]
+        if n >= 256:
+            assert (out == 2).all(), n
+        else:
+            assert np.array_equal(lab, out), n
+
+
+def test_pseudo_selection_bit_exact(gold):
+    g = gold('pseudo.npz')
+    for i in range(int(g['n'])):
+        out = labels.pseudo_selection(g[f'in{i}'], 0.8, 0.6, -1)
+        assert np.array_equal(out, g[f'out{i}'].astype(np.int64)), f'case {i}'
+    assert list(g['out3'].reshape(-1)) == [0, -1, -1, -1]
+
+
+def test_pseudo_selection_asserts_range():
+    with pytest.raises(AssertionError):
+        labels.pseudo_selection(np.full((1, 2, 2, 2), 1.5, np.float32))
+
+
+def test_downscale_label_bit_exact(gold):
+    g = gold('downscale.npz')
+    out = labels.downscale_label(g['lab'].astype(np.int64), 16, 6, -1, 0.75)
+    assert np.array_equal(out, g['out'].astype(np.int64))
+    assert out[0, 0, 0, 0] == 2 and out[0, 0, 0, 1] == -1 and out[0, 0, 0, 2] == -1 and out[0, 0, 0, 3] == -1
+
+
+def test_label_refine_and_prototypes(gold):
+    g = gold('refine.npz')
+    t = lambda k: torch.from_numpy(g[k])
+    k = g['feat_t'].shape[1]
+    dist = labelpath.pearson_dist(t('feat_t').permute(0, 2, 3, 1).reshape(-1, k), t('protos'))
+    # the feature that equals a prototype has dist ~1e-7 whose RELATIVE error is O(1) in fp32
+    # for any summation order; everything else is tight.
+    d_ref = g['dist']
+    big = d_ref > 1e-4
+    np.testing.assert_allclose(dist.numpy()[big], d_ref[big], rtol=1e-5, atol=1e-6)
+    out = labelpath.label_refine(t('feat_t'), t('protos'), [t('p1'), t('p2')], t('soft'))
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=2e-5, atol=1e-6)
+    new, ds = labelpath.update_prototype(t('feat_s'), t('lab_s').long(), t('protos'))
+    assert np.array_equal(ds.numpy(), g['ds'].astype(np.int64))
+    np.testing.assert_allclose(new.numpy(), g['protos_new'], rtol=1e-5, atol=1e-6)
+
+
+def test_loss_and_grad(gold):
+    g = gold('loss.npz')
+    p1 = torch.from_numpy(g['p1']).requires_grad_(True)
+    p2 = torch.from_numpy(g['p2']).requires_grad_(True)
+    lab = torch.from_numpy(g['lab'].astype(np.int64))
+    loss = labelpath.loss_calc([p1, p2], lab, -1)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-6)
+    np.testing.assert_allclose(p1.grad.numpy(), g['g1'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(p2.grad.numpy(), g['g2'], rtol=1e-5, atol=1e-8)
+    # class-balanced variant
+    cb = labelpath.ClassBalanceState(6, -1, 0.99, 2.0)
+    q1 = torch.from_numpy(g['p1']).requires_grad_(True)
+    q2 = torch.from_numpy(g['p2']).requires_grad_(True)
+    lossb = labelpath.loss_calc([q1, q2], lab, -1, cb)
+    lossb.backward()
+    np.testing.assert_allclose(cb.freq.numpy(), g['freq'], rtol=1e-6)      # updated once per head
+    np.testing.assert_allclose(lossb.item(), g['lossb'], rtol=1e-6)
+    np.testing.assert_allclose(q1.grad.numpy(), g['gb1'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(q2.grad.numpy(), g['gb2'], rtol=1e-5, atol=1e-8)
+
+
+def test_lr_and_ema(gold):
+    g = gold('lr_ema.npz')
+    for it, lr in zip(g['its'], g['lrs']):
+        assert labelpath.lr_at(int(it)) == pytest.approx(float(lr), rel=1e-12, abs=0)
+    sh = labelpath.ema_update(torch.from_numpy(g['w0']), torch.from_numpy(g['w1']), 0.99)
+    np.testing.assert_allclose(sh.numpy(), g['shadow'], rtol=1e-6)
+    # only parameters (not BN buffers) are shadowed (ema.py:41-44)
+    assert list(g['shadow_keys']) == ['0.bias', '0.weight', '1.bias', '1.weight']
+
+
+def test_state_dict_manifest():
+    with open(os.path.join(GOLD, 'state_dict_manifest.json')) as f:
+        man = json.load(f)
+    sd = model.init_state_dict('resnet101', 6, seed=0)
+    assert len(man) == 688
+    assert [m[0] for m in man] == list(sd.keys())
+    for (k, shape, dt), v in zip(man, sd.values()):
+        assert list(v.shape) == shape and str(v.dtype).replace('torch.', '') == dt, k
+    assert sum(v.numel() for k, v in sd.items() if k in model.param_names(sd)) == 88653900
+
+
+@pytest.fixture(scope='module')
+def small_case(gold):
+    g = gold('model_small.npz')
+    sd = model.init_state_dict('resnet101', 6, seed=1)
+    return g, sd
+
+
+def test_model_forward_small(small_case):
+    g, sd = small_case
+    ns = {}
+    m5, m6 = torch.from_numpy(g['m5']), torch.from_numpy(g['m6'])
+    s1, s2, fs = model.forward(sd, torch.from_numpy(g['xs']), True, (m5[0], m6[0]), 'resnet101', ns)
+    np.testing.assert_allclose(s1.numpy(), g['s1'], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(s2.numpy(), g['s2'], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(fs.numpy()[:, :32], g['feat_s'], rtol=1e-3, atol=2e-4)
+
+
+def test_full_step_small(small_case):
+    """End-to-end: oracle.step.CpuStep vs the reference's step composed as
+    tools/train_ssl_reg.py:198-241 (losses, labels, prototypes, grads, BN buffers, teacher)."""
+    g, sd = small_case
+    t = lambda k: torch.from_numpy(g[k])
+    st = step.CpuStep(sd, t('protos'), lr=0.0)
+    m5, m6 = t('m5'), t('m6')
+    r = st.step(t('xs'), t('lab_s').long(), t('xt'), t('soft_t'), t('regs').long(),
+                (m5[0], m6[0]), (m5[1], m6[1]))
+    np.testing.assert_allclose(r['preds'][2].numpy(), g['t1'], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(r['soft'].numpy(), g['soft2'], rtol=1e-3, atol=1e-5)
+    # labels: the float inputs differ by summation-order noise, so allow a handful of flips
+    assert (r['hard'].numpy() != g['hard2'].astype(np.int64)).mean() < 2e-3
+    assert r['loss_source'] == pytest.approx(float(g['loss_s']), rel=1e-4)
+    assert r['loss_target'] == pytest.approx(float(g['loss_t']), rel=2e-3)
+    assert r['grad_norm'] == pytest.approx(float(g['grad_norm']), rel=5e-3)
+    np.testing.assert_allclose(st.prototypes.numpy(), g['protos_new'], rtol=1e-4, atol=1e-6)
+    for k in ['encoder.resnet.conv1.weight', 'layer5.conv_last.4.weight', 'layer5.conv_last.4.bias',
+              'encoder.resnet.bn1.bias', 'layer6.ppm.3.2.bias']:
+        ref = g['grad:' + k]
+        got = r['grads'][k].numpy()
+        assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, k
+    np.testing.assert_allclose(st.sd['encoder.resnet.bn1.running_mean'].numpy(), g['bn1_rm'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st.sd['layer5.conv_last.1.running_var'].numpy(), g['l5bn_rv'], rtol=1e-4, atol=1e-6)
+    assert int(st.sd['encoder.resnet.bn1.num_batches_tracked']) == int(g['nbt']) == 2
+    with torch.no_grad():
+        sd_eval = {k: v.detach() for k, v in st.sd.items()}
+        probs = model.forward(sd_eval, t('xt'), False)
+    np.testing.assert_allclose(probs.numpy(), g['probs'], rtol=2e-3, atol=2e-5)

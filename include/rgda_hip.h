@@ -1,0 +1,225 @@
+/*
+ * rgda_hip.h -- C ABI of librgda_hip.so: the MI355X (gfx950) kernels behind the
+ * RegDA self-training (SSL) step.  One process per GPU; every entry point only
+ * ENQUEUES work on the caller's HIP stream (no host sync, no allocation, no
+ * retained pointers, no global mutable state).  All buffers are device memory
+ * owned by the caller (PyTorch tensors' data_ptr()).
+ *
+ * The reference (StuLiu/RegDA) has no FFI: its operator interface for this path
+ * is a set of Python callables.  Each entry point below names the reference
+ * callable (file:line under /root/reference) it replaces; the Python mirror of
+ * those callables lives in regda_amd/ and calls these symbols through ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Return value: 0 on success, negative rgda_status otherwise (rgda_strerror()).
+ * Layout vocabulary: "NCHW f32" = the reference's tensors at the API boundary;
+ * "PxC bf16" = the internal pixel-major activation matrix [N*H*W][ld] with
+ * channels contiguous (row stride ld elements), bf16.
+ */
+#ifndef RGDA_HIP_H
+#define RGDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGDA_ABI_VERSION 1
+
+typedef void* rgda_stream_t; /* hipStream_t */
+
+enum rgda_status {
+    RGDA_OK = 0,
+    RGDA_ERR_ARG = -1,       /* bad shape / null pointer / unsupported parameter */
+    RGDA_ERR_WORKSPACE = -2, /* workspace too small */
+    RGDA_ERR_LAUNCH = -3,    /* hipGetLastError() after launch != hipSuccess */
+    RGDA_ERR_UNSUPPORTED = -4
+};
+
+int rgda_abi_version(void);
+const char* rgda_strerror(int status);
+
+/* ------------------------------------------------------------------ labels */
+
+/* pseudo_selection(mask, cutoff_top, cutoff_low, 'tensor', ignore_label)
+ *   regda/gast/pseudo_generation.py:59-93.
+ * soft: NCHW f32 (b,c,hw) probabilities.  out: (b,hw) int64.
+ * ws: >= rgda_pseudo_select_workspace(b,c) bytes; on return (stream order)
+ *   ws[0 .. b*c) f32 = per-image per-class max, then one int32 flag word:
+ *   bit0 = some value < 0 or > 1 (the reference asserts, :71).
+ * If classmax_ready != 0 the per-class maxima already sit in ws (written by
+ * rgda_label_refine) and the reduction pass is skipped. */
+size_t rgda_pseudo_select_workspace(int b, int c);
+int rgda_pseudo_select(const float* soft, int64_t* out, int b, int c, int hw, float cutoff_top,
+                       float cutoff_low, int ignore_label, int classmax_ready, void* ws,
+                       size_t ws_bytes, rgda_stream_t stream);
+
+/* Homogenizer.forward(pseudo_labels, regions)  (LRH)
+ *   regda/utils/local_region_homog.py:125-152 (+ torch_scatter.scatter sum, :140).
+ * labels, regions, out: (b,hw) int64.  Region ids must lie in [0, max_regions);
+ * pixels with ids outside are left unchanged and flag bit0 is set; labels
+ * outside [0,class_num) other than ignore_label set bit1 (the reference's
+ * one_hot would raise).  ws layout: int32 hist[b][max_regions][class_num],
+ * int32 ids[b][max_regions], int32 flag.  Bit-exact vs the reference. */
+size_t rgda_lrh_workspace(int b, int max_regions, int class_num);
+int rgda_lrh(const int64_t* labels, const int64_t* regions, int64_t* out, int b, int hw,
+             int class_num, int ignore_label, float percent, int max_regions, void* ws,
+             size_t ws_bytes, rgda_stream_t stream);
+
+/* Aligner.label_refine(None, feat_t, [p1,p2], soft, refine=1, mode='all', temp)
+ *   regda/gast/alignment.py:194-265 (+ _pearson_dist :396-423, _softmax_T, _logits_norm).
+ * feat: NCHW f32 (b,k,h,w); protos (c,k) f32; p1,p2: NCHW f32 (b,c,h,w);
+ * soft/out: NCHW f32 (b,c,H,W) (out may alias soft).  ws >= workspace bytes:
+ * f32 sim[b][c][h*w] then f32 classmax[b][c] (+ int32 flag) laid out so that
+ * `classmax` can be handed to rgda_pseudo_select (returned offset). */
+size_t rgda_label_refine_workspace(int b, int c, int h, int w);
+size_t rgda_label_refine_classmax_offset(int b, int c, int h, int w);
+int rgda_label_refine(const float* feat, const float* protos, const float* p1, const float* p2,
+                      const float* soft, float* out, int b, int k, int c, int h, int w, int H,
+                      int W, float temp, void* ws, size_t ws_bytes, rgda_stream_t stream);
+
+/* Aligner.update_prototype(feat, label)  regda/gast/alignment.py:86-90,300-327,456-481.
+ * feat NCHW f32 (b,k,h,w); label (b,H,W) int64 with H = 16h, W = 16w;
+ * protos (c,k) f32 updated in place; label_ds (b,h*w) int64 out.
+ * ws: f32 sums[c][k], f32 cnt[c]. */
+size_t rgda_proto_update_workspace(int c, int k);
+int rgda_proto_update(const float* feat, const int64_t* label, float* protos, int64_t* label_ds,
+                      int b, int k, int c, int h, int w, int scale, int ignore_label,
+                      float min_ratio, float decay, void* ws, size_t ws_bytes,
+                      rgda_stream_t stream);
+
+/* loss_calc([p1,p2], label, CrossEntropy, multi=True) forward + d(loss)/d(logits)
+ *   regda/utils/tools.py:240-254; regda/gast/balance.py:88-101.
+ * p1,p2: NCHW f32 (b,c,h,w) logits; label (b,H,W) int64; class_weight: NULL or
+ * f32[2][c] per-head per-class weights (ClassBalance, balance.py:27-43).
+ * loss: f32[1] (mean over ALL pixels, mean over heads).  g1,g2: NULL or
+ * NCHW f32 (b,c,h,w) gradients of `loss` w.r.t. p1,p2. */
+size_t rgda_upsample_ce_workspace(int b, int c, int h, int w, int H, int W);
+int rgda_upsample_ce(const float* p1, const float* p2, const int64_t* label,
+                     const float* class_weight, float* loss, float* g1, float* g2, int b, int c,
+                     int h, int w, int H, int W, int ignore_label, void* ws, size_t ws_bytes,
+                     rgda_stream_t stream);
+
+/* Deeplabv2 eval-branch output  regda/models/Encoder.py:152-155:
+ * (softmax(up(x1)) + softmax(up(x2))) / 2, up = bilinear align_corners=True. */
+int rgda_teacher_probs(const float* p1, const float* p2, float* probs, int b, int c, int h, int w,
+                       int H, int W, rgda_stream_t stream);
+
+/* ClassBalance._local_freq counts (balance.py:45-53): cnt[c] int32 += #pixels per class. */
+int rgda_class_count(const int64_t* label, int32_t* cnt, int64_t n, int c, rgda_stream_t stream);
+
+/* ------------------------------------------------------------- conv stack  */
+
+/* Implicit-GEMM convolution on PxC bf16 activations, bf16 MFMA, fp32 accumulate.
+ * Replaces nn.Conv2d forward (cuDNN) for every conv of regda/_resnets.py:72-112,
+ * regda/models/Encoder.py:8-65, and -- with mode=1 and transposed weights -- the
+ * data-gradient of the same convs.
+ *   x   : [N*H*W][ldx] bf16, Cin channels used
+ *   wgt : [Cout][kh*kw][Cin] bf16  (mode 1: [Cin_of_fwd][kh*kw][Cout_of_fwd])
+ *   y   : [N*Ho*Wo][ldy] bf16
+ *   res : NULL or [N*Ho*Wo][ldres] bf16 added to the result before the store
+ *   stats: NULL or f32[2][Cout]; per-channel sum and sum of squares of the
+ *          (bf16-rounded) outputs are atomically accumulated (BatchNorm batch stats)
+ *   mode 0: y[n,ho,wo] = sum x[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil] * w
+ *   mode 1: y[n,ho,wo] = sum x[n, (ho+pad-kh*dil)/stride, (wo+pad-kw*dil)/stride] * w
+ *           (terms with a non-integer or out-of-range source are zero)
+ * Requires Cin % 32 == 0, Cout % 8 == 0, ld* % 8 == 0. */
+int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res,
+                int ldres, float* stats, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream);
+
+/* Weight gradient: dw[co][tap][ci] (f32, row stride taps*Cin) +=
+ *   sum_p dy[p][co] * x[src(p,tap)][ci]   (same geometry as mode 0 above). */
+int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int N, int H,
+                      int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride,
+                      int pad, int dil, rgda_stream_t stream);
+
+/* Stem im2col: NCHW f32 image (N,3,H,W) -> [N*Ho*Wo][Kp] bf16 patches of the
+ * 7x7/2 pad-3 conv (regda/_resnets.py:150-151), k index = (kh*7+kw)*3+c, zero padded to Kp. */
+int rgda_stem_im2col(const float* img, void* col, int N, int H, int W, int Ho, int Wo, int Kp,
+                     rgda_stream_t stream);
+
+/* BatchNorm2d (train) on PxC bf16, nn.BatchNorm2d defaults (eps 1e-5, momentum .1):
+ *  finalize: stats f32[2][C] (sum,sumsq over M rows) -> mean/invstd f32[2][C] in `mi`,
+ *            running_mean/var/num_batches_tracked update.  If stats==NULL, eval mode:
+ *            mi is filled from the running statistics.
+ *  apply   : y = act( (x-mean)*invstd*gamma+beta [+ res] ) [* nscale[n][c]]
+ *  bwd     : two passes (reduce, apply) -- see kernels. */
+int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, int C, rgda_stream_t stream);
+int rgda_bn_finalize(const float* stats, float* mi, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum,
+                     rgda_stream_t stream);
+int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, const float* beta,
+                  const void* res, int ldres, const float* nscale, int rows_per_image, void* y,
+                  int ldy, int64_t M, int C, int relu, rgda_stream_t stream);
+/* sums f32[2][C] must be zero on entry: sum(g'), sum(g' * xhat), g' = g*[y>0]*nscale */
+int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
+                       const float* mi, const float* nscale, int rows_per_image, float* sums,
+                       int64_t M, int C, int relu, rgda_stream_t stream);
+/* dx = gamma*invstd*(g' - sum(g')/M - xhat*sum(g' xhat)/M); gmask (optional) = g';
+ * dgamma += sum(g' xhat), dbeta += sum(g') (f32, accumulated) */
+int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
+                      const float* mi, const float* gamma, const float* nscale,
+                      int rows_per_image, const float* sums, void* dx, int lddx, void* gmask,
+                      int ldgm, float* dgamma, float* dbeta, int64_t M, int C, int relu,
+                      rgda_stream_t stream);
+
+/* MaxPool2d(3,2,1) on PxC bf16 (regda/_resnets.py:153); idx = argmax tap (uint8). */
+int rgda_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho,
+                     int Wo, rgda_stream_t stream);
+int rgda_maxpool_bwd(const void* gy, const uint8_t* idx, void* gx, int N, int H, int W, int C,
+                     int Ho, int Wo, rgda_stream_t stream);
+
+/* InstanceNorm2d(C, affine=False, eps) (regda/models/Encoder.py:123,146-147).
+ * x [N*HW][ldx] bf16 -> y0,y1 (optional, bf16 PxC, ld ldy) and feat NCHW f32 (optional);
+ * mi f32[N][2][C] mean/invstd saved for backward. */
+int rgda_instnorm_fwd(const void* x, int ldx, void* y0, void* y1, int ldy, float* feat_nchw,
+                      float* mi, int N, int HW, int C, float eps, rgda_stream_t stream);
+/* g = ga + gb (+ gc f32) (any may be NULL); dx bf16 */
+int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const float* gc, const void* x,
+                      int ldx, const float* mi, void* dx, int lddx, int N, int HW, int C,
+                      rgda_stream_t stream);
+
+/* Spatial linear map shared by AdaptiveAvgPool2d / bilinear(align_corners=False)
+ * and their transposes (regda/models/Encoder.py:16-18,48-51):
+ *   out[n][i][c] (+)= sum_j Mx[i][j] * in[n][j][c],  Mx f32 [I][J] row-major.
+ * in: bf16 [N*J][ldin]; out: bf16 [N*I][ldout] (out_f32 != 0: f32). */
+int rgda_spatial_mix(const void* in, int ldin, const float* Mx, void* out, int ldout, int N, int I,
+                     int J, int C, int accumulate, int out_f32, rgda_stream_t stream);
+
+/* 1x1 classifier with bias (regda/models/Encoder.py:40): hidden [M][ldh] bf16 ->
+ * logits NCHW f32 (N,ncls,HW); backward gives dhidden (bf16), dW f32[ncls][C] +=, db += */
+int rgda_classifier_fwd(const void* hidden, int ldh, const float* w, const float* bias,
+                        float* logits, int N, int HW, int C, int ncls, rgda_stream_t stream);
+int rgda_classifier_bwd(const void* hidden, int ldh, const float* w, const float* glogits,
+                        void* dhidden, int lddh, float* dw, float* db, int N, int HW, int C,
+                        int ncls, rgda_stream_t stream);
+
+/* ------------------------------------------------------------- optimizer   */
+
+/* sum of squares of a flat f32 buffer -> out[0] (f32, overwritten).  ws: f32[1024]. */
+int rgda_sumsq(const float* g, int64_t n, float* out, float* ws, rgda_stream_t stream);
+
+/* clip_grad_norm_(max_norm, 2) + SGD(momentum, weight_decay) + EMA shadow + bf16 mirror
+ *   tools/train_ssl_reg.py:174-175,239-241; regda/utils/ema.py:46-51.
+ * coef = min(1, max_norm / (sqrt(gnorm_sq[0]) * gscale + 1e-6)); g = g*gscale*coef (gscale = 1/world)
+ * v = momentum*v + (g + wd*p); p -= lr*v; shadow = (1-d)*p + d*shadow (if shadow);
+ * p_bf16 = bf16(p) (if given).  lr is read from device memory (lr_dev[0]). */
+int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf16,
+                  const float* gnorm_sq, const float* lr_dev, int64_t n, float momentum,
+                  float weight_decay, float max_norm, float gscale, float ema_decay,
+                  int first_step, rgda_stream_t stream);
+
+/* w [Co][T][Ci] f32 -> wt [Ci][T][Co] bf16 (weights for the data-gradient pass). */
+int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, rgda_stream_t stream);
+int rgda_cast_bf16(const float* src, void* dst, int64_t n, rgda_stream_t stream);
+/* out = a + b (bf16, PxC) */
+int rgda_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t M,
+                  int C, rgda_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGDA_HIP_H */

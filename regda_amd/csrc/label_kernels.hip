@@ -1,0 +1,764 @@
+// Label path of the RegDA SSL step on gfx950: pseudo_selection, LRH (Homogenizer),
+// label_refine, update_prototype, fused bilinear-upsample + cross-entropy, teacher probs.
+// All fp32 / integer, HBM-bound: coalesced wide loads, LDS-resident small state,
+// wavefront-level pre-reduction in front of every atomic.  No fast-math: the
+// integer decisions must match the reference bit for bit (DESIGN.md "Parity").
+#include "common.h"
+
+// --------------------------------------------------------------------------------------
+// pseudo_selection   (regda/gast/pseudo_generation.py:59-93)
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pseudo_max_kernel(const float* __restrict__ soft, float* classmax,
+                                                         int* flag, int hw, int chunk) {
+    const int plane = blockIdx.y;  // b*c + c
+    const float* p = soft + (size_t)plane * hw;
+    int beg = blockIdx.x * chunk, end = min(hw, beg + chunk);
+    float mx = 0.f, mn = 0.f;
+    bool bad = false;
+    if ((hw & 3) == 0 && (chunk & 3) == 0) {
+        const float4* p4 = (const float4*)p;
+        for (int i = beg / 4 + threadIdx.x; i < end / 4; i += 256) {
+            float4 v = p4[i];
+            mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            mn = fminf(mn, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+        }
+    } else {
+        for (int i = beg + threadIdx.x; i < end; i += 256) {
+            float v = p[i];
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+        }
+    }
+    bad = (mx > 1.f) || (mn < 0.f);
+    mx = wave_max(mx);
+    __shared__ float smx[4];
+    __shared__ int sbad;
+    if (threadIdx.x == 0) sbad = 0;
+    __syncthreads();
+    if (bad) sbad = 1;
+    if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        // values are >= 0 on the valid path, so the uint order equals the float order
+        atomicMax((unsigned*)(classmax + plane), __float_as_uint(fmaxf(m, 0.f)));
+        if (sbad) atomicOr(flag, 1);
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) pseudo_pick_kernel(const float* __restrict__ soft,
+                                                          const float* __restrict__ classmax,
+                                                          int64_t* __restrict__ out, int hw, float top,
+                                                          float low, int ignore_label, int c_rt) {
+    const int b = blockIdx.y;
+    const int c = C > 0 ? C : c_rt;
+    float thr[C > 0 ? C : 16];
+    for (int k = 0; k < c; ++k) thr[k] = fmaxf(__fmul_rn(classmax[b * c + k], top), low);
+    const float* base = soft + (size_t)b * c * hw;
+    int64_t* o = out + (size_t)b * hw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        int cnt = 0, first = 0;
+#pragma unroll
+        for (int k = 0; k < c; ++k) {
+            float v = base[(size_t)k * hw + i];
+            bool pass = v > thr[k];
+            if (pass && cnt == 0) first = k;
+            cnt += pass ? 1 : 0;
+        }
+        o[i] = (cnt == 1) ? (int64_t)first : (int64_t)ignore_label;
+    }
+}
+
+extern "C" size_t rgda_pseudo_select_workspace(int b, int c) { return (size_t)b * c * 4 + 16; }
+
+extern "C" int rgda_pseudo_select(const float* soft, int64_t* out, int b, int c, int hw, float cutoff_top,
+                                  float cutoff_low, int ignore_label, int classmax_ready, void* ws,
+                                  size_t ws_bytes, rgda_stream_t stream) {
+    if (!soft || !out || !ws || b <= 0 || c <= 0 || c > 16 || hw < 0) return RGDA_ERR_ARG;
+    if (ws_bytes < rgda_pseudo_select_workspace(b, c)) return RGDA_ERR_WORKSPACE;
+    if (hw == 0) return RGDA_OK;
+    hipStream_t st = to_stream(stream);
+    float* classmax = (float*)ws;
+    int* flag = (int*)(classmax + (size_t)b * c);
+    if (!classmax_ready) {
+        if (hipMemsetAsync(ws, 0, (size_t)b * c * 4 + 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+        int chunk = 16384;
+        dim3 grid(cdiv(hw, chunk), b * c);
+        pseudo_max_kernel<<<grid, 256, 0, st>>>(soft, classmax, flag, hw, chunk);
+        RGDA_CHECK_LAUNCH();
+    }
+    dim3 grid(min(cdiv(hw, 256), 1024), b);
+    if (c == 6)
+        pseudo_pick_kernel<6><<<grid, 256, 0, st>>>(soft, classmax, out, hw, cutoff_top, cutoff_low, ignore_label, c);
+    else
+        pseudo_pick_kernel<0><<<grid, 256, 0, st>>>(soft, classmax, out, hw, cutoff_top, cutoff_low, ignore_label, c);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// LRH / Homogenizer   (regda/utils/local_region_homog.py:125-152)
+//   pass 1: per (image, region) class histogram.  Each workgroup owns a contiguous pixel
+//           chunk of ONE image, keeps an LDS histogram for region ids < lds_regions and
+//           merges equal (region,class) keys of neighbouring lanes before touching it
+//           (wavefront run-length reduction); the LDS bins are flushed with one global
+//           atomic per non-empty bin.
+//   pass 2: per region: n, m, first argmax, fp32 ratio test -> id table.
+//   pass 3: gather.
+// --------------------------------------------------------------------------------------
+static __device__ __forceinline__ void lrh_add(int key, bool valid, int* lds_hist, int lds_bins, int* ghist) {
+    // merge runs of equal keys across the 64 lanes: only run heads issue an atomic
+    const int lane = threadIdx.x & 63;
+    int prev = __shfl_up(key, 1, 64);
+    bool pvalid = __shfl_up((int)valid, 1, 64);
+    bool head = valid && (lane == 0 || !pvalid || prev != key);
+    unsigned long long heads = __ballot(head);
+    unsigned long long valids = __ballot(valid);
+    if (head) {
+        // run ends at the next head or at the next invalid lane
+        unsigned long long stop = (heads | ~valids) >> lane >> 1;
+        int len = stop ? (__builtin_ctzll(stop) + 1) : (64 - lane);
+        if (key < lds_bins)
+            atomicAdd(&lds_hist[key], len);
+        else
+            atomicAdd(&ghist[key], len);
+    }
+}
+
+__global__ void __launch_bounds__(256) lrh_hist_kernel(const int64_t* __restrict__ labels,
+                                                       const int64_t* __restrict__ regions, int* hist,
+                                                       int* flag, int hw, int chunk, int C, int ignore_label,
+                                                       int R, int lds_regions) {
+    extern __shared__ int lds_hist[];
+    const int b = blockIdx.y;
+    const int lds_bins = lds_regions * C;
+    for (int i = threadIdx.x; i < lds_bins; i += 256) lds_hist[i] = 0;
+    __syncthreads();
+    const int64_t* lab = labels + (size_t)b * hw;
+    const int64_t* reg = regions + (size_t)b * hw;
+    int* gh = hist + (size_t)b * R * C;
+    int beg = blockIdx.x * chunk, end = min(hw, beg + chunk);
+    int bad = 0;
+    // the loop bound is wave-uniform so the shuffles/ballots in lrh_add see full waves
+    for (int i0 = beg; i0 < end; i0 += 256) {
+        int i = i0 + threadIdx.x;
+        bool in = i < end;
+        long long l = in ? lab[i] : (long long)ignore_label;
+        long long r = in ? reg[i] : 0;
+        bool rok = (r >= 0) && (r < R);
+        bool lok = (l >= 0) && (l < C);
+        if (in && !rok) bad |= 1;
+        if (in && !lok && l != ignore_label) bad |= 2;
+        bool valid = in && rok && lok;
+        int key = valid ? ((int)r * C + (int)l) : -1;
+        lrh_add(key, valid, lds_hist, lds_bins, gh);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lds_bins; i += 256) {
+        int v = lds_hist[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+    if (bad) atomicOr(flag, bad);
+}
+
+__global__ void __launch_bounds__(256) lrh_decide_kernel(const int* __restrict__ hist, int* ids, int total, int C,
+                                                         int ignore_label, float percent) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int* h = hist + (size_t)i * C;
+    int n = 0, m = h[0], arg = 0;
+    for (int c = 0; c < C; ++c) {
+        int v = h[c];
+        n += v;
+        if (v > m) { m = v; arg = c; }   // strict > keeps the FIRST maximum (torch.max)
+    }
+    // class_num_max / (pixel_num_4sup + 1e-5) in fp32, IEEE divide (local_region_homog.py:143)
+    float ratio = __fdiv_rn((float)m, __fadd_rn((float)n, 1e-5f));
+    ids[i] = (ratio < percent) ? ignore_label : arg;
+}
+
+__global__ void __launch_bounds__(256) lrh_gather_kernel(const int64_t* __restrict__ labels,
+                                                         const int64_t* __restrict__ regions,
+                                                         const int* __restrict__ ids, int64_t* __restrict__ out,
+                                                         int hw, int R, int ignore_label) {
+    const int b = blockIdx.y;
+    const int64_t* lab = labels + (size_t)b * hw;
+    const int64_t* reg = regions + (size_t)b * hw;
+    const int* id = ids + (size_t)b * R;
+    int64_t* o = out + (size_t)b * hw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        long long r = reg[i];
+        long long l = lab[i];
+        long long v = ignore_label;
+        if (r > 0 && r < R) v = id[r];
+        o[i] = (v == ignore_label) ? l : v;
+    }
+}
+
+extern "C" size_t rgda_lrh_workspace(int b, int max_regions, int class_num) {
+    return ((size_t)b * max_regions * class_num + (size_t)b * max_regions) * 4 + 16;
+}
+
+extern "C" int rgda_lrh(const int64_t* labels, const int64_t* regions, int64_t* out, int b, int hw,
+                        int class_num, int ignore_label, float percent, int max_regions, void* ws,
+                        size_t ws_bytes, rgda_stream_t stream) {
+    if (!labels || !regions || !out || !ws || b <= 0 || hw < 0 || class_num <= 0 || max_regions <= 0)
+        return RGDA_ERR_ARG;
+    if (ws_bytes < rgda_lrh_workspace(b, max_regions, class_num)) return RGDA_ERR_WORKSPACE;
+    if (hw == 0) return RGDA_OK;
+    hipStream_t st = to_stream(stream);
+    const int R = max_regions, C = class_num;
+    int* hist = (int*)ws;
+    int* ids = hist + (size_t)b * R * C;
+    int* flag = ids + (size_t)b * R;
+    size_t hist_bytes = (size_t)b * R * C * 4;
+    if (hipMemsetAsync(hist, 0, hist_bytes, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    int lds_regions = min(R, (48 * 1024) / (C * 4));
+    int chunk = 16384;
+    dim3 g1(cdiv(hw, chunk), b);
+    lrh_hist_kernel<<<g1, 256, (size_t)lds_regions * C * 4, st>>>(labels, regions, hist, flag, hw, chunk, C,
+                                                                    ignore_label, R, lds_regions);
+    RGDA_CHECK_LAUNCH();
+    lrh_decide_kernel<<<cdiv((long long)b * R, 256), 256, 0, st>>>(hist, ids, b * R, C, ignore_label, percent);
+    RGDA_CHECK_LAUNCH();
+    dim3 g3(min(cdiv(hw, 256), 1024), b);
+    lrh_gather_kernel<<<g3, 256, 0, st>>>(labels, regions, ids, out, hw, R, ignore_label);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// bilinear align_corners=True helpers (torch upsample_bilinear2d semantics)
+// --------------------------------------------------------------------------------------
+struct Lerp {
+    int i0, i1;
+    float l0, l1;
+};
+static __device__ __forceinline__ Lerp lerp_ac(int dst, int in, int out) {
+    float scale = (out > 1) ? __fdiv_rn((float)(in - 1), (float)(out - 1)) : 0.f;
+    float src = __fmul_rn(scale, (float)dst);
+    Lerp r;
+    r.i0 = (int)src;
+    r.i1 = r.i0 + ((r.i0 < in - 1) ? 1 : 0);
+    r.l1 = __fsub_rn(src, (float)r.i0);
+    r.l0 = __fsub_rn(1.f, r.l1);
+    return r;
+}
+static __device__ __forceinline__ float bilerp(const float* p, int w, const Lerp& ly, const Lerp& lx) {
+    float v00 = p[ly.i0 * w + lx.i0], v01 = p[ly.i0 * w + lx.i1];
+    float v10 = p[ly.i1 * w + lx.i0], v11 = p[ly.i1 * w + lx.i1];
+    float top = __fadd_rn(__fmul_rn(lx.l0, v00), __fmul_rn(lx.l1, v01));
+    float bot = __fadd_rn(__fmul_rn(lx.l0, v10), __fmul_rn(lx.l1, v11));
+    return __fadd_rn(__fmul_rn(ly.l0, top), __fmul_rn(ly.l1, bot));
+}
+
+// --------------------------------------------------------------------------------------
+// label_refine   (regda/gast/alignment.py:194-265, 396-423)
+// --------------------------------------------------------------------------------------
+// centred prototypes pc[c][k] and their unbiased std
+__global__ void __launch_bounds__(256) proto_center_kernel(const float* __restrict__ protos, float* pc, float* pstd,
+                                                           int K) {
+    const int c = blockIdx.x;
+    const float* p = protos + (size_t)c * K;
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) s += p[k];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
+    __syncthreads();
+    float q = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float d = p[k] - mean;
+        pc[(size_t)c * K + k] = d;
+        q += d * d;
+    }
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) pstd[c] = sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)(K - 1));
+}
+
+// sim[b][c][p] = 1 / pearson_dist(feat[b,:,p], protos[c]).  Workgroup = 64 pixels x 4 k-slices.
+template <int C>
+__global__ void __launch_bounds__(256) pearson_sim_kernel(const float* __restrict__ feat, const float* __restrict__ pc,
+                                                          const float* __restrict__ pstd, float* __restrict__ sim,
+                                                          int K, int hw) {
+    extern __shared__ float lds[];      // pc[C][K] then red[4][64][C+1]
+    float* lpc = lds;
+    float* red = lds + (size_t)C * K;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const bool ok = p < hw;
+    for (int i = threadIdx.x; i < C * K; i += 256) lpc[i] = pc[i];
+    const float* f = feat + (size_t)b * K * hw + (ok ? p : 0);
+    const int k0 = slice * (K / 4), k1 = (slice == 3) ? K : k0 + K / 4;
+    float s = 0.f;
+    for (int k = k0; k < k1; ++k) s += f[(size_t)k * hw];
+    red[(slice * 64 + lane) * (C + 1)] = s;
+    __syncthreads();
+    float mean = (red[lane * (C + 1)] + red[(64 + lane) * (C + 1)] + red[(128 + lane) * (C + 1)] +
+                  red[(192 + lane) * (C + 1)]) / (float)K;
+    __syncthreads();
+    float q = 0.f, cov[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) cov[c] = 0.f;
+    for (int k = k0; k < k1; ++k) {
+        float d = f[(size_t)k * hw] - mean;
+        q += d * d;
+#pragma unroll
+        for (int c = 0; c < C; ++c) cov[c] += d * lpc[c * K + k];
+    }
+    float* r = red + (slice * 64 + lane) * (C + 1);
+    r[0] = q;
+#pragma unroll
+    for (int c = 0; c < C; ++c) r[1 + c] = cov[c];
+    __syncthreads();
+    if (slice == 0 && ok) {
+        float qq = 0.f;
+        for (int s4 = 0; s4 < 4; ++s4) qq += red[(s4 * 64 + lane) * (C + 1)];
+        float fstd = sqrtf(qq / (float)(K - 1));
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float cv = 0.f;
+            for (int s4 = 0; s4 < 4; ++s4) cv += red[(s4 * 64 + lane) * (C + 1) + 1 + c];
+            float bcov = cv / ((float)(K - 1) + 1e-7f);
+            float dist = (-1.0f * bcov / (fstd * pstd[c] + 1e-7f) + 1.0f) * 0.5f;
+            sim[((size_t)b * C + c) * hw + p] = 1.0f / dist;
+        }
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restrict__ sim, const float* __restrict__ p1,
+                                                           const float* __restrict__ p2, const float* __restrict__ soft,
+                                                           float* __restrict__ out, float* classmax, int h, int w,
+                                                           int H, int W, float temp) {
+    const int b = blockIdx.z, Y = blockIdx.y;
+    const int X = blockIdx.x * 256 + threadIdx.x;
+    const int hw = h * w;
+    const size_t HW = (size_t)H * W;
+    float o[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = 0.f;
+    if (X < W) {
+        Lerp ly = lerp_ac(Y, h, H), lx = lerp_ac(X, w, W);
+        float a[C], z1[C], z2[C];
+        float ma = -INFINITY, m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            size_t off = ((size_t)b * C + c) * hw;
+            a[c] = bilerp(sim + off, w, ly, lx);
+            z1[c] = __fdiv_rn(bilerp(p1 + off, w, ly, lx), temp);
+            z2[c] = __fdiv_rn(bilerp(p2 + off, w, ly, lx), temp);
+            ma = fmaxf(ma, a[c]); m1 = fmaxf(m1, z1[c]); m2 = fmaxf(m2, z2[c]);
+        }
+        float sa = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            a[c] = expf(a[c] - ma); z1[c] = expf(z1[c] - m1); z2[c] = expf(z2[c] - m2);
+            sa += a[c]; s1 += z1[c]; s2 += z2[c];
+        }
+        float pmax = 0.f, lmax = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            a[c] = a[c] / sa;                                        // softmax_T(simi, 1)
+            z1[c] = (z1[c] / s1 + z2[c] / s2) * 0.5f;               // (softmax + softmax) * 0.5
+            pmax = fmaxf(pmax, a[c]); lmax = fmaxf(lmax, z1[c]);
+        }
+        float tot = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float wgt = a[c] / (pmax + 1e-7f) + z1[c] / (lmax + 1e-7f);
+            float v = wgt * soft[((size_t)b * C + c) * HW + (size_t)Y * W + X];
+            o[c] = v;
+            tot += v;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            o[c] = o[c] / (tot + 1e-7f);
+            out[((size_t)b * C + c) * HW + (size_t)Y * W + X] = o[c];
+        }
+    }
+    if (classmax) {
+        __shared__ float red[4][C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float m = wave_max(o[c]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]),
+                            fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+            atomicMax((unsigned*)(classmax + b * C + threadIdx.x), __float_as_uint(fmaxf(m, 0.f)));
+        }
+    }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t rgda_label_refine_classmax_offset(int b, int c, int h, int w) {
+    // sim | pc (c*k is not known here: pc lives after classmax) -> sim first, classmax second
+    return align256((size_t)b * c * h * w * 4);
+}
+extern "C" size_t rgda_label_refine_workspace(int b, int c, int h, int w) {
+    // sim[b][c][hw] | classmax[b][c] + flag | pstd[c] | pc[c][K<=4096]
+    return rgda_label_refine_classmax_offset(b, c, h, w) + align256((size_t)b * c * 4 + 16) + align256((size_t)c * 4) +
+           (size_t)c * 4096 * 4;
+}
+
+extern "C" int rgda_label_refine(const float* feat, const float* protos, const float* p1, const float* p2,
+                                 const float* soft, float* out, int b, int k, int c, int h, int w, int H, int W,
+                                 float temp, void* ws, size_t ws_bytes, rgda_stream_t stream) {
+    if (!feat || !protos || !p1 || !p2 || !soft || !out || !ws) return RGDA_ERR_ARG;
+    if (c != 6) return RGDA_ERR_UNSUPPORTED;   // ISPRS: 6 classes (regda/datasets/isprsda.py:18-26)
+    if (b <= 0 || k < 2 || k > 4096 || (k & 3) || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(temp > 0.f))
+        return RGDA_ERR_ARG;
+    if (ws_bytes < rgda_label_refine_workspace(b, c, h, w)) return RGDA_ERR_WORKSPACE;
+    hipStream_t st = to_stream(stream);
+    char* base = (char*)ws;
+    float* sim = (float*)base;
+    size_t off = rgda_label_refine_classmax_offset(b, c, h, w);
+    float* classmax = (float*)(base + off);
+    off += align256((size_t)b * c * 4 + 16);
+    float* pstd = (float*)(base + off);
+    off += align256((size_t)c * 4);
+    float* pc = (float*)(base + off);
+    if (hipMemsetAsync(classmax, 0, (size_t)b * c * 4 + 16, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    proto_center_kernel<<<c, 256, 0, st>>>(protos, pc, pstd, k);
+    RGDA_CHECK_LAUNCH();
+    const int hw = h * w;
+    size_t lds = ((size_t)6 * k + 4 * 64 * 7) * 4;
+    dim3 g1(cdiv(hw, 64), b);
+    pearson_sim_kernel<6><<<g1, 256, lds, st>>>(feat, pc, pstd, sim, k, hw);
+    RGDA_CHECK_LAUNCH();
+    dim3 g2(cdiv(W, 256), H, b);
+    refine_apply_kernel<6><<<g2, 256, 0, st>>>(sim, p1, p2, soft, out, classmax, h, w, H, W, temp);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// update_prototype   (regda/gast/alignment.py:86-90, 300-327, 456-481)
+// --------------------------------------------------------------------------------------
+// one workgroup per low-res cell: histogram of the s x s block over C+1 classes
+__global__ void __launch_bounds__(256) downscale_label_kernel(const int64_t* __restrict__ label, int64_t* label_ds,
+                                                              float* cnt, int* flag, int h, int w, int s, int C,
+                                                              int ignore_label, float min_ratio) {
+    __shared__ int hist[17];
+    const int cell = blockIdx.x;             // b*h*w + y*w + x
+    const int b = cell / (h * w), yx = cell % (h * w), y = yx / w, x = yx % w;
+    const int H = h * s, W = w * s;
+    if (threadIdx.x < 17) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t* src = label + ((size_t)b * H + (size_t)y * s) * W + (size_t)x * s;
+    int bad = 0;
+    for (int i = threadIdx.x; i < s * s; i += 256) {
+        long long l = src[(size_t)(i / s) * W + (i % s)];
+        if (l == ignore_label) l = C;
+        if (l < 0 || l > C) { bad = 1; continue; }
+        atomicAdd(&hist[(int)l], 1);
+    }
+    if (bad) atomicOr(flag, 2);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // avg_pool2d of the one-hot: count / s^2 in fp32; torch.max keeps the first maximum
+        float inv = (float)(s * s);
+        float best = __fdiv_rn((float)hist[0], inv);
+        int arg = 0;
+        for (int c = 1; c <= C; ++c) {
+            float r = __fdiv_rn((float)hist[c], inv);
+            if (r > best) { best = r; arg = c; }
+        }
+        long long o = arg;
+        if (arg == C) o = ignore_label;
+        if (best < min_ratio) o = ignore_label;
+        label_ds[cell] = o;
+        if (o != ignore_label) atomicAdd(&cnt[(int)o], 1.0f);
+    }
+}
+
+// one wavefront per (image, channel) row of hw features; per-class sums, one atomic per class
+template <int C>
+__global__ void __launch_bounds__(256) proto_accum_kernel(const float* __restrict__ feat,
+                                                          const int64_t* __restrict__ label_ds, float* sums, int K,
+                                                          int hw, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // b*K + k
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int b = row / K, k = row % K;
+    const float* f = feat + (size_t)row * hw;
+    const int64_t* l = label_ds + (size_t)b * hw;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    for (int p = lane; p < hw; p += 64) {
+        float v = f[p];
+        int c0 = (int)l[p];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] += (c0 == c) ? v : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float s = wave_sum(acc[c]);
+        if (lane == 0 && s != 0.f) atomicAdd(&sums[(size_t)c * K + k], s);
+    }
+}
+
+__global__ void __launch_bounds__(256) proto_finalize_kernel(float* protos, const float* __restrict__ sums,
+                                                             const float* __restrict__ cnt, int K, int total,
+                                                             float one_minus_decay, float decay) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float n = cnt[i / K];
+    float old = protos[i];
+    float local = __fdiv_rn(sums[i], __fadd_rn(n, 1e-7f));
+    if (n < 1.f) local = old;
+    protos[i] = __fadd_rn(__fmul_rn(one_minus_decay, local), __fmul_rn(decay, old));
+}
+
+extern "C" size_t rgda_proto_update_workspace(int c, int k) { return ((size_t)c * k + c) * 4 + 16; }
+
+extern "C" int rgda_proto_update(const float* feat, const int64_t* label, float* protos, int64_t* label_ds, int b,
+                                 int k, int c, int h, int w, int scale, int ignore_label, float min_ratio,
+                                 float decay, void* ws, size_t ws_bytes, rgda_stream_t stream) {
+    if (!feat || !label || !protos || !label_ds || !ws) return RGDA_ERR_ARG;
+    if (c != 6) return RGDA_ERR_UNSUPPORTED;
+    if (b <= 0 || k <= 0 || h <= 0 || w <= 0 || scale <= 1 || !(decay > 0.f && decay < 1.f)) return RGDA_ERR_ARG;
+    if (ws_bytes < rgda_proto_update_workspace(c, k)) return RGDA_ERR_WORKSPACE;
+    hipStream_t st = to_stream(stream);
+    float* sums = (float*)ws;
+    float* cnt = sums + (size_t)c * k;
+    int* flag = (int*)(cnt + c);
+    if (hipMemsetAsync(ws, 0, rgda_proto_update_workspace(c, k), st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    downscale_label_kernel<<<b * h * w, 256, 0, st>>>(label, label_ds, cnt, flag, h, w, scale, c, ignore_label, min_ratio);
+    RGDA_CHECK_LAUNCH();
+    int rows = b * k;
+    proto_accum_kernel<6><<<cdiv(rows, 4), 256, 0, st>>>(feat, label_ds, sums, k, h * w, rows);
+    RGDA_CHECK_LAUNCH();
+    float omd = (float)(1.0 - (double)decay);
+    proto_finalize_kernel<<<cdiv((long long)c * k, 256), 256, 0, st>>>(protos, sums, cnt, k, c * k, omd, decay);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// loss_calc(multi=True) + CrossEntropy  (regda/utils/tools.py:240-254; regda/gast/balance.py:88-101)
+// forward and d(loss)/d(low-res logits) in one pass over the full-resolution pixels:
+//   stage 1 (one workgroup per output row): bilinear(ac=True) logits -> log-softmax -> loss
+//           partial; per-pixel gradient kept in LDS and contracted with the horizontal
+//           interpolation weights -> T[b][Y][head][c][x]
+//   stage 2: vertical contraction T -> g[head][b][c][y][x]; deterministic loss reduction.
+// --------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) upce_row_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                       const int64_t* __restrict__ label,
+                                                       const float* __restrict__ class_weight, float* partial,
+                                                       float* T, int h, int w, int H, int W, int ignore_label,
+                                                       float gscale, int want_grad) {
+    extern __shared__ float lds[];
+    // rows[2 heads][C][2][w] | G[2][C][W]
+    float* rows = lds;
+    float* G = lds + 2 * C * 2 * w;
+    const int b = blockIdx.y, Y = blockIdx.x;
+    const int hw = h * w;
+    Lerp ly = lerp_ac(Y, h, H);
+    for (int i = threadIdx.x; i < 2 * C * 2 * w; i += 256) {
+        int x = i % w, r = (i / w) & 1, c = (i / (2 * w)) % C, hd = i / (2 * w * C);
+        const float* p = hd ? p2 : p1;
+        rows[i] = p[((size_t)b * C + c) * hw + (r ? ly.i1 : ly.i0) * w + x];
+    }
+    __syncthreads();
+    float lsum0 = 0.f, lsum1 = 0.f;
+    for (int X = threadIdx.x; X < W; X += 256) {
+        Lerp lx = lerp_ac(X, w, W);
+        long long lab = label[((size_t)b * H + Y) * W + X];
+        bool valid = lab != ignore_label;
+        int li = valid ? (int)lab : 0;
+#pragma unroll
+        for (int hd = 0; hd < 2; ++hd) {
+            float z[C], m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float* r = rows + ((hd * C + c) * 2) * w;
+                float top = __fadd_rn(__fmul_rn(lx.l0, r[lx.i0]), __fmul_rn(lx.l1, r[lx.i1]));
+                float bot = __fadd_rn(__fmul_rn(lx.l0, r[w + lx.i0]), __fmul_rn(lx.l1, r[w + lx.i1]));
+                z[c] = __fadd_rn(__fmul_rn(ly.l0, top), __fmul_rn(ly.l1, bot));
+                m = fmaxf(m, z[c]);
+            }
+            float se = 0.f, e[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { e[c] = expf(z[c] - m); se += e[c]; }
+            float lse = m + logf(se);
+            float wgt = valid ? (class_weight ? class_weight[hd * C + li] : 1.f) : 0.f;
+            float zl = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) zl = (c == li) ? z[c] : zl;
+            float lp = valid ? (lse - zl) * wgt : 0.f;
+            if (hd == 0) lsum0 += lp; else lsum1 += lp;
+            if (want_grad) {
+                float gs = wgt * gscale;
+#pragma unroll
+                for (int c = 0; c < C; ++c) G[(hd * C + c) * W + X] = (e[c] / se - ((c == li) ? 1.f : 0.f)) * gs;
+            }
+        }
+    }
+    __shared__ float red[2][4];
+    lsum0 = wave_sum(lsum0); lsum1 = wave_sum(lsum1);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lsum0; red[1][threadIdx.x >> 6] = lsum1; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        partial[((size_t)b * H + Y) * 2 + threadIdx.x] =
+            red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (!want_grad) return;
+    // horizontal contraction: T[hd][c][x] = sum_X G[hd][c][X] * Rx[X][x]
+    const float inv_scale = (w > 1) ? (float)(W - 1) / (float)(w - 1) : 0.f;
+    for (int o = threadIdx.x; o < 2 * C * w; o += 256) {
+        int x = o % w, hc = o / w;
+        int lo = (w > 1) ? max(0, (int)floorf((float)(x - 1) * inv_scale) - 1) : 0;
+        int hi = (w > 1) ? min(W - 1, (int)ceilf((float)(x + 1) * inv_scale) + 1) : W - 1;
+        float acc = 0.f;
+        for (int X = lo; X <= hi; ++X) {
+            Lerp lx = lerp_ac(X, w, W);
+            float wt = ((lx.i0 == x) ? lx.l0 : 0.f) + ((lx.i1 == x) ? lx.l1 : 0.f);
+            acc += wt * G[hc * W + X];
+        }
+        T[(((size_t)b * H + Y) * 2 * C + hc) * w + x] = acc;
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) upce_col_kernel(const float* __restrict__ T, float* g1, float* g2, int b_n,
+                                                       int h, int w, int H) {
+    int i = blockIdx.x * 256 + threadIdx.x;           // over [hd][b][c][y][x]
+    int total = 2 * b_n * C * h * w;
+    if (i >= total) return;
+    int x = i % w, y = (i / w) % h, c = (i / (w * h)) % C, b = (i / (w * h * C)) % b_n, hd = i / (w * h * C * b_n);
+    const float inv_scale = (h > 1) ? (float)(H - 1) / (float)(h - 1) : 0.f;
+    int lo = (h > 1) ? max(0, (int)floorf((float)(y - 1) * inv_scale) - 1) : 0;
+    int hi = (h > 1) ? min(H - 1, (int)ceilf((float)(y + 1) * inv_scale) + 1) : H - 1;
+    float acc = 0.f;
+    for (int Y = lo; Y <= hi; ++Y) {
+        Lerp ly = lerp_ac(Y, h, H);
+        float wt = ((ly.i0 == y) ? ly.l0 : 0.f) + ((ly.i1 == y) ? ly.l1 : 0.f);
+        acc += wt * T[(((size_t)b * H + Y) * 2 * C + hd * C + c) * w + x];
+    }
+    float* g = hd ? g2 : g1;
+    g[(((size_t)b * C + c) * h + y) * w + x] = acc;
+}
+
+__global__ void __launch_bounds__(256) upce_loss_kernel(const float* __restrict__ partial, float* loss, int n,
+                                                        double inv_npix) {
+    // deterministic: fixed strided order, double accumulation
+    __shared__ double red[2][256];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { s0 += partial[2 * i]; s1 += partial[2 * i + 1]; }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float l0 = (float)(red[0][0] * inv_npix), l1 = (float)(red[1][0] * inv_npix);   // torch.mean per head
+        loss[0] = (l0 + l1) / 2.f;                                                       // loss / num (tools.py:252)
+    }
+}
+
+extern "C" size_t rgda_upsample_ce_workspace(int b, int c, int h, int w, int H, int W) {
+    (void)W;
+    return align256((size_t)b * H * 2 * 4) + (size_t)b * H * 2 * c * w * 4;
+}
+
+extern "C" int rgda_upsample_ce(const float* p1, const float* p2, const int64_t* label, const float* class_weight,
+                                float* loss, float* g1, float* g2, int b, int c, int h, int w, int H, int W,
+                                int ignore_label, void* ws, size_t ws_bytes, rgda_stream_t stream) {
+    if (!p1 || !p2 || !label || !loss || !ws || ((g1 == nullptr) != (g2 == nullptr))) return RGDA_ERR_ARG;
+    if (c != 6) return RGDA_ERR_UNSUPPORTED;
+    if (b <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return RGDA_ERR_ARG;
+    if (ws_bytes < rgda_upsample_ce_workspace(b, c, h, w, H, W)) return RGDA_ERR_WORKSPACE;
+    hipStream_t st = to_stream(stream);
+    float* partial = (float*)ws;
+    float* T = (float*)((char*)ws + align256((size_t)b * H * 2 * 4));
+    const int want = g1 != nullptr;
+    double npix = (double)b * H * W;
+    float gscale = (float)(0.5 / npix);
+    size_t lds = ((size_t)2 * 6 * 2 * w + (want ? (size_t)2 * 6 * W : 0)) * 4;
+    if (lds > 150 * 1024) return RGDA_ERR_UNSUPPORTED;
+    dim3 g(H, b);
+    upce_row_kernel<6><<<g, 256, lds, st>>>(p1, p2, label, class_weight, partial, T, h, w, H, W, ignore_label, gscale, want);
+    RGDA_CHECK_LAUNCH();
+    if (want) {
+        upce_col_kernel<6><<<cdiv((long long)2 * b * 6 * h * w, 256), 256, 0, st>>>(T, g1, g2, b, h, w, H);
+        RGDA_CHECK_LAUNCH();
+    }
+    upce_loss_kernel<<<1, 256, 0, st>>>(partial, loss, b * H, 1.0 / npix);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// teacher probabilities   (regda/models/Encoder.py:152-155)
+// --------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) teacher_probs_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                            float* __restrict__ probs, int h, int w, int H, int W) {
+    const int b = blockIdx.z, Y = blockIdx.y, X = blockIdx.x * 256 + threadIdx.x;
+    if (X >= W) return;
+    const int hw = h * w;
+    const size_t HW = (size_t)H * W;
+    Lerp ly = lerp_ac(Y, h, H), lx = lerp_ac(X, w, W);
+    float z1[C], z2[C], m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        size_t off = ((size_t)b * C + c) * hw;
+        z1[c] = bilerp(p1 + off, w, ly, lx);
+        z2[c] = bilerp(p2 + off, w, ly, lx);
+        m1 = fmaxf(m1, z1[c]); m2 = fmaxf(m2, z2[c]);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { z1[c] = expf(z1[c] - m1); z2[c] = expf(z2[c] - m2); s1 += z1[c]; s2 += z2[c]; }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+        probs[((size_t)b * C + c) * HW + (size_t)Y * W + X] = (z1[c] / s1 + z2[c] / s2) / 2.f;
+}
+
+extern "C" int rgda_teacher_probs(const float* p1, const float* p2, float* probs, int b, int c, int h, int w, int H,
+                                  int W, rgda_stream_t stream) {
+    if (!p1 || !p2 || !probs || b <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return RGDA_ERR_ARG;
+    if (c != 6) return RGDA_ERR_UNSUPPORTED;
+    dim3 g(cdiv(W, 256), H, b);
+    teacher_probs_kernel<6><<<g, 256, 0, to_stream(stream)>>>(p1, p2, probs, h, w, H, W);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// ClassBalance._local_freq counts  (regda/gast/balance.py:45-53)
+// --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) class_count_kernel(const int64_t* __restrict__ label, int* cnt, long long n,
+                                                          int C) {
+    __shared__ int h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        long long l = label[i];
+        if (l >= 0 && l < C) atomicAdd(&h[(int)l], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < C && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
+}
+
+extern "C" int rgda_class_count(const int64_t* label, int32_t* cnt, int64_t n, int c, rgda_stream_t stream) {
+    if (!label || !cnt || n < 0 || c <= 0 || c > 16) return RGDA_ERR_ARG;
+    if (n == 0) return RGDA_OK;
+    class_count_kernel<<<min(cdiv(n, 256 * 8), 2048), 256, 0, to_stream(stream)>>>(label, cnt, n, c);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}

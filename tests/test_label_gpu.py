@@ -1,0 +1,184 @@
+"""GPU parity of the label path (pseudo_selection, LRH, label_refine, update_prototype, loss, teacher)
+through the C ABI, against the golden vectors of the reference and against the oracle on seeded
+inputs.  Integer results must be bit-identical; float tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import labels as olab
+from oracle import labelpath as opath
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def mods():
+    from regda_amd.utils.local_region_homog import Homogenizer
+    from regda_amd.gast.pseudo_generation import pseudo_selection
+    from regda_amd.gast.alignment import Aligner, DownscaleLabel
+    from regda_amd.gast.balance import CrossEntropy, ClassBalance
+    from regda_amd.utils.tools import loss_calc
+    from regda_amd import ops
+    import types
+    return types.SimpleNamespace(**locals())
+
+
+def cu(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.to(dt)
+    return t.cuda()
+
+
+def test_lrh_golden_bit_exact(mods, gold):
+    g = gold('lrh.npz')
+    for i in range(int(g['n'])):
+        h = mods.Homogenizer(percent=float(g[f'pct{i}']), class_num=6, ignore_label=-1)
+        out = h(cu(g[f'lab{i}'], torch.int64), cu(g[f'reg{i}'], torch.int64)).cpu().numpy()
+        assert np.array_equal(out, g[f'out{i}'].astype(np.int64)), f'golden case {i}'
+
+
+@pytest.mark.parametrize('shape,nreg', [((8, 512, 512), 250), ((2, 512, 512), 3000), ((1, 7, 5), 3), ((3, 100, 37), 60)])
+def test_lrh_vs_oracle_seeded(mods, shape, nreg):
+    rng = np.random.default_rng(123)
+    b, h, w = shape
+    regs = np.zeros(shape, np.int64)
+    for i in range(b):
+        for r in range(1, nreg + 1):
+            y0, x0 = rng.integers(0, h), rng.integers(0, w)
+            regs[i, y0:y0 + rng.integers(1, max(2, h // 4)), x0:x0 + rng.integers(1, max(2, w // 4))] = r
+    lab = rng.integers(-1, 6, size=shape).astype(np.int64)
+    blk = np.kron(rng.integers(-1, 6, size=(b, (h + 31) // 32, (w + 31) // 32)), np.ones((32, 32), np.int64))[:, :h, :w]
+    lab = np.where(rng.random(shape) < 0.85, blk, lab)
+    h_ = mods.Homogenizer(percent=0.5, class_num=6, ignore_label=-1)
+    out = h_(cu(lab), cu(regs)).cpu().numpy()
+    assert np.array_equal(out, olab.homogenize(lab, regs, 0.5, 6, -1))
+    # properties at full size: idempotent on homogenised regions, region 0 untouched
+    assert np.array_equal(out[regs == 0], lab[regs == 0])
+    out2 = h_(cu(out), cu(regs)).cpu().numpy()
+    changed = out != lab
+    assert np.array_equal(out2[changed], out[changed])
+
+
+def test_lrh_errors_and_empty(mods):
+    h = mods.Homogenizer(percent=0.5, class_num=6, ignore_label=-1, max_regions=8)
+    lab = torch.zeros((1, 4, 4), dtype=torch.int64, device='cuda')
+    reg = torch.full((1, 4, 4), 9, dtype=torch.int64, device='cuda')
+    with pytest.raises(ValueError):
+        h(lab, reg)
+    with pytest.raises(AssertionError):
+        h(lab[0], reg[0])
+    with pytest.raises(RuntimeError):
+        h(lab.cpu(), reg.cpu())
+    e = h(torch.zeros((2, 0, 4), dtype=torch.int64, device='cuda'), torch.zeros((2, 0, 4), dtype=torch.int64, device='cuda'))
+    assert e.shape == (2, 0, 4)
+
+
+def test_pseudo_selection_golden_bit_exact(mods, gold):
+    g = gold('pseudo.npz')
+    for i in range(int(g['n'])):
+        out = mods.pseudo_selection(cu(g[f'in{i}']), 0.8, 0.6, 'tensor', -1).cpu().numpy()
+        assert np.array_equal(out, g[f'out{i}'].astype(np.int64)), f'golden case {i}'
+    nd = mods.pseudo_selection(cu(g['in0']), 0.8, 0.6, 'ndarray', -1)
+    assert isinstance(nd, np.ndarray)
+    with pytest.raises(AssertionError):
+        mods.pseudo_selection(torch.full((1, 6, 4, 4), 1.5, device='cuda'), 0.8, 0.6, 'tensor', -1)
+
+
+def test_pseudo_selection_full_size(mods):
+    g = torch.Generator().manual_seed(5)
+    soft = torch.softmax(torch.randn(8, 6, 512, 512, generator=g) * 3, 1)
+    out = mods.pseudo_selection(soft.cuda(), 0.8, 0.6, 'tensor', -1).cpu().numpy()
+    assert np.array_equal(out, olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1))
+
+
+def test_downscale_and_prototypes_golden(mods, gold):
+    g = gold('downscale.npz')
+    ds = mods.DownscaleLabel(16, 6, -1, 0.75)(cu(g['lab'], torch.int64)).cpu().numpy()
+    assert np.array_equal(ds, g['out'].astype(np.int64))
+    g = gold('refine.npz')
+    al = mods.Aligner(None, feat_channels=64, class_num=6, ignore_label=-1, decay=0.996)
+    al.prototypes = cu(g['protos']).clone()
+    ds = al.update_prototype(cu(g['feat_s']), cu(g['lab_s'], torch.int64))
+    assert np.array_equal(ds.cpu().numpy(), g['ds'].astype(np.int64))
+    # fp32 sums in a different order than the reference's (n,c,k) broadcast-sum: 1e-5 relative
+    np.testing.assert_allclose(al.prototypes.cpu().numpy(), g['protos_new'], rtol=1e-5, atol=1e-6)
+
+
+def test_label_refine_golden(mods, gold):
+    g = gold('refine.npz')
+    al = mods.Aligner(None, feat_channels=64, class_num=6, ignore_label=-1, decay=0.996)
+    al.prototypes = cu(g['protos']).clone()
+    out = al.label_refine(None, cu(g['feat_t']), [cu(g['p1']), cu(g['p2'])], cu(g['soft']), True, 'all', 2.0)
+    # tolerance: fp32 with a different summation order in the k=64 Pearson contraction and fma
+    # contraction in the interpolation; the 1/dist ~ 1e7 pixel saturates the softmax either way
+    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=2e-4, atol=2e-6)
+
+
+def test_label_refine_full_size_vs_oracle(mods):
+    g = torch.Generator().manual_seed(11)
+    b, k, h, w = 2, 2048, 32, 32
+    feat = torch.randn(b, k, h, w, generator=g)
+    protos = torch.randn(6, k, generator=g)
+    p1, p2 = torch.randn(b, 6, h, w, generator=g) * 2, torch.randn(b, 6, h, w, generator=g) * 2
+    soft = torch.softmax(torch.randn(b, 6, 512, 512, generator=g) * 3, 1)
+    ref = opath.label_refine(feat, protos, [p1, p2], soft)
+    al = mods.Aligner(None, feat_channels=k, class_num=6, ignore_label=-1, decay=0.996)
+    al.prototypes = protos.cuda()
+    out = al.label_refine(None, feat.cuda(), [p1.cuda(), p2.cuda()], soft.cuda(), True, 'all', 2.0).cpu()
+    # 1/dist amplifies the fp32 rounding of the 2048-term contraction (dist ~ 0.5 -> sim ~ 2):
+    # stated tolerance 5e-4 relative on probabilities
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=5e-4, atol=1e-6)
+    # the per-class maxima handed to pseudo_selection equal the maxima of the output
+    cm = al._classmax_ws[:b * 6 * 4].view(torch.float32).cpu().reshape(b, 6)
+    assert torch.equal(cm, out.flatten(2).max(-1)[0])
+
+
+def test_loss_golden_and_grad(mods, gold):
+    g = gold('loss.npz')
+    p1, p2 = cu(g['p1']).requires_grad_(True), cu(g['p2']).requires_grad_(True)
+    lab = cu(g['lab'], torch.int64)
+    ce = mods.CrossEntropy(ignore_label=-1, class_balancer=None)
+    loss = mods.loss_calc([p1, p2], lab, loss_fn=ce, multi=True)
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g['loss']), rel=2e-6)
+    np.testing.assert_allclose(p1.grad.cpu().numpy(), g['g1'], rtol=2e-4, atol=1e-8)
+    np.testing.assert_allclose(p2.grad.cpu().numpy(), g['g2'], rtol=2e-4, atol=1e-8)
+    cb = mods.ClassBalance(class_num=6, ignore_label=-1, decay=0.99, temperature=2.0)
+    ceb = mods.CrossEntropy(ignore_label=-1, class_balancer=cb)
+    q1, q2 = cu(g['p1']).requires_grad_(True), cu(g['p2']).requires_grad_(True)
+    lossb = mods.loss_calc([q1, q2], lab, loss_fn=ceb, multi=True)
+    lossb.backward()
+    assert lossb.item() == pytest.approx(float(g['lossb']), rel=2e-6)
+    np.testing.assert_allclose(cb.freq.cpu().numpy(), g['freq'], rtol=1e-6)
+    np.testing.assert_allclose(q1.grad.cpu().numpy(), g['gb1'], rtol=2e-4, atol=1e-8)
+
+
+def test_loss_full_size_vs_oracle(mods):
+    g = torch.Generator().manual_seed(3)
+    b = 4
+    p1 = (torch.randn(b, 6, 32, 32, generator=g) * 2).requires_grad_(True)
+    p2 = (torch.randn(b, 6, 32, 32, generator=g) * 2).requires_grad_(True)
+    lab = torch.randint(-1, 6, (b, 512, 512), generator=g)
+    ref = opath.loss_calc([p1, p2], lab, -1)
+    ref.backward()
+    q1, q2 = p1.detach().cuda().requires_grad_(True), p2.detach().cuda().requires_grad_(True)
+    ce = mods.CrossEntropy(ignore_label=-1)
+    loss = mods.loss_calc([q1, q2], lab.cuda(), loss_fn=ce, multi=True)
+    loss.backward()
+    assert loss.item() == pytest.approx(ref.item(), rel=1e-5)
+    np.testing.assert_allclose(q1.grad.cpu().numpy(), p1.grad.numpy(), rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(q2.grad.cpu().numpy(), p2.grad.numpy(), rtol=1e-3, atol=1e-9)
+    # single full-resolution prediction through CrossEntropy.forward (identity upsample)
+    z = torch.randn(1, 6, 24, 40, generator=g)
+    l2 = torch.randint(-1, 6, (1, 24, 40), generator=g)
+    r2 = opath.cross_entropy_mean(z, l2, -1)
+    assert ce(z.cuda(), l2.cuda()).item() == pytest.approx(r2.item(), rel=1e-5)
+
+
+def test_teacher_probs_vs_oracle(mods):
+    g = torch.Generator().manual_seed(8)
+    p1, p2 = torch.randn(2, 6, 32, 32, generator=g) * 3, torch.randn(2, 6, 32, 32, generator=g) * 3
+    ref = opath.teacher_probs(p1, p2, (512, 512))
+    out = mods.ops.teacher_probs(p1.cuda(), p2.cuda(), (512, 512)).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)

@@ -1,0 +1,197 @@
+"""Headline benchmark: src+tgt 512x512 image-pairs/sec for one full RegDA self-training (SSL) step
+(BASELINE.json metric; config st.regda.2potsdam, ResNet-101 DeepLabV2/PPM, batch 8+8 per GPU, bf16 MFMA
+compute with fp32 accumulate, online EMA teacher) on N MI355X GPUs, one process per GPU over RCCL.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  A step = model(src), model(tgt), EMA-teacher forward on tgt, label_refine,
+pseudo_selection, LRH, update_prototype, 2x loss, backward of both passes, grad all-reduce, clip + SGD +
+EMA: nothing is skipped inside the timed region.  `roofline` is measured live with HIP events around
+every conv launch of one extra (untimed) step; `cpu_baseline` times the CPU oracle (stock PyTorch fp32)
+on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_PAIR_STUDENT = 1087.0     # (fwd + dgrad + wgrad) x (src + tgt) conv FLOPs
+GFLOP_PER_PAIR_TEACHER = 181.17     # + one eval forward of the EMA teacher on the target image
+MFMA_PEAK_TFLOPS = 2500.0           # bf16 dense, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='source (= target) images per GPU')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--model', default='resnet101')
+    ap.add_argument('--no-teacher', action='store_true', help='offline soft labels (the reference\'s mode) instead of the online EMA teacher')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2)
+    return ap.parse_args()
+
+
+def conv_flops_probe(step_fn):
+    """Run one step with HIP events around every conv launch; returns (total GFLOP, total ms, per-kind dict)."""
+    import torch
+    from regda_amd import ops
+    rec = []
+    o_conv, o_wgrad = ops.conv2d, ops.conv2d_wgrad
+
+    def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats)
+        e1.record()
+        co, taps, ci = w.shape
+        rec.append(('dgrad' if mode else 'fwd', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1))
+
+    def wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil)
+        e1.record()
+        co, taps, ci = dw.shape
+        rec.append(('wgrad', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1))
+    ops.conv2d, ops.conv2d_wgrad = conv, wgrad
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d, ops.conv2d_wgrad = o_conv, o_wgrad
+    kinds = {}
+    for kind, fl, e0, e1 in rec:
+        k = kinds.setdefault(kind, [0.0, 0.0, 0])
+        k[0] += fl
+        k[1] += e0.elapsed_time(e1)
+        k[2] += 1
+    tot_f = sum(k[0] for k in kinds.values())
+    tot_ms = sum(k[1] for k in kinds.values())
+    return tot_f / 1e9, tot_ms, {k: dict(gflop=v[0] / 1e9, ms=v[1], launches=v[2],
+                                         tflops=v[0] / 1e9 / max(v[1], 1e-9)) for k, v in kinds.items()}
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/step.py: the reference's step restated in stock PyTorch fp32) on a bounded
+    sample: b = cpu_batch + cpu_batch images, 1 warm-up + timed steps until ~20 s."""
+    import torch
+    from oracle import model as omodel
+    from oracle.step import CpuStep
+    from regda_amd.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    b = args.cpu_batch
+    batch = make_batch(b=b, size=args.size, seed=2333, device='cpu')
+    sd = omodel.init_state_dict(args.model, 6, seed=0)
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
+    st = CpuStep(sd, protos, resnet_type=args.model)
+    run = lambda: st.step(batch['images_s'], batch['label_s'], batch['images_t'], batch['soft_t'], batch['regs_t'], lr=1e-4)
+    t0 = time.time()
+    run()
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 1 or (time.time() - t0 < 15.0 and n < 5):
+        run()
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=b / dt, unit='pairs/s', cores=threads, kind='port',
+                sample=f'oracle/step.py (stock PyTorch CPU fp32, offline soft labels), {args.model}, b={b}+{b} {args.size}x{args.size}, '
+                       f'{n} timed step(s) after 1 warm-up ({warm:.1f}s), {dt:.2f} s/step')
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    from regda_amd.models.Encoder import Deeplabv2
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    from regda_amd.utils.tools import lr_poly, lr_warmup
+
+    torch.manual_seed(2333)
+    model = Deeplabv2(dict(backbone=dict(resnet_type=args.model, output_stride=16, pretrained=False),
+                           multi_layer=True, cascade=False, use_ppm=True,
+                           ppm=dict(num_classes=6, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=6,
+                           is_ins_norm=True))
+    if world > 1:       # identical initial weights on every rank
+        dist.broadcast(model.flat_p, 0)
+        dist.broadcast(model.flat_buf, 0)
+        model.sync_weights()
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
+    teacher = not args.no_teacher
+    step = SSLStep(model, protos, ema_decay=0.999 if teacher else None)
+    batch = make_batch(b=args.batch, size=args.size, seed=2333 + rank, with_soft=not teacher)
+    soft = batch.get('soft_t')
+    it = [0]
+
+    def one():
+        i = it[0]
+        lr = lr_warmup(1e-2, i, 300) if i < 300 else lr_poly(1e-2, i, 9000, 0.9)   # tools.py:191-207
+        it[0] += 1
+        return step.step(batch['images_s'], batch['label_s'], batch['images_t'], soft, batch['regs_t'], lr)
+
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = [float(x.item()) for x in out]
+    pairs = args.batch * world * args.steps
+    value = pairs / dt
+    gflop_pair = GFLOP_PER_PAIR_STUDENT + (GFLOP_PER_PAIR_TEACHER if teacher else 0.0)
+    res = {
+        'metric': 'src+tgt 512x512 image-pairs/sec (SSL step)', 'value': value, 'unit': 'pairs/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f'st.regda.2potsdam SSL step, {args.model} DeepLabV2(PPM), batch {args.batch}+{args.batch} '
+                               f'{args.size}x{args.size} per GPU, ' + ('online EMA teacher' if teacher else 'offline soft labels'),
+                   'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'gflop_per_pair': gflop_pair},
+        'pairs_per_sec_per_gpu': value / world,
+        'step_mfma_frac': value / world * gflop_pair / (MFMA_PEAK_TFLOPS * 1e3),
+        'loss_source': losses[0], 'loss_target': losses[1],
+    }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        gf, ms, kinds = conv_flops_probe(one)
+        res['roofline'] = {'bound': 'mfma', 'achieved': gf / ms, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': gf / ms / MFMA_PEAK_TFLOPS, 'traffic': None,
+                           'kernel': 'conv_igemm_kernel + conv_wgrad_kernel (all conv launches of one step, HIP events)',
+                           'gflop_per_step': gf, 'conv_ms_per_step': ms, 'by_kind': kinds}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -215,6 +215,10 @@ int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf1
 /* w [Co][T][Ci] f32 -> wt [Ci][T][Co] bf16 (weights for the data-gradient pass). */
 int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, rgda_stream_t stream);
 int rgda_cast_bf16(const float* src, void* dst, int64_t n, rgda_stream_t stream);
+/* rows of K f32 -> rows of Kp bf16, zero padded (stem weights [64][147] -> [64][192]); and the
+ * reverse accumulation dst[R][K] f32 += src[R][Kp] f32 for the stem weight gradient. */
+int rgda_pad_cast_bf16(const float* src, void* dst, int R, int K, int Kp, rgda_stream_t stream);
+int rgda_unpad_acc_f32(const float* src, float* dst, int R, int K, int Kp, rgda_stream_t stream);
 /* out = a + b (bf16, PxC) */
 int rgda_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t M,
                   int C, rgda_stream_t stream);

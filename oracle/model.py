@@ -12,7 +12,8 @@ reference model, to this oracle and to the HIP path.
 import torch
 import torch.nn.functional as F
 
-LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3)}
+LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3),
+          'resnet17t': (2, 1, 1, 2)}   # resnet17t: test-only shallow topology (same code paths, 6 blocks)
 POOL_SCALES = (1, 2, 3, 6)
 
 
@@ -32,10 +33,20 @@ def layer_specs(resnet_type='resnet101'):
     return specs
 
 
-def init_state_dict(resnet_type='resnet101', num_classes=6, seed=0, dtype=torch.float32):
+def init_state_dict(resnet_type='resnet101', num_classes=6, seed=0, dtype=torch.float32, res_gamma=0.1,
+                    ppm0_gamma=0.0):
     """Seeded random weights in the reference layout: conv kaiming_normal(fan_out)
     (_resnets.py:164-169), BN gamma ~ U(0.5,1.5), beta ~ N(0,0.1) (non-trivial on
-    purpose so affine terms are exercised), running stats (0,1)."""
+    purpose so affine terms are exercised), running stats (0,1).  The last BN of every
+    residual branch (bn3) is scaled by `res_gamma`: with O(1) residual gains a 101-layer
+    random net is chaotic (rounding the weights to bf16 alone moves the fp32 logits by
+    ~70 %), with 0.1 it is as well conditioned as a trained network (~2 %), which is
+    what a bf16-vs-fp32 parity tolerance can be stated against.
+    ppm0_gamma scales the BN weight of the scale-1 PPM branch: that branch pools an
+    instance-normalised map globally, i.e. its input is exactly 0 up to rounding noise in
+    the reference itself, and its BatchNorm (2..8 samples) turns that noise into +-gamma;
+    no two implementations (or two cuDNN algorithms) agree on it, so parity fixtures set
+    gamma to 0 there (the branch then contributes relu(beta), a constant)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
@@ -45,8 +56,8 @@ def init_state_dict(resnet_type='resnet101', num_classes=6, seed=0, dtype=torch.
         if bias:
             sd[name + '.bias'] = torch.randn(co, generator=g, dtype=dtype) * 0.1
 
-    def bn(name, c):
-        sd[name + '.weight'] = torch.rand(c, generator=g, dtype=dtype) + 0.5
+    def bn(name, c, scale=1.0):
+        sd[name + '.weight'] = (torch.rand(c, generator=g, dtype=dtype) + 0.5) * scale
         sd[name + '.bias'] = torch.randn(c, generator=g, dtype=dtype) * 0.1
         sd[name + '.running_mean'] = torch.zeros(c, dtype=dtype)
         sd[name + '.running_var'] = torch.ones(c, dtype=dtype)
@@ -57,12 +68,12 @@ def init_state_dict(resnet_type='resnet101', num_classes=6, seed=0, dtype=torch.
     for p, inpl, planes, stride, dil, ds in layer_specs(resnet_type):
         conv(p + '.conv1', planes, inpl, 1); bn(p + '.bn1', planes)
         conv(p + '.conv2', planes, planes, 3); bn(p + '.bn2', planes)
-        conv(p + '.conv3', planes * 4, planes, 1); bn(p + '.bn3', planes * 4)
+        conv(p + '.conv3', planes * 4, planes, 1); bn(p + '.bn3', planes * 4, res_gamma)
         if ds:
             conv(p + '.downsample.0', planes * 4, inpl, 1); bn(p + '.downsample.1', planes * 4)
     for head in ('layer5', 'layer6'):
         for i in range(4):
-            conv(f'{head}.ppm.{i}.1', 512, 2048, 1); bn(f'{head}.ppm.{i}.2', 512)
+            conv(f'{head}.ppm.{i}.1', 512, 2048, 1); bn(f'{head}.ppm.{i}.2', 512, ppm0_gamma if i == 0 else 1.0)
         conv(f'{head}.conv_last.0', 512, 2048 + 4 * 512, 3); bn(f'{head}.conv_last.1', 512)
         conv(f'{head}.conv_last.4', num_classes, 512, 1, bias=True)
     return sd
@@ -82,9 +93,22 @@ def _bn(x, sd, name, training, new_stats):
     return F.batch_norm(x, rm, rv, w, b, False, 0.1, 1e-5)
 
 
+def _rb(x):
+    """Round to bf16 with a straight-through gradient (used by emulate_bf16)."""
+    return x + (x.to(torch.bfloat16).float() - x).detach()
+
+
 def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_stats=None,
-            taps=None):
+            taps=None, emulate_bf16=False):
     """Train: (x1, x2, feat).  Eval: per-pixel class probabilities at input size.
+
+    emulate_bf16: numerics model of the HIP path -- conv weights/inputs and every stored
+    activation are rounded to bf16 at the points where regda_amd stores bf16 (conv output,
+    BN/ReLU output, pooled / upsampled / instance-normalised tensors); accumulation stays
+    fp32 and the rounding has a straight-through gradient.  A 101-layer random net turns a
+    2^-9 relative perturbation into ~25 % gradient changes (measured, DESIGN.md "Parity"),
+    so gradients of a bf16 pipeline can only be compared tightly against this model; the
+    plain fp32 path (emulate_bf16=False) is the reference semantics.
 
     drop_masks: optional (m5, m6), each (b,512) of {0,1}: the Dropout2d(0.1)
     channel keep-masks of the two heads (Encoder.py:39); kept channels are
@@ -97,40 +121,48 @@ def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_
             taps[name] = t
         return t
 
-    y = F.conv2d(x, sd['encoder.resnet.conv1.weight'], None, 2, 3)
-    y = F.relu(_bn(y, sd, 'encoder.resnet.bn1', training, new_stats))
+    rb = _rb if emulate_bf16 else (lambda t: t)
+    if emulate_bf16:
+        sd = {k: (_rb(v) if (v.dim() == 4 and 'conv_last.4' not in k) else v) for k, v in sd.items()}
+        x = _rb(x)
+    y = rb(F.conv2d(x, sd['encoder.resnet.conv1.weight'], None, 2, 3))
+    y = rb(F.relu(_bn(y, sd, 'encoder.resnet.bn1', training, new_stats)))
     tap('stem', y)
     y = F.max_pool2d(y, 3, 2, 1)
     tap('pool', y)
     for p, inpl, planes, stride, dil, ds in layer_specs(resnet_type):
         idt = y
-        o = F.conv2d(y, sd[p + '.conv1.weight'])
-        o = F.relu(_bn(o, sd, p + '.bn1', training, new_stats))
-        o = F.conv2d(o, sd[p + '.conv2.weight'], None, stride, dil, dil)
-        o = F.relu(_bn(o, sd, p + '.bn2', training, new_stats))
-        o = F.conv2d(o, sd[p + '.conv3.weight'])
+        o = rb(F.conv2d(y, sd[p + '.conv1.weight']))
+        o = rb(F.relu(_bn(o, sd, p + '.bn1', training, new_stats)))
+        o = rb(F.conv2d(o, sd[p + '.conv2.weight'], None, stride, dil, dil))
+        o = rb(F.relu(_bn(o, sd, p + '.bn2', training, new_stats)))
+        o = rb(F.conv2d(o, sd[p + '.conv3.weight']))
         o = _bn(o, sd, p + '.bn3', training, new_stats)
         if ds:
-            idt = F.conv2d(y, sd[p + '.downsample.0.weight'], None, stride)
-            idt = _bn(idt, sd, p + '.downsample.1', training, new_stats)
-        y = F.relu(o + idt)
+            idt = rb(F.conv2d(y, sd[p + '.downsample.0.weight'], None, stride))
+            idt = rb(_bn(idt, sd, p + '.downsample.1', training, new_stats))
+        y = rb(F.relu(o + idt))
         tap(p, y)
     feat = F.instance_norm(y, eps=1e-5)                       # Encoder.py:123,146-147
     tap('feat', feat)
+    featq = rb(feat)
     outs = []
     for hi, head in enumerate(('layer5', 'layer6')):
         size = feat.shape[-2:]
-        parts = [feat]
+        parts = [featq]
         for i, s in enumerate(POOL_SCALES):
-            q = F.adaptive_avg_pool2d(feat, s)
-            q = F.conv2d(q, sd[f'{head}.ppm.{i}.1.weight'])
-            q = F.relu(_bn(q, sd, f'{head}.ppm.{i}.2', training, new_stats))
-            parts.append(F.interpolate(q, size, mode='bilinear', align_corners=False))
+            q = rb(F.adaptive_avg_pool2d(featq, s))
+            q = rb(F.conv2d(q, sd[f'{head}.ppm.{i}.1.weight']))
+            q = rb(F.relu(_bn(q, sd, f'{head}.ppm.{i}.2', training, new_stats)))
+            tap(f'{head}.q{i}', q)
+            parts.append(rb(F.interpolate(q, size, mode='bilinear', align_corners=False)))
         cat = torch.cat(parts, 1)
-        o = F.conv2d(cat, sd[f'{head}.conv_last.0.weight'], None, 1, 1)
+        tap(head + '.cat', cat)
+        o = rb(F.conv2d(cat, sd[f'{head}.conv_last.0.weight'], None, 1, 1))
         o = F.relu(_bn(o, sd, f'{head}.conv_last.1', training, new_stats))
         if training and drop_masks is not None:
             o = o * (drop_masks[hi].to(o.dtype) / 0.9)[:, :, None, None]
+        o = rb(o)
         tap(head + '.hidden', o)
         o = F.conv2d(o, sd[f'{head}.conv_last.4.weight'], sd[f'{head}.conv_last.4.bias'])
         outs.append(o)

@@ -1,0 +1,759 @@
+// HBM-bound passes of the conv stack on PxC bf16 activations: BatchNorm (train) forward /
+// backward, InstanceNorm, MaxPool, the spatial linear maps of the PPM head, the stem im2col
+// and the 6-class classifier.  Every thread owns one 16-byte channel vector (8 bf16) and walks
+// rows, so global accesses are 16 B per lane and row-contiguous; per-channel parameters live in
+// registers; reductions are wave shuffle -> LDS -> one atomic per channel per workgroup.
+#include "common.h"
+
+// thread layout shared by the per-channel passes: VPB channel-vectors per block (<= 256),
+// RPB = 256 / VPB row lanes.
+struct RowLayout {
+    int vpr;     // vectors per row (C/8)
+    int vpb;     // vectors handled per block (power of two <= 256)
+    int rpb;     // row lanes per block
+};
+static RowLayout row_layout(int C) {
+    RowLayout L;
+    L.vpr = C / 8;
+    int v = 1;
+    while (v < L.vpr && v < 256) v <<= 1;
+    L.vpb = v;
+    L.rpb = 256 / v;
+    return L;
+}
+
+static __device__ __forceinline__ void load8(const bf16_t* p, float (&f)[8]) {
+    u16x8 v = *(const u16x8*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = bf2f(v[e]);
+}
+static __device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
+    u16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f2bf(f[e]);
+    *(u16x8*)p = v;
+}
+
+// reduce two 8-vectors over the row lanes of a block and atomically add to out0[c], out1[c]
+static __device__ __forceinline__ void block_reduce_atomic(float (&s)[8], float (&q)[8], int cvl, int rl, int vpb,
+                                                           int rpb, int cglobal, bool cok, float* out0, float* out1,
+                                                           float* lds) {
+    // lds: [rpb][vpb*8][2]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        lds[((rl * vpb + cvl) * 8 + e) * 2 + 0] = s[e];
+        lds[((rl * vpb + cvl) * 8 + e) * 2 + 1] = q[e];
+    }
+    __syncthreads();
+    if (rl == 0 && cok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < rpb; ++r) {
+                a += lds[((r * vpb + cvl) * 8 + e) * 2 + 0];
+                b += lds[((r * vpb + cvl) * 8 + e) * 2 + 1];
+            }
+            atomicAdd(out0 + cglobal + e, a);
+            atomicAdd(out1 + cglobal + e, b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ BN statistics (standalone)
+__global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict__ x, int ldx, float* stats,
+                                                       long long M, int C, int vpb, int rpb, int rows_per_block) {
+    __shared__ float lds[256 * 16];
+    const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
+    const int cg = (blockIdx.y * vpb + cvl) * 8;
+    const bool cok = cg < C;
+    float s[8] = {0}, q[8] = {0};
+    long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    if (cok)
+        for (long long r = r0 + rl; r < r1; r += rpb) {
+            float f[8];
+            load8(x + r * ldx + cg, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+        }
+    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, stats, stats + C, lds);
+}
+
+extern "C" int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, int C, rgda_stream_t stream) {
+    if (!x || !stats || M <= 0 || C <= 0 || (C & 7) || (ldx & 7)) return RGDA_ERR_ARG;
+    RowLayout L = row_layout(C);
+    int rows_per_block = 256;
+    while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 4096) rows_per_block *= 2;
+    dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
+    bn_stats_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, stats, M, C, L.vpb, L.rpb, rows_per_block);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// ------------------------------------------------------------------ BN finalize
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, float* mi, float* rm, float* rv,
+                                                          long long* nbt, double M, int C, float eps, float mom) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (stats) {
+        double mean = (double)stats[c] / M;
+        double var = (double)stats[C + c] / M - mean * mean;     // biased (normalisation)
+        if (var < 0) var = 0;
+        mi[c] = (float)mean;
+        mi[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rm) {
+            double unb = (M > 1) ? var * M / (M - 1.0) : var;   // unbiased (running update)
+            rm[c] = (1.f - mom) * rm[c] + mom * (float)mean;
+            rv[c] = (1.f - mom) * rv[c] + mom * (float)unb;
+        }
+        if (c == 0 && nbt) *nbt += 1;
+    } else {
+        mi[c] = rm[c];
+        mi[C + c] = 1.f / sqrtf(rv[c] + eps);
+    }
+}
+
+extern "C" int rgda_bn_finalize(const float* stats, float* mi, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum,
+                                rgda_stream_t stream) {
+    if (!mi || C <= 0 || (!stats && (!running_mean || !running_var))) return RGDA_ERR_ARG;
+    if (stats && M < 2) return RGDA_ERR_ARG;   // "Expected more than 1 value per channel when training"
+    bn_finalize_kernel<<<cdiv(C, 256), 256, 0, to_stream(stream)>>>(stats, mi, running_mean, running_var,
+                                                                      (long long*)num_batches_tracked, (double)M, C,
+                                                                      eps, momentum);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// ------------------------------------------------------------------ BN apply (forward)
+__global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                       const float* __restrict__ mi, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const bf16_t* __restrict__ res,
+                                                       int ldres, const float* __restrict__ nscale, int rpi,
+                                                       bf16_t* __restrict__ y, int ldy, long long M, int C, int relu,
+                                                       int vpb, int rpb, int rows_per_block) {
+    const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
+    const int cg = (blockIdx.y * vpb + cvl) * 8;
+    if (cg >= C) return;
+    float mean[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mean[e] = mi[cg + e];
+        sc[e] = mi[C + cg + e] * gamma[cg + e];
+        sh[e] = beta[cg + e];
+    }
+    long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (long long r = r0 + rl; r < r1; r += rpb) {
+        float f[8];
+        load8(x + r * ldx + cg, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean[e]) * sc[e] + sh[e];
+        if (res) {
+            float g[8];
+            load8(res + r * ldres + cg, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+        }
+        if (nscale) {
+            const float* ns = nscale + (r / rpi) * C + cg;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= ns[e];
+        }
+        store8(y + r * ldy + cg, f);
+    }
+}
+
+static void elementwise_grid(long long M, int C, RowLayout& L, int& rows_per_block, dim3& grid) {
+    L = row_layout(C);
+    rows_per_block = L.rpb * 8;
+    while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 8192) rows_per_block *= 2;
+    grid = dim3(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
+}
+
+extern "C" int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, const float* beta,
+                             const void* res, int ldres, const float* nscale, int rows_per_image, void* y, int ldy,
+                             int64_t M, int C, int relu, rgda_stream_t stream) {
+    if (!x || !mi || !gamma || !beta || !y || M <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7)) return RGDA_ERR_ARG;
+    if (res && (ldres & 7)) return RGDA_ERR_ARG;
+    if (nscale && rows_per_image <= 0) return RGDA_ERR_ARG;
+    RowLayout L; int rpbk; dim3 grid;
+    elementwise_grid(M, C, L, rpbk, grid);
+    bn_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, mi, gamma, beta, (const bf16_t*)res,
+                                                          ldres, nscale, rows_per_image, (bf16_t*)y, ldy, M, C, relu,
+                                                          L.vpb, L.rpb, rpbk);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// ------------------------------------------------------------------ BN backward
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __restrict__ g, int ldg,
+                                                            const bf16_t* __restrict__ y, int ldy,
+                                                            const bf16_t* __restrict__ x, int ldx,
+                                                            const float* __restrict__ mi, const float* __restrict__ nscale,
+                                                            int rpi, float* sums, long long M, int C, int relu, int vpb,
+                                                            int rpb, int rows_per_block) {
+    __shared__ float lds[256 * 16];
+    const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
+    const int cg = (blockIdx.y * vpb + cvl) * 8;
+    const bool cok = cg < C;
+    float s[8] = {0}, q[8] = {0};
+    if (cok) {
+        float mean[8], istd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mean[e] = mi[cg + e]; istd[e] = mi[C + cg + e]; }
+        long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+        for (long long r = r0 + rl; r < r1; r += rpb) {
+            float gf[8], xf[8];
+            load8(g + r * ldg + cg, gf);
+            load8(x + r * ldx + cg, xf);
+            if (relu) {
+                float yf[8];
+                load8(y + r * ldy + cg, yf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+            }
+            if (nscale) {
+                const float* ns = nscale + (r / rpi) * C + cg;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += gf[e]; q[e] += gf[e] * ((xf[e] - mean[e]) * istd[e]); }
+        }
+    }
+    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, sums, sums + C, lds);
+}
+
+extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
+                                  const float* mi, const float* nscale, int rows_per_image, float* sums, int64_t M,
+                                  int C, int relu, rgda_stream_t stream) {
+    if (!g || !x || !mi || !sums || (relu && !y) || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || (ldx & 7)) return RGDA_ERR_ARG;
+    hipStream_t st = to_stream(stream);
+    if (hipMemsetAsync(sums, 0, (size_t)2 * C * 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    RowLayout L = row_layout(C);
+    int rows_per_block = 256;
+    while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 4096) rows_per_block *= 2;
+    dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
+    bn_bwd_reduce_kernel<<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mi,
+                                               nscale, rows_per_image, sums, M, C, relu, L.vpb, L.rpb, rows_per_block);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restrict__ g, int ldg,
+                                                           const bf16_t* __restrict__ y, int ldy,
+                                                           const bf16_t* __restrict__ x, int ldx,
+                                                           const float* __restrict__ mi, const float* __restrict__ gamma,
+                                                           const float* __restrict__ nscale, int rpi,
+                                                           const float* __restrict__ sums, bf16_t* __restrict__ dx,
+                                                           int lddx, bf16_t* __restrict__ gmask, int ldgm, float* dgamma,
+                                                           float* dbeta, long long M, int C, int relu, int vpb, int rpb,
+                                                           int rows_per_block) {
+    const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
+    const int cg = (blockIdx.y * vpb + cvl) * 8;
+    if (cg >= C) return;
+    float mean[8], istd[8], k0[8], k1[8], k2[8];
+    const float invM = 1.f / (float)M;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mean[e] = mi[cg + e];
+        istd[e] = mi[C + cg + e];
+        float gi = gamma[cg + e] * istd[e];
+        k0[e] = gi;
+        k1[e] = sums[cg + e] * invM;          // mean of g'
+        k2[e] = sums[C + cg + e] * invM;      // mean of g' * xhat
+    }
+    if (blockIdx.x == 0 && rl == 0 && dgamma) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dgamma[cg + e] += sums[C + cg + e];
+            dbeta[cg + e] += sums[cg + e];
+        }
+    }
+    long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (long long r = r0 + rl; r < r1; r += rpb) {
+        float gf[8], xf[8];
+        load8(g + r * ldg + cg, gf);
+        load8(x + r * ldx + cg, xf);
+        if (relu) {
+            float yf[8];
+            load8(y + r * ldy + cg, yf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+        }
+        if (nscale) {
+            const float* ns = nscale + (r / rpi) * C + cg;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
+        }
+        if (gmask) store8(gmask + r * ldgm + cg, gf);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = k0[e] * (gf[e] - k1[e] - (xf[e] - mean[e]) * istd[e] * k2[e]);
+        store8(dx + r * lddx + cg, o);
+    }
+}
+
+extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
+                                 const float* mi, const float* gamma, const float* nscale, int rows_per_image,
+                                 const float* sums, void* dx, int lddx, void* gmask, int ldgm, float* dgamma,
+                                 float* dbeta, int64_t M, int C, int relu, rgda_stream_t stream) {
+    if (!g || !x || !mi || !gamma || !sums || !dx || (relu && !y) || M <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
+    if ((ldg & 7) || (ldx & 7) || (lddx & 7) || (gmask && (ldgm & 7)) || ((dgamma == nullptr) != (dbeta == nullptr)))
+        return RGDA_ERR_ARG;
+    RowLayout L; int rpbk; dim3 grid;
+    elementwise_grid(M, C, L, rpbk, grid);
+    bn_bwd_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy,
+                                                              (const bf16_t*)x, ldx, mi, gamma, nscale, rows_per_image,
+                                                              sums, (bf16_t*)dx, lddx, (bf16_t*)gmask, ldgm, dgamma,
+                                                              dbeta, M, C, relu, L.vpb, L.rpb, rpbk);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// ------------------------------------------------------------------ MaxPool 3x3 / 2 / pad 1
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+    const int vpr = C / 8;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long total = (long long)N * Ho * Wo * vpr;
+    if (i >= total) return;
+    int cv = (int)(i % vpr);
+    long long p = i / vpr;
+    int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), n = (int)(p / ((long long)Wo * Ho));
+    float best[8];
+    unsigned char bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+    for (int kh = 0; kh < 3; ++kh) {
+        int hi = ho * 2 - 1 + kh;
+        if (hi < 0 || hi >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            int wi = wo * 2 - 1 + kw;
+            if (wi < 0 || wi >= W) continue;
+            float f[8];
+            load8(x + ((size_t)(n * H + hi) * W + wi) * C + cv * 8, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (first || f[e] > best[e]) { best[e] = f[e]; bi[e] = (unsigned char)(kh * 3 + kw); }
+            first = false;
+        }
+    }
+    store8(y + (size_t)p * C + cv * 8, best);
+    uint2 pk;
+    pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
+    pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
+    *(uint2*)(idx + (size_t)p * C + cv * 8) = pk;
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const bf16_t* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                          bf16_t* __restrict__ gx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+    const int vpr = C / 8;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long total = (long long)N * H * W * vpr;
+    if (i >= total) return;
+    int cv = (int)(i % vpr);
+    long long p = i / vpr;
+    int wi = (int)(p % W), hi = (int)((p / W) % H), n = (int)(p / ((long long)W * H));
+    float acc[8] = {0};
+    for (int ho = (hi) / 2; ho <= (hi + 1) / 2; ++ho) {
+        if (ho < 0 || ho >= Ho) continue;
+        int kh = hi - (ho * 2 - 1);
+        if (kh < 0 || kh > 2) continue;
+        for (int wo = (wi) / 2; wo <= (wi + 1) / 2; ++wo) {
+            if (wo < 0 || wo >= Wo) continue;
+            int kw = wi - (wo * 2 - 1);
+            if (kw < 0 || kw > 2) continue;
+            size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * 8;
+            uint2 pk = *(const uint2*)(idx + o);
+            float g[8];
+            load8(gy + o, g);
+            unsigned tapid = (unsigned)(kh * 3 + kw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned b = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+                if (b == tapid) acc[e] += g[e];
+            }
+        }
+    }
+    store8(gx + (size_t)p * C + cv * 8, acc);
+}
+
+extern "C" int rgda_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho, int Wo,
+                                rgda_stream_t stream) {
+    if (!x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
+    if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RGDA_ERR_ARG;
+    long long total = (long long)N * Ho * Wo * (C / 8);
+    maxpool_fwd_kernel<<<cdiv(total, 256), 256, 0, to_stream(stream)>>>((const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+extern "C" int rgda_maxpool_bwd(const void* gy, const uint8_t* idx, void* gx, int N, int H, int W, int C, int Ho,
+                                int Wo, rgda_stream_t stream) {
+    if (!gy || !gx || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
+    long long total = (long long)N * H * W * (C / 8);
+    maxpool_bwd_kernel<<<cdiv(total, 256), 256, 0, to_stream(stream)>>>((const bf16_t*)gy, idx, (bf16_t*)gx, N, H, W, C, Ho, Wo);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// ------------------------------------------------------------------ InstanceNorm2d (no affine)
+// block = (image n, 64 channels): 8 channel vectors x 32 pixel lanes.
+__global__ void __launch_bounds__(256) instnorm_fwd_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* y0, bf16_t* y1,
+                                                           int ldy, float* feat, float* mi, int HW, int C, float eps) {
+    __shared__ float lds[32 * 64 * 2];
+    __shared__ float tile[64][33];
+    const int n = blockIdx.y, c0 = blockIdx.x * 64;
+    const int cv = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int cg = c0 + cv * 8;
+    const bool cok = cg < C;
+    const bf16_t* xb = x + (size_t)n * HW * ldx;
+    float s[8] = {0}, q[8] = {0};
+    if (cok)
+        for (int p = rl; p < HW; p += 32) {
+            float f[8];
+            load8(xb + (size_t)p * ldx + cg, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        lds[(rl * 64 + cv * 8 + e) * 2] = s[e];
+        lds[(rl * 64 + cv * 8 + e) * 2 + 1] = q[e];
+    }
+    __syncthreads();
+    float mean[8], istd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < 32; ++r) { a += lds[(r * 64 + cv * 8 + e) * 2]; b += lds[(r * 64 + cv * 8 + e) * 2 + 1]; }
+        float m = a / (float)HW;
+        float var = fmaxf(b / (float)HW - m * m, 0.f);
+        mean[e] = m;
+        istd[e] = 1.f / sqrtf(var + eps);
+    }
+    if (rl == 0 && cok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mi[((size_t)n * 2 + 0) * C + cg + e] = mean[e];
+            mi[((size_t)n * 2 + 1) * C + cg + e] = istd[e];
+        }
+    }
+    for (int pb = 0; pb < HW; pb += 32) {
+        int p = pb + rl;
+        float f[8] = {0};
+        if (cok && p < HW) {
+            load8(xb + (size_t)p * ldx + cg, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean[e]) * istd[e];
+            size_t o = ((size_t)n * HW + p) * ldy + cg;
+            if (y0) store8(y0 + o, f);
+            if (y1) store8(y1 + o, f);
+        }
+        if (feat) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[cv * 8 + e][rl] = f[e];
+            __syncthreads();
+            int ch = threadIdx.x >> 2, part = threadIdx.x & 3;
+            if (c0 + ch < C) {
+                float* dst = feat + ((size_t)n * C + c0 + ch) * HW + pb + part * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (pb + part * 8 + e < HW) dst[e] = tile[ch][part * 8 + e];
+            }
+        }
+    }
+}
+
+extern "C" int rgda_instnorm_fwd(const void* x, int ldx, void* y0, void* y1, int ldy, float* feat_nchw, float* mi,
+                                 int N, int HW, int C, float eps, rgda_stream_t stream) {
+    if (!x || !mi || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldx & 7) || ((y0 || y1) && (ldy & 7))) return RGDA_ERR_ARG;
+    dim3 grid(cdiv(C, 64), N);
+    instnorm_fwd_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, (bf16_t*)y0, (bf16_t*)y1, ldy,
+                                                              feat_nchw, mi, HW, C, eps);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+__global__ void __launch_bounds__(256) instnorm_bwd_kernel(const bf16_t* __restrict__ ga, const bf16_t* __restrict__ gb,
+                                                           int ldg, const float* __restrict__ gc,
+                                                           const bf16_t* __restrict__ x, int ldx,
+                                                           const float* __restrict__ mi, bf16_t* __restrict__ dx, int lddx,
+                                                           int HW, int C) {
+    __shared__ float lds[32 * 64 * 2];
+    const int n = blockIdx.y, c0 = blockIdx.x * 64;
+    const int cv = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int cg = c0 + cv * 8;
+    const bool cok = cg < C;
+    float mean[8] = {0}, istd[8] = {0};
+    if (cok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mean[e] = mi[((size_t)n * 2) * C + cg + e]; istd[e] = mi[((size_t)n * 2 + 1) * C + cg + e]; }
+    }
+    auto gload = [&](int p, float (&g)[8]) {
+        size_t row = (size_t)n * HW + p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        float t8[8];
+        if (ga) { load8(ga + row * ldg + cg, t8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += t8[e]; }
+        if (gb) { load8(gb + row * ldg + cg, t8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += t8[e]; }
+        if (gc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += gc[row * C + cg + e]; }
+    };
+    float s[8] = {0}, q[8] = {0};
+    if (cok)
+        for (int p = rl; p < HW; p += 32) {
+            float g[8], f[8];
+            gload(p, g);
+            load8(x + ((size_t)n * HW + p) * ldx + cg, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += g[e]; q[e] += g[e] * ((f[e] - mean[e]) * istd[e]); }
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        lds[(rl * 64 + cv * 8 + e) * 2] = s[e];
+        lds[(rl * 64 + cv * 8 + e) * 2 + 1] = q[e];
+    }
+    __syncthreads();
+    float k1[8], k2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < 32; ++r) { a += lds[(r * 64 + cv * 8 + e) * 2]; b += lds[(r * 64 + cv * 8 + e) * 2 + 1]; }
+        k1[e] = a / (float)HW;
+        k2[e] = b / (float)HW;
+    }
+    if (cok)
+        for (int p = rl; p < HW; p += 32) {
+            float g[8], f[8], o[8];
+            gload(p, g);
+            load8(x + ((size_t)n * HW + p) * ldx + cg, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = istd[e] * (g[e] - k1[e] - (f[e] - mean[e]) * istd[e] * k2[e]);
+            store8(dx + ((size_t)n * HW + p) * lddx + cg, o);
+        }
+}
+
+extern "C" int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const float* gc, const void* x, int ldx,
+                                 const float* mi, void* dx, int lddx, int N, int HW, int C, rgda_stream_t stream) {
+    if (!x || !mi || !dx || (!ga && !gb && !gc) || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (lddx & 7) ||
+        ((ga || gb) && (ldg & 7)))
+        return RGDA_ERR_ARG;
+    dim3 grid(cdiv(C, 64), N);
+    instnorm_bwd_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)ga, (const bf16_t*)gb, ldg, gc,
+                                                              (const bf16_t*)x, ldx, mi, (bf16_t*)dx, lddx, HW, C);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// ------------------------------------------------------------------ spatial linear map
+// out[n][i][c] (+)= sum_j Mx[i][j] * in[n][j][c]; block = (i, n), threads over channel vectors
+__global__ void __launch_bounds__(256) spatial_mix_kernel(const bf16_t* __restrict__ in, int ldin,
+                                                          const float* __restrict__ Mx, void* out, int ldout, int I,
+                                                          int J, int C, int accumulate, int out_f32) {
+    const int i = blockIdx.x, n = blockIdx.y;
+    const float* mrow = Mx + (size_t)i * J;
+    for (int cv = threadIdx.x; cv < C / 8; cv += 256) {
+        float acc[8] = {0};
+        for (int j = 0; j < J; ++j) {
+            float m = mrow[j];
+            if (m == 0.f) continue;
+            float f[8];
+            load8(in + ((size_t)n * J + j) * ldin + cv * 8, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += m * f[e];
+        }
+        size_t o = ((size_t)n * I + i) * ldout + cv * 8;
+        if (out_f32) {
+            float* op = (float*)out + o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) op[e] = accumulate ? op[e] + acc[e] : acc[e];
+        } else {
+            bf16_t* op = (bf16_t*)out + o;
+            if (accumulate) {
+                float f[8];
+                load8(op, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += f[e];
+            }
+            store8(op, acc);
+        }
+    }
+}
+
+extern "C" int rgda_spatial_mix(const void* in, int ldin, const float* Mx, void* out, int ldout, int N, int I, int J,
+                                int C, int accumulate, int out_f32, rgda_stream_t stream) {
+    if (!in || !Mx || !out || N <= 0 || I <= 0 || J <= 0 || C <= 0 || (C & 7) || (ldin & 7) || (ldout & 7)) return RGDA_ERR_ARG;
+    dim3 grid(I, N);
+    spatial_mix_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)in, ldin, Mx, out, ldout, I, J, C, accumulate, out_f32);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// ------------------------------------------------------------------ stem im2col (7x7 / 2 / pad 3, 3 channels)
+__global__ void __launch_bounds__(256) stem_im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ col, int N,
+                                                          int H, int W, int Ho, int Wo, int Kp) {
+    const int vpr = Kp / 8;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long total = (long long)N * Ho * Wo * vpr;
+    if (i >= total) return;
+    int v = (int)(i % vpr);
+    long long m = i / vpr;
+    int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho), n = (int)(m / ((long long)Wo * Ho));
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int k = v * 8 + e;
+        float val = 0.f;
+        if (k < 147) {
+            int tap = k / 3, c = k % 3, kh = tap / 7, kw = tap % 7;
+            int hi = ho * 2 - 3 + kh, wi = wo * 2 - 3 + kw;
+            if (hi >= 0 && hi < H && wi >= 0 && wi < W) val = img[((size_t)(n * 3 + c) * H + hi) * W + wi];
+        }
+        f[e] = val;
+    }
+    store8(col + (size_t)m * Kp + v * 8, f);
+}
+
+extern "C" int rgda_stem_im2col(const float* img, void* col, int N, int H, int W, int Ho, int Wo, int Kp,
+                                rgda_stream_t stream) {
+    if (!img || !col || N <= 0 || H <= 0 || W <= 0 || Kp < 152 || (Kp & 7)) return RGDA_ERR_ARG;
+    if (Ho != (H + 6 - 7) / 2 + 1 || Wo != (W + 6 - 7) / 2 + 1) return RGDA_ERR_ARG;
+    long long total = (long long)N * Ho * Wo * (Kp / 8);
+    stem_im2col_kernel<<<cdiv(total, 256), 256, 0, to_stream(stream)>>>(img, (bf16_t*)col, N, H, W, Ho, Wo, Kp);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// ------------------------------------------------------------------ classifier (1x1, ncls outputs, bias)
+// one wavefront per pixel: lanes split the C hidden channels, ncls dot products, shuffle reduce
+template <int NC>
+__global__ void __launch_bounds__(256) classifier_fwd_kernel(const bf16_t* __restrict__ hid, int ldh,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ logits, int N, int HW, int C) {
+    const int lane = threadIdx.x & 63;
+    long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long long)N * HW) return;
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+    for (int k = lane * 8; k < C; k += 512) {
+        float f[8];
+        load8(hid + m * ldh + k, f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[c] += f[e] * w[c * C + k + e];
+    }
+    int n = (int)(m / HW), p = (int)(m % HW);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float s = wave_sum(acc[c]);
+        if (lane == 0) logits[((size_t)n * NC + c) * HW + p] = s + bias[c];
+    }
+}
+
+// dhidden[m][k] = sum_c g[n][c][p] * w[c][k];   dW[c][k] += sum_m g * hidden[m][k];  db[c] += sum_m g
+template <int NC>
+__global__ void __launch_bounds__(256) classifier_bwd_kernel(const bf16_t* __restrict__ hid, int ldh,
+                                                             const float* __restrict__ w, const float* __restrict__ gl,
+                                                             bf16_t* __restrict__ dhid, int lddh, float* dw, float* db,
+                                                             int N, int HW, int C, int rows_per_block) {
+    // block: channel vectors x row lanes, like the BN passes
+    extern __shared__ float lds[];       // [rpb][vpb*8][NC]
+    const int vpr = C / 8;
+    int vpb = 1;
+    while (vpb < vpr && vpb < 256) vpb <<= 1;
+    const int rpb = 256 / vpb;
+    const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
+    const int cg = (blockIdx.y * vpb + cvl) * 8;
+    const bool cok = cg < C;
+    float wreg[NC][8], dwacc[NC][8], dbacc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        dbacc[c] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { wreg[c][e] = cok ? w[c * C + cg + e] : 0.f; dwacc[c][e] = 0.f; }
+    }
+    long long M = (long long)N * HW;
+    long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    if (cok)
+        for (long long m = r0 + rl; m < r1; m += rpb) {
+            int n = (int)(m / HW), p = (int)(m % HW);
+            float g[NC], h[8], o[8];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) g[c] = gl[((size_t)n * NC + c) * HW + p];
+            load8(hid + m * ldh + cg, h);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                dbacc[c] += g[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] += g[c] * wreg[c][e]; dwacc[c][e] += g[c] * h[e]; }
+            }
+            store8(dhid + m * lddh + cg, o);
+        }
+    // reduce dW over the row lanes
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds[((rl * vpb + cvl) * 8 + e) * NC + c] = dwacc[c][e];
+    __syncthreads();
+    if (rl == 0 && cok) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = 0.f;
+                for (int r = 0; r < rpb; ++r) a += lds[((r * vpb + cvl) * 8 + e) * NC + c];
+                atomicAdd(dw + c * C + cg + e, a);
+            }
+    }
+    if (blockIdx.y == 0 && cvl == 0) {
+        // every row lane of channel-vector 0 saw a disjoint set of rows
+#pragma unroll
+        for (int c = 0; c < NC; ++c) atomicAdd(db + c, dbacc[c]);
+    }
+}
+
+extern "C" int rgda_classifier_fwd(const void* hidden, int ldh, const float* w, const float* bias, float* logits,
+                                   int N, int HW, int C, int ncls, rgda_stream_t stream) {
+    if (!hidden || !w || !bias || !logits || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldh & 7)) return RGDA_ERR_ARG;
+    if (ncls != 6) return RGDA_ERR_UNSUPPORTED;
+    long long M = (long long)N * HW;
+    classifier_fwd_kernel<6><<<cdiv(M, 4), 256, 0, to_stream(stream)>>>((const bf16_t*)hidden, ldh, w, bias, logits, N, HW, C);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+extern "C" int rgda_classifier_bwd(const void* hidden, int ldh, const float* w, const float* glogits, void* dhidden,
+                                   int lddh, float* dw, float* db, int N, int HW, int C, int ncls,
+                                   rgda_stream_t stream) {
+    if (!hidden || !w || !glogits || !dhidden || !dw || !db || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldh & 7) ||
+        (lddh & 7))
+        return RGDA_ERR_ARG;
+    if (ncls != 6) return RGDA_ERR_UNSUPPORTED;
+    long long M = (long long)N * HW;
+    RowLayout L = row_layout(C);
+    int rows_per_block = 64;
+    while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 1024) rows_per_block *= 2;
+    dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
+    classifier_bwd_kernel<6><<<grid, 256, (size_t)256 * 8 * 6 * 4, to_stream(stream)>>>(
+        (const bf16_t*)hidden, ldh, w, glogits, (bf16_t*)dhidden, lddh, dw, db, N, HW, C, rows_per_block);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}

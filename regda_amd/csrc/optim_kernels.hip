@@ -1,0 +1,197 @@
+// Optimizer side of the SSL step on flat fp32 parameter / gradient / momentum / EMA buffers
+// (tools/train_ssl_reg.py:174-175,239-241; regda/utils/ema.py:46-51) and the weight-format
+// passes that feed the conv kernels.  All HBM-bound, float4 per lane.
+#include "common.h"
+
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float* __restrict__ g, long long n, float* part) {
+    double acc = 0.0;
+    long long n4 = n >> 2;
+    const float4* g4 = (const float4*)g;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = g4[i];
+        acc += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[(n4 << 2) + threadIdx.x]; acc += (double)v * v; }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = (float)red[0];
+}
+__global__ void __launch_bounds__(256) sumsq_final_kernel(const float* __restrict__ part, int n, float* out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+extern "C" int rgda_sumsq(const float* g, int64_t n, float* out, float* ws, rgda_stream_t stream) {
+    if (!g || !out || !ws || n <= 0) return RGDA_ERR_ARG;
+    hipStream_t st = to_stream(stream);
+    int blocks = min(cdiv(n, 256 * 16), 1024);
+    sumsq_partial_kernel<<<blocks, 256, 0, st>>>(g, n, ws);
+    RGDA_CHECK_LAUNCH();
+    sumsq_final_kernel<<<1, 256, 0, st>>>(ws, blocks, out);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+__global__ void __launch_bounds__(256) sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ v, float* __restrict__ shadow,
+                                                       bf16_t* __restrict__ pb, const float* __restrict__ gnorm_sq,
+                                                       const float* __restrict__ lr_dev, long long n4, float momentum,
+                                                       float wd, float max_norm, float gscale, float ema_d,
+                                                       int first_step) {
+    // torch clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+    const float total = sqrtf(gnorm_sq[0]) * gscale;
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.f) * gscale;
+    const float lr = lr_dev[0];
+    float4* p4 = (float4*)p;
+    const float4* g4 = (const float4*)g;
+    float4* v4 = (float4*)v;
+    float4* s4 = (float4*)shadow;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 pp = p4[i], gg = g4[i], vv;
+        float d0 = gg.x * coef + wd * pp.x, d1 = gg.y * coef + wd * pp.y, d2 = gg.z * coef + wd * pp.z,
+              d3 = gg.w * coef + wd * pp.w;
+        if (first_step) { vv = make_float4(d0, d1, d2, d3); }       // torch SGD: buf = d_p on the first step
+        else {
+            vv = v4[i];
+            vv.x = momentum * vv.x + d0; vv.y = momentum * vv.y + d1; vv.z = momentum * vv.z + d2; vv.w = momentum * vv.w + d3;
+        }
+        pp.x -= lr * vv.x; pp.y -= lr * vv.y; pp.z -= lr * vv.z; pp.w -= lr * vv.w;
+        v4[i] = vv;
+        p4[i] = pp;
+        if (shadow) {
+            float4 ss = s4[i];
+            const float a = 1.f - ema_d;
+            ss.x = a * pp.x + ema_d * ss.x; ss.y = a * pp.y + ema_d * ss.y; ss.z = a * pp.z + ema_d * ss.z; ss.w = a * pp.w + ema_d * ss.w;
+            s4[i] = ss;
+        }
+        if (pb) {
+            uint2 pk;
+            pk.x = pack2bf(pp.x, pp.y);
+            pk.y = pack2bf(pp.z, pp.w);
+            *(uint2*)(pb + (i << 2)) = pk;
+        }
+    }
+}
+
+extern "C" int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf16, const float* gnorm_sq,
+                             const float* lr_dev, int64_t n, float momentum, float weight_decay, float max_norm,
+                             float gscale, float ema_decay, int first_step, rgda_stream_t stream) {
+    if (!p || !g || !v || !gnorm_sq || !lr_dev || n <= 0 || (n & 3)) return RGDA_ERR_ARG;
+    long long n4 = n >> 2;
+    int blocks = min(cdiv(n4, 256 * 4), 4096);
+    sgd_step_kernel<<<blocks, 256, 0, to_stream(stream)>>>(p, g, v, shadow, (bf16_t*)p_bf16, gnorm_sq, lr_dev, n4,
+                                                            momentum, weight_decay, max_norm, gscale, ema_decay,
+                                                            first_step);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+__global__ void __launch_bounds__(256) cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+    long long n4 = n >> 2;
+    const float4* s4 = (const float4*)src;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 v = s4[i];
+        uint2 pk;
+        pk.x = pack2bf(v.x, v.y);
+        pk.y = pack2bf(v.z, v.w);
+        *(uint2*)(dst + (i << 2)) = pk;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = f2bf(src[(n4 << 2) + threadIdx.x]);
+}
+
+extern "C" int rgda_cast_bf16(const float* src, void* dst, int64_t n, rgda_stream_t stream) {
+    if (!src || !dst || n <= 0) return RGDA_ERR_ARG;
+    int blocks = min(cdiv(n, 256 * 16), 4096);
+    cast_bf16_kernel<<<blocks, 256, 0, to_stream(stream)>>>(src, (bf16_t*)dst, n);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// w [Co][T][Ci] f32 -> wt [Ci][T][Co] bf16, 32x32 LDS tiles per tap
+__global__ void __launch_bounds__(256) weight_transpose_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int Co,
+                                                               int T, int Ci) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + tap) * Ci + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int ci = ci0 + r, co = co0 + tx;
+        if (ci < Ci && co < Co) wt[((size_t)ci * T + tap) * Co + co] = f2bf(tile[tx][r]);
+    }
+}
+
+extern "C" int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, rgda_stream_t stream) {
+    if (!w || !wt || Co <= 0 || T <= 0 || Ci <= 0) return RGDA_ERR_ARG;
+    dim3 grid(cdiv(Ci, 32), cdiv(Co, 32), T);
+    weight_transpose_kernel<<<grid, 256, 0, to_stream(stream)>>>(w, (bf16_t*)wt, Co, T, Ci);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// rows of K f32 -> rows of Kp bf16, zero padded (stem weights [64][147] -> [64][192])
+__global__ void __launch_bounds__(256) pad_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int K, int Kp) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * Kp) return;
+    int r = i / Kp, k = i % Kp;
+    dst[i] = (k < K) ? f2bf(src[(size_t)r * K + k]) : (bf16_t)0;
+}
+// dst[R][K] f32 += src[R][Kp] f32 (first K columns)
+__global__ void __launch_bounds__(256) unpad_acc_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int K, int Kp) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * K) return;
+    int r = i / K, k = i % K;
+    dst[i] += src[(size_t)r * Kp + k];
+}
+
+extern "C" int rgda_pad_cast_bf16(const float* src, void* dst, int R, int K, int Kp, rgda_stream_t stream) {
+    if (!src || !dst || R <= 0 || K <= 0 || Kp < K) return RGDA_ERR_ARG;
+    pad_cast_kernel<<<cdiv((long long)R * Kp, 256), 256, 0, to_stream(stream)>>>(src, (bf16_t*)dst, R, K, Kp);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+extern "C" int rgda_unpad_acc_f32(const float* src, float* dst, int R, int K, int Kp, rgda_stream_t stream) {
+    if (!src || !dst || R <= 0 || K <= 0 || Kp < K) return RGDA_ERR_ARG;
+    unpad_acc_kernel<<<cdiv((long long)R * K, 256), 256, 0, to_stream(stream)>>>(src, dst, R, K, Kp);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+__global__ void __launch_bounds__(256) add_bf16_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
+                                                       int ldb, bf16_t* __restrict__ o, int ldo, long long M, int vpr) {
+    long long total = M * vpr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i / vpr;
+        int c = (int)(i % vpr) * 8;
+        u16x8 x = *(const u16x8*)(a + r * lda + c), y = *(const u16x8*)(b + r * ldb + c), z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = f2bf(bf2f(x[e]) + bf2f(y[e]));
+        *(u16x8*)(o + r * ldo + c) = z;
+    }
+}
+
+extern "C" int rgda_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t M, int C,
+                             rgda_stream_t stream) {
+    if (!a || !b || !out || M <= 0 || C <= 0 || (C & 7) || (lda & 7) || (ldb & 7) || (ldo & 7)) return RGDA_ERR_ARG;
+    long long total = M * (C / 8);
+    add_bf16_kernel<<<min(cdiv(total, 256), 8192), 256, 0, to_stream(stream)>>>((const bf16_t*)a, lda, (const bf16_t*)b,
+                                                                                ldb, (bf16_t*)out, ldo, M, C / 8);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}

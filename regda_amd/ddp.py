@@ -1,0 +1,60 @@
+"""Data-parallel gradient exchange for the flat fp32 gradient buffer (new capability: the reference is
+single-GPU).  One process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI)
+on the GPU box, "gloo" in the CPU tests.
+
+The gradient is ONE flat tensor laid out in forward order, so backward finalises it from the END towards
+the start: buckets are contiguous ranges issued in reverse order as soon as the backward pass has moved
+below them, each as an async all-reduce (sum) that overlaps the remaining dgrad/wgrad kernels; the
+1/world scale is folded into the fused clip+SGD kernel (`gscale`), not applied as a separate pass.
+"""
+import torch
+import torch.distributed as dist
+
+
+def make_buckets(boundaries, total, bucket_elems):
+    """boundaries: ascending element offsets where a bucket may be cut (layer starts).  Returns
+    [(start, end)] in ISSUE order (last range first), each at least `bucket_elems` long except the last."""
+    cuts = sorted(set(b for b in boundaries if 0 < b < total))
+    buckets, end = [], total
+    for c in reversed(cuts):
+        if end - c >= bucket_elems:
+            buckets.append((c, end))
+            end = c
+    buckets.append((0, end))
+    return buckets
+
+
+class FlatGradReducer:
+    def __init__(self, flat_g, boundaries, bucket_elems=8 << 20, group=None):
+        self.flat_g = flat_g
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = make_buckets(boundaries, flat_g.numel(), bucket_elems)
+        self._next = 0
+        self._works = []
+
+    def reset(self):
+        self._next = 0
+        self._works = []
+
+    def ready_down_to(self, offset):
+        """Backward has finished every gradient at element offset >= `offset`: launch the buckets that
+        lie entirely above it."""
+        if self.world == 1:
+            return
+        while self._next < len(self.buckets) and self.buckets[self._next][0] >= offset:
+            a, b = self.buckets[self._next]
+            self._works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+            self._next += 1
+
+    def finish(self):
+        """Launch what is left and make the current stream wait for every bucket."""
+        self.ready_down_to(0)
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    @property
+    def gscale(self):
+        return 1.0 / self.world

@@ -1,0 +1,591 @@
+"""Deeplabv2 (ResNet encoder, output stride 16, InstanceNorm, two PPMBilinear heads) -- the host-side
+mirror of regda/models/Encoder.py:87-186 + regda/resnet.py:43-207 + regda/_resnets.py:72-112 for the
+configuration every st.regda.* entry point builds (tools/train_ssl_reg.py:94-111):
+    multi_layer=True, cascade=False, use_ppm=True, is_ins_norm=True.
+
+Same constructor (a config dict), same train()/eval() outputs ((x1, x2, feat) / class probabilities),
+same state_dict layout (688 keys for ResNet-101) as the reference, so checkpoints interchange.
+
+Execution is NOT torch.nn: the network is a static plan of HIP kernels from librgda_hip.so over
+pixel-major bf16 activations ("PxC": [N*H*W][C], channels contiguous -- the layout whose implicit-GEMM
+operands are K-contiguous for bf16 MFMA; NCHW only at the API boundary), with an explicit backward
+plan.  Parameters live in ONE flat fp32 buffer (conv weights physically [Cout][kh][kw][Cin]; the
+nn.Parameter objects are zero-copy views with the reference's logical [Cout,Cin,kh,kw] shape), with a
+bf16 mirror for the forward pass, a transposed bf16 copy for the data-gradient pass and ONE flat fp32
+gradient buffer (what the RCCL all-reduce and the fused SGD kernel work on).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+BF = torch.bfloat16
+LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3),
+          'resnet17t': (2, 1, 1, 2)}   # resnet17t: test-only shallow topology (same code paths, 6 blocks)
+POOL_SCALES = (1, 2, 3, 6)
+STEM_KP = 192           # 7*7*3 = 147 im2col columns, zero padded to a multiple of 64
+
+
+# ----------------------------------------------------------------------------- spatial matrices
+def pool_matrix(H, W, s):
+    """AdaptiveAvgPool2d(s) on an HxW map as a dense [s*s, H*W] matrix (bins floor/ceil, Encoder.py:16-18)."""
+    P = torch.zeros(s * s, H * W)
+    for i in range(s):
+        h0, h1 = (i * H) // s, -((-(i + 1) * H) // s)
+        for j in range(s):
+            w0, w1 = (j * W) // s, -((-(j + 1) * W) // s)
+            v = 1.0 / ((h1 - h0) * (w1 - w0))
+            for y in range(h0, h1):
+                P[i * s + j, y * W + w0: y * W + w1] = v
+    return P
+
+
+def _src_index(dst, scale):
+    src = scale * (dst + 0.5) - 0.5          # align_corners=False
+    return max(src, 0.0)
+
+
+def upsample_matrix(h, w, H, W):
+    """F.interpolate(mode='bilinear', align_corners=False) from hxw to HxW as a dense [H*W, h*w] matrix
+    (Encoder.py:48-51)."""
+    import numpy as np
+    U = torch.zeros(H * W, h * w)
+    sh, sw = np.float32(h) / np.float32(H), np.float32(w) / np.float32(W)
+
+    def taps(dst, scale, n):
+        src = np.float32(scale) * (np.float32(dst) + np.float32(0.5)) - np.float32(0.5)
+        src = max(src, np.float32(0))
+        i0 = int(src)
+        i1 = i0 + (1 if i0 < n - 1 else 0)
+        l1 = np.float32(src) - np.float32(i0)
+        return i0, i1, float(np.float32(1) - l1), float(l1)
+    for Y in range(H):
+        y0, y1, ly0, ly1 = taps(Y, sh, h)
+        for X in range(W):
+            x0, x1, lx0, lx1 = taps(X, sw, w)
+            r = Y * W + X
+            U[r, y0 * w + x0] += ly0 * lx0
+            U[r, y0 * w + x1] += ly0 * lx1
+            U[r, y1 * w + x0] += ly1 * lx0
+            U[r, y1 * w + x1] += ly1 * lx1
+    return U
+
+
+# ----------------------------------------------------------------------------- parameter specs
+def _block_specs(resnet_type):
+    """[(prefix, inplanes, planes, stride, dilation, has_downsample)] at output stride 16
+    (resnet.py:62-63,192-207: layer4 strides -> 1, its later blocks dilation 2)."""
+    specs, inpl = [], 64
+    for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), LAYERS[resnet_type]), start=1):
+        for bi in range(nblk):
+            stride = 2 if (bi == 0 and li in (2, 3)) else 1
+            dil = 2 if (li == 4 and bi > 0) else 1
+            specs.append((f'encoder.resnet.layer{li}.{bi}', inpl, planes, stride, dil, bi == 0))
+            inpl = planes * 4
+    return specs
+
+
+class _Conv:
+    __slots__ = ('name', 'co', 'ci', 'k', 'stride', 'pad', 'dil', 'w', 'g', 'wb', 'wtb', 'bias', 'gbias')
+
+    def out_hw(self, H, W):
+        e = self.dil * (self.k - 1) + 1
+        return (H + 2 * self.pad - e) // self.stride + 1, (W + 2 * self.pad - e) // self.stride + 1
+
+
+class _BN:
+    __slots__ = ('name', 'c', 'gamma', 'beta', 'rm', 'rv', 'nbt', 'dgamma', 'dbeta')
+
+
+class _Container(nn.Module):
+    pass
+
+
+def _attach(root, dotted, kind, tensor):
+    """Register `tensor` as parameter/buffer under the reference's dotted name, creating containers."""
+    parts = dotted.split('.')
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Container())
+        m = m._modules[p]
+    if kind == 'param':
+        m.register_parameter(parts[-1], tensor)
+    else:
+        m.register_buffer(parts[-1], tensor)
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class Deeplabv2(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        cfg = dict(backbone=dict(resnet_type='resnet50', output_stride=16, pretrained=True), multi_layer=False,
+                   cascade=False, use_ppm=False, ppm=dict(num_classes=7, use_aux=False), inchannels=2048,
+                   num_classes=7, is_ins_norm=False)          # Encoder.py:167-186 defaults
+        for k, v in dict(config).items():
+            if isinstance(v, dict) and isinstance(cfg.get(k), dict):
+                cfg[k] = dict(cfg[k], **v)
+            else:
+                cfg[k] = v
+        self.config = cfg
+        rt = cfg['backbone']['resnet_type']
+        if not (cfg['multi_layer'] and cfg['use_ppm'] and not cfg['cascade'] and cfg['is_ins_norm']):
+            raise NotImplementedError('regda_amd builds the st.regda.* model: multi_layer=True, cascade=False, '
+                                      'use_ppm=True, is_ins_norm=True (ASPP/cascade heads: DESIGN.md "next")')
+        if rt not in LAYERS or cfg['backbone'].get('output_stride', 16) != 16:
+            raise NotImplementedError('resnet50/resnet101 at output_stride 16 only')
+        if not torch.cuda.is_available():
+            raise RuntimeError('regda_amd.Deeplabv2 needs an MI355X: there is no CPU fallback')
+        self.resnet_type = rt
+        self.num_classes = int(cfg['num_classes'])
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self._build_params()
+        self._init_weights()
+        self._anchor = torch.zeros(1, device=self.device, requires_grad=True)   # routes autograd into backward()
+        self._drop_override = None
+        self._mat_cache = {}
+        self._synced_version = -1
+        self.sync_weights()
+
+    # ------------------------------------------------------------------ parameters
+    def _build_params(self):
+        dev = self.device
+        entries = []            # (name, kind, shape) in the reference's state_dict order
+
+        def conv(name, co, ci, k, bias=False):
+            entries.append((name + '.weight', 'convw', (co, ci, k, k)))
+            if bias:
+                entries.append((name + '.bias', 'vec', (co,)))
+
+        def bn(name, c):
+            entries.append((name + '.weight', 'vec', (c,)))
+            entries.append((name + '.bias', 'vec', (c,)))
+            entries.append((name + '.running_mean', 'buf', (c,)))
+            entries.append((name + '.running_var', 'buf', (c,)))
+            entries.append((name + '.num_batches_tracked', 'nbt', ()))
+
+        conv('encoder.resnet.conv1', 64, 3, 7); bn('encoder.resnet.bn1', 64)
+        self.blocks = _block_specs(self.resnet_type)
+        for p, inpl, planes, stride, dil, ds in self.blocks:
+            conv(p + '.conv1', planes, inpl, 1); bn(p + '.bn1', planes)
+            conv(p + '.conv2', planes, planes, 3); bn(p + '.bn2', planes)
+            conv(p + '.conv3', planes * 4, planes, 1); bn(p + '.bn3', planes * 4)
+            if ds:
+                conv(p + '.downsample.0', planes * 4, inpl, 1); bn(p + '.downsample.1', planes * 4)
+        for head in ('layer5', 'layer6'):
+            for i in range(4):
+                conv(f'{head}.ppm.{i}.1', 512, 2048, 1); bn(f'{head}.ppm.{i}.2', 512)
+            conv(f'{head}.conv_last.0', 512, 2048 + 4 * 512, 3); bn(f'{head}.conv_last.1', 512)
+            conv(f'{head}.conv_last.4', self.num_classes, 512, 1, bias=True)
+
+        n_param = sum(_pad64(math.prod(s)) for _, k, s in entries if k in ('convw', 'vec'))
+        n_buf = sum(_pad64(math.prod(s)) for _, k, s in entries if k == 'buf')
+        n_nbt = sum(1 for _, k, _s in entries if k == 'nbt')
+        self.flat_p = torch.zeros(n_param, device=dev)             # fp32 master weights
+        self.flat_g = torch.zeros(n_param, device=dev)             # fp32 gradients
+        self.flat_pb = torch.zeros(n_param, dtype=BF, device=dev)  # bf16 mirror (same offsets)
+        self.flat_buf = torch.zeros(n_buf, device=dev)             # BN running statistics
+        self.flat_nbt = torch.zeros(n_nbt, dtype=torch.int64, device=dev)
+        self.n_param_elems = sum(math.prod(s) for _, k, s in entries if k in ('convw', 'vec'))
+        self._views, self._gviews = {}, {}
+        self.convs, self.bns = {}, {}
+        op = ob = on = 0
+        wt_total = 0
+        for name, kind, shape in entries:
+            n = math.prod(shape)
+            if kind == 'convw':
+                co, ci, k, _ = shape
+                phys = self.flat_p[op:op + n].view(co, k, k, ci)
+                gphys = self.flat_g[op:op + n].view(co, k, k, ci)
+                par = nn.Parameter(phys.permute(0, 3, 1, 2))       # logical [Cout,Cin,kh,kw], zero copy
+                _attach(self, name, 'param', par)
+                self._views[name], self._gviews[name] = par, gphys.permute(0, 3, 1, 2)
+                c = _Conv()
+                c.name, c.co, c.ci, c.k = name[:-7], co, ci, k
+                c.stride, c.pad, c.dil = 1, 0, 1
+                c.w, c.g = self.flat_p[op:op + n].view(co, k * k, ci), self.flat_g[op:op + n].view(co, k * k, ci)
+                c.wb = self.flat_pb[op:op + n].view(co, k * k, ci)
+                c.wtb, c.bias, c.gbias = None, None, None
+                self.convs[c.name] = c
+                wt_total += _pad64(n)
+                op += _pad64(n)
+            elif kind == 'vec':
+                par = nn.Parameter(self.flat_p[op:op + n].view(shape))
+                _attach(self, name, 'param', par)
+                self._views[name], self._gviews[name] = par, self.flat_g[op:op + n].view(shape)
+                base = name.rsplit('.', 1)[0]
+                if base in self.convs:                               # classifier bias
+                    self.convs[base].bias, self.convs[base].gbias = self.flat_p[op:op + n], self.flat_g[op:op + n]
+                else:
+                    b = self.bns.setdefault(base, _BN())
+                    b.name, b.c = base, n
+                    if name.endswith('.weight'):
+                        b.gamma, b.dgamma = self.flat_p[op:op + n], self.flat_g[op:op + n]
+                    else:
+                        b.beta, b.dbeta = self.flat_p[op:op + n], self.flat_g[op:op + n]
+                op += _pad64(n)
+            elif kind == 'buf':
+                t = self.flat_buf[ob:ob + n]
+                _attach(self, name, 'buf', t)
+                b = self.bns[name.rsplit('.', 1)[0]]
+                if name.endswith('running_mean'):
+                    b.rm = t
+                else:
+                    b.rv = t
+                ob += _pad64(n)
+            else:
+                t = self.flat_nbt[on:on + 1].view(())
+                _attach(self, name, 'buf', t)
+                self.bns[name.rsplit('.', 1)[0]].nbt = t
+                on += 1
+        # geometry of the 3x3 / strided convs
+        for p, inpl, planes, stride, dil, ds in self.blocks:
+            c2 = self.convs[p + '.conv2']
+            c2.stride, c2.pad, c2.dil = stride, dil, dil
+            if ds:
+                self.convs[p + '.downsample.0'].stride = stride
+        for head in ('layer5', 'layer6'):
+            self.convs[f'{head}.conv_last.0'].pad = 1
+        # transposed bf16 weights for the data-gradient pass (every conv but the stem and the classifiers)
+        self.flat_wt = torch.zeros(wt_total, dtype=BF, device=dev)
+        o = 0
+        for c in self.convs.values():
+            if c.name == 'encoder.resnet.conv1' or c.bias is not None:
+                continue
+            n = c.co * c.k * c.k * c.ci
+            c.wtb = self.flat_wt[o:o + n].view(c.ci, c.k * c.k, c.co)
+            o += _pad64(n)
+        self.stem_wb = torch.zeros(64, 1, STEM_KP, dtype=BF, device=dev)
+        self.stem_gtmp = torch.zeros(64, 1, STEM_KP, device=dev)
+
+    def _init_weights(self):
+        """kaiming_normal_(fan_out, relu) convs, BN weight 1 / bias 0 (_resnets.py:164-169); heads keep the
+        torch defaults of nn.Conv2d (kaiming_uniform(a=sqrt(5)))."""
+        with torch.no_grad():
+            for name, par in self._views.items():
+                if par.dim() == 4:
+                    co, ci, k, _ = par.shape
+                    if name.startswith('encoder.'):
+                        par.copy_(torch.randn(co, ci, k, k, device=self.device) * math.sqrt(2.0 / (co * k * k)))
+                    else:
+                        bound = 1.0 / math.sqrt(ci * k * k)
+                        par.copy_((torch.rand(co, ci, k, k, device=self.device) * 2 - 1) * bound)
+                elif name.endswith('.weight'):
+                    par.fill_(1.0)
+                else:
+                    par.zero_()
+            for c in self.convs.values():
+                if c.bias is not None:
+                    bound = 1.0 / math.sqrt(c.ci)
+                    c.bias.copy_((torch.rand(c.co, device=self.device) * 2 - 1) * bound)
+            for b in self.bns.values():
+                b.rv.fill_(1.0)
+
+    def sync_weights(self):
+        """Refresh the bf16 mirror and the transposed copies from the fp32 master weights."""
+        ops.cast_bf16(self.flat_p, self.flat_pb)
+        self.sync_derived_weights()
+        self._synced_version = self.flat_p._version
+
+    def sync_derived_weights(self):
+        """Transposed (data-gradient) copies + padded stem weights; the bf16 mirror is already fresh."""
+        for c in self.convs.values():
+            if c.wtb is not None:
+                ops.weight_transpose_bf16(c.w, c.wtb, c.co, c.k * c.k, c.ci)
+        s = self.convs['encoder.resnet.conv1']
+        ops.pad_cast_bf16(s.w, self.stem_wb, 64, 147, STEM_KP)
+
+    def _maybe_sync(self):
+        if self.flat_p._version != self._synced_version:
+            self.sync_weights()
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.sync_weights()
+        return r
+
+    def new_tape(self):
+        return {'stats_pool': _StatsPool(sum(2 * _pad64(b.c) for b in self.bns.values()) + 64, self.device)}
+
+    def param_boundaries(self):
+        """Element offsets (into flat_p / flat_g) where a residual block / head starts: legal bucket cuts."""
+        base = self.flat_p.data_ptr()
+        offs = [(self.convs[p + '.conv1'].w.data_ptr() - base) // 4 for p, *_ in self.blocks]
+        offs += [(self.convs[f'{h}.ppm.0.1'].w.data_ptr() - base) // 4 for h in ('layer5', 'layer6')]
+        return sorted(offs)
+
+    def _offset_of(self, conv_name):
+        return (self.convs[conv_name].w.data_ptr() - self.flat_p.data_ptr()) // 4
+
+    def make_teacher(self):
+        """EMA teacher (regda/utils/ema.py:41-58): its own (shadow) parameters, the STUDENT's BN buffers."""
+        t = Deeplabv2(self.config)
+        with torch.no_grad():
+            t.flat_p.copy_(self.flat_p)                       # ema.register(): shadow = param.clone()
+        for name, b in t.bns.items():
+            src = self.bns[name]
+            b.rm, b.rv, b.nbt = src.rm, src.rv, src.nbt
+        t.refresh_from_master()
+        t.eval()
+        return t
+
+    def refresh_from_master(self):
+        """bf16 mirror + padded stem weights only (a forward-only model needs no transposed copies)."""
+        ops.cast_bf16(self.flat_p, self.flat_pb)
+        s = self.convs['encoder.resnet.conv1']
+        ops.pad_cast_bf16(s.w, self.stem_wb, 64, 147, STEM_KP)
+        self._synced_version = self.flat_p._version
+
+    def set_drop_masks(self, m5, m6):
+        """Test hook: fix the Dropout2d(0.1) keep-masks (b,512) of the two heads (None -> random)."""
+        self._drop_override = None if m5 is None else (m5, m6)
+
+    # ------------------------------------------------------------------ building blocks
+    def _mats(self, h, w):
+        key = (h, w)
+        if key not in self._mat_cache:
+            d = {}
+            for s in POOL_SCALES:
+                P = pool_matrix(h, w, s)
+                U = upsample_matrix(s, s, h, w)
+                d[s] = tuple(t.to(self.device).contiguous() for t in (P, P.t(), U, U.t()))
+            self._mat_cache[key] = d
+        return self._mat_cache[key]
+
+    def _cbr_fwd(self, T, key, conv, bn, x, N, H, W, relu, res=None, nscale=None, wb=None, geom=None):
+        Ho, Wo = conv.out_hw(H, W) if geom is None else geom
+        M = N * Ho * Wo
+        train = T is not None
+        c = torch.empty(M, conv.co, dtype=BF, device=self.device)
+        stats = T['stats_pool'].take(2 * conv.co).view(2, conv.co) if train else None
+        if geom is None:
+            ops.conv2d(x, conv.wb if wb is None else wb, c, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad,
+                       conv.dil, 0, None, stats)
+        else:       # stem: GEMM over the im2col matrix
+            ops.conv2d(x, wb, c, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1, 0, None, stats)
+        mi = torch.empty(2, conv.co, device=self.device)
+        if train:
+            if M < 2:
+                raise ValueError('Expected more than 1 value per channel when training')
+            ops.bn_finalize(stats, mi, bn.rm, bn.rv, bn.nbt, M, conv.co)
+        else:
+            ops.bn_finalize(None, mi, bn.rm, bn.rv, None, M, conv.co)
+        y = torch.empty(M, conv.co, dtype=BF, device=self.device)
+        ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale, Ho * Wo)
+        if train:
+            T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale)
+        return y, Ho, Wo
+
+    def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False):
+        x, c, y, mi, (N, H, W, Ho, Wo), nscale = T[key]
+        M, C = N * Ho * Wo, conv.co
+        sums = torch.empty(2, C, device=self.device)
+        ops.bn_bwd_reduce(g, y if relu else None, c, mi, sums, M, C, relu, nscale, Ho * Wo)
+        dc = torch.empty(M, C, dtype=BF, device=self.device)
+        gm = torch.empty(M, C, dtype=BF, device=self.device) if want_gmask else None
+        ops.bn_bwd_apply(g, y if relu else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm, bn.dgamma, bn.dbeta,
+                         nscale, Ho * Wo)
+        if stem:
+            self.stem_gtmp.zero_()
+            ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
+            ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
+            return None, gm
+        ops.conv2d_wgrad(x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil)
+        dx = None
+        if need_dx:
+            dx = torch.empty(N * H * W, conv.ci, dtype=BF, device=self.device)
+            ops.conv2d(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil, 1, dx_res,
+                       None)
+        return dx, gm
+
+    # ------------------------------------------------------------------ forward plan
+    def _forward_plan(self, x, T):
+        dev = self.device
+        N, _, H, W = x.shape
+        C = self.convs
+        B = self.bns
+        H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        col = torch.empty(N * H1 * W1, STEM_KP, dtype=BF, device=dev)
+        ops.stem_im2col(x, col, N, H, W, H1, W1)
+        a0, _, _ = self._cbr_fwd(T, 'stem', C['encoder.resnet.conv1'], B['encoder.resnet.bn1'], col, N, H, W, True,
+                                 wb=self.stem_wb, geom=(H1, W1))
+        H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        y = torch.empty(N * H2 * W2, 64, dtype=BF, device=dev)
+        idx = torch.empty(N * H2 * W2, 64, dtype=torch.uint8, device=dev)
+        ops.maxpool_fwd(a0, y, idx, N, H1, W1, 64, H2, W2)
+        if T is not None:
+            T['pool'] = (idx, (N, H1, W1, H2, W2))
+        dbg = getattr(self, '_debug_taps', None)
+        if dbg is not None:
+            dbg['stem'] = a0.float().reshape(N, H1, W1, -1).permute(0, 3, 1, 2)
+            dbg['pool'] = y.float().reshape(N, H2, W2, -1).permute(0, 3, 1, 2)
+        h, w = H2, W2
+        for p, inpl, planes, stride, dil, ds in self.blocks:
+            a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True)
+            a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True)
+            idt = y
+            if ds:
+                idt, _, _ = self._cbr_fwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], y, N, h, w,
+                                          False)
+            y, _, _ = self._cbr_fwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], a2, N, h2, w2, True, res=idt)
+            h, w = h2, w2
+            if dbg is not None:
+                dbg[p] = y.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
+        HW, M = h * w, N * h * w
+        cats = [torch.empty(M, 4096, dtype=BF, device=dev) for _ in range(2)]
+        feat = torch.empty(N, 2048, h, w, device=dev)
+        imi = torch.empty(N, 2, 2048, device=dev)
+        ops.instnorm_fwd(y, cats[0][:, :2048], cats[1][:, :2048], feat, imi, N, HW, 2048)
+        if T is not None:
+            T['inorm'] = (y, imi, (N, h, w))
+        mats = self._mats(h, w)
+        if T is not None:
+            if self._drop_override is not None:
+                masks = [m.to(dev).float() / 0.9 for m in self._drop_override]
+            else:
+                masks = [(torch.rand(N, 512, device=dev) >= 0.1).float() / 0.9 for _ in range(2)]
+        else:
+            masks = [None, None]
+        logits = []
+        for hi, head in enumerate(('layer5', 'layer6')):
+            cat = cats[hi]
+            for i, s in enumerate(POOL_SCALES):
+                P, Pt, U, Ut = mats[s]
+                pooled = torch.empty(N * s * s, 2048, dtype=BF, device=dev)
+                ops.spatial_mix(cat[:, :2048], P, pooled, N, s * s, HW, 2048)
+                q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'], pooled,
+                                        N, s, s, True)
+                ops.spatial_mix(q, U, cat[:, 2048 + 512 * i: 2048 + 512 * (i + 1)], N, HW, s * s, 512)
+                if dbg is not None:
+                    dbg[f'{head}.q{i}'] = q.float().reshape(N, s, s, -1).permute(0, 3, 1, 2)
+            hid, _, _ = self._cbr_fwd(T, f'{head}.last', C[f'{head}.conv_last.0'], B[f'{head}.conv_last.1'], cat, N,
+                                      h, w, True, nscale=masks[hi])
+            if dbg is not None:
+                dbg[head + '.cat'] = cat.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
+                dbg[head + '.hidden'] = hid.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
+            cl = C[f'{head}.conv_last.4']
+            lg = torch.empty(N, self.num_classes, h, w, device=dev)
+            ops.classifier_fwd(hid, cl.w.view(cl.co, cl.ci), cl.bias, lg, N, HW, 512, self.num_classes)
+            if T is not None:
+                T[f'{head}.cls'] = (hid, (N, h, w))
+            logits.append(lg)
+        return logits[0], logits[1], feat
+
+    # ------------------------------------------------------------------ backward plan
+    def _backward_plan(self, T, g1, g2, on_progress=None):
+        dev = self.device
+        C, B = self.convs, self.bns
+        y4, imi, (N, h, w) = T['inorm']
+        HW, M = h * w, N * h * w
+        mats = self._mats(h, w)
+        dfeat = torch.zeros(M, 2048, device=dev)
+        dcats = []
+        dbg = getattr(self, '_debug_grads', None)
+
+        def nchw(t, hh, ww):
+            return t.float().reshape(N, hh, ww, -1).permute(0, 3, 1, 2)
+        for hi, (head, gl) in enumerate((('layer5', g1), ('layer6', g2))):
+            hid, _ = T[f'{head}.cls']
+            cl = C[f'{head}.conv_last.4']
+            dh = torch.empty(M, 512, dtype=BF, device=dev)
+            ops.classifier_bwd(hid, cl.w.view(cl.co, cl.ci), gl.contiguous().float(), dh, cl.g.view(cl.co, cl.ci),
+                               cl.gbias, N, HW, 512, self.num_classes)
+            dcat, _ = self._cbr_bwd(T, f'{head}.last', C[f'{head}.conv_last.0'], B[f'{head}.conv_last.1'], dh, True)
+            if dbg is not None:
+                dbg[head + '.hidden'] = nchw(dh, h, w)
+                dbg[head + '.cat'] = nchw(dcat, h, w)
+            for i, s in enumerate(POOL_SCALES):
+                P, Pt, U, Ut = mats[s]
+                dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
+                ops.spatial_mix(dcat[:, 2048 + 512 * i: 2048 + 512 * (i + 1)], Ut, dq, N, s * s, HW, 512)
+                dpool, _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'], dq, True)
+                ops.spatial_mix(dpool, Pt, dfeat, N, HW, s * s, 2048, accumulate=True)
+            dcats.append(dcat)
+        g = torch.empty(M, 2048, dtype=BF, device=dev)
+        ops.instnorm_bwd(dcats[0][:, :2048], dcats[1][:, :2048], dfeat, y4, imi, g, N, HW, 2048)
+        del dcats, dfeat
+        if on_progress is not None:
+            on_progress(self._offset_of('layer5.ppm.0.1'))
+        hh, ww = h, w
+        for p, inpl, planes, stride, dil, ds in reversed(self.blocks):
+            if dbg is not None:
+                dbg[p] = nchw(g, hh, ww)
+                hh, ww = hh * stride, ww * stride
+            da2, gm = self._cbr_bwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], g, True, want_gmask=True)
+            da1, _ = self._cbr_bwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], da2, True)
+            if ds:
+                dxd, _ = self._cbr_bwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], gm, False)
+                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=dxd)
+            else:
+                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm)
+            if on_progress is not None:
+                on_progress(self._offset_of(p + '.conv1'))
+        idx, (N, H1, W1, H2, W2) = T['pool']
+        ga0 = torch.empty(N * H1 * W1, 64, dtype=BF, device=dev)
+        ops.maxpool_bwd(g, idx, ga0, N, H1, W1, 64, H2, W2)
+        self._cbr_bwd(T, 'stem', C['encoder.resnet.conv1'], B['encoder.resnet.bn1'], ga0, True, stem=True)
+
+    # ------------------------------------------------------------------ grads <-> torch
+    def attach_grads(self):
+        for name, par in self._views.items():
+            par.grad = self._gviews[name]
+
+    def _prepare_grads(self):
+        """torch semantics: .grad accumulates; zero_grad(set_to_none=True) drops it.  If any .grad was
+        dropped since our last backward the flat buffer is re-zeroed and every view re-attached."""
+        if any(par.grad is None for par in self._views.values()):
+            self.flat_g.zero_()
+            self.attach_grads()
+
+    # ------------------------------------------------------------------ public forward
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('regda_amd.Deeplabv2 runs on the GPU only')
+        x = x.contiguous().float()
+        self._maybe_sync()
+        if self.training:
+            if x.shape[0] < 2:
+                raise ValueError('Expected more than 1 value per channel when training (PPM scale-1 BatchNorm)')
+            return _ModelFn.apply(x, self._anchor, self)
+        with torch.no_grad():
+            x1, x2, _ = self._forward_plan(x, None)
+            return ops.teacher_probs(x1, x2, tuple(x.shape[-2:]))     # Encoder.py:152-155
+
+
+class _StatsPool:
+    """One zero-initialised fp32 arena per forward for every BatchNorm's (sum, sumsq) accumulator."""
+
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n, device=device)
+        self.off = 0
+
+    def take(self, n):
+        t = self.buf[self.off:self.off + n]
+        self.off += (n + 63) // 64 * 64
+        return t
+
+
+class _ModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, model):
+        T = model.new_tape()
+        x1, x2, feat = model._forward_plan(x, T)
+        ctx.model, ctx.tape = model, T
+        ctx.mark_non_differentiable(feat)
+        return x1, x2, feat
+
+    @staticmethod
+    def backward(ctx, g1, g2, _gfeat):
+        model, T = ctx.model, ctx.tape
+        model._prepare_grads()
+        model._backward_plan(T, g1, g2)
+        T.clear()
+        return None, None, None

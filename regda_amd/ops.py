@@ -152,3 +152,126 @@ def class_count(label, class_num):
     cnt = torch.zeros(class_num, dtype=torch.int32, device=label.device)
     lib().call('rgda_class_count', label.data_ptr(), cnt.data_ptr(), label.numel(), class_num, _stream())
     return cnt
+
+
+# --------------------------------------------------------------------------- conv stack
+# Activations are torch.bfloat16 2-D tensors [N*H*W, ld] ("PxC"); a view with a column offset is
+# expressed by passing a slice of the buffer (data_ptr of the slice) and its row stride.
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0)
+
+
+def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None):
+    """x [N*H*W, Cin(view)], w bf16 [Cout, kh*kw, Cin] contiguous, y [N*Ho*Wo, Cout(view)]."""
+    Cout, taps, Cin = w.shape
+    assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
+    lib().call('rgda_conv2d', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
+               _ld(res) if res is not None else 0, _p(stats), N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil,
+               mode, _stream())
+
+
+def conv2d_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
+    """dw f32 [Cout, kh*kw, Cin] contiguous, accumulated."""
+    Cout, taps, Cin = dw.shape
+    assert dw.is_contiguous() and dw.dtype == torch.float32
+    lib().call('rgda_conv2d_wgrad', x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dw.data_ptr(), N, H, W, Cin, Ho, Wo,
+               Cout, kh, kw, stride, pad, dil, _stream())
+
+
+def stem_im2col(img, col, N, H, W, Ho, Wo):
+    lib().call('rgda_stem_im2col', img.data_ptr(), col.data_ptr(), N, H, W, Ho, Wo, col.shape[1], _stream())
+
+
+def bn_stats(x, stats, M, C):
+    lib().call('rgda_bn_stats', x.data_ptr(), _ld(x), stats.data_ptr(), M, C, _stream())
+
+
+def bn_finalize(stats, mi, rm, rv, nbt, M, C, eps=1e-5, momentum=0.1):
+    lib().call('rgda_bn_finalize', _p(stats), mi.data_ptr(), _p(rm), _p(rv), _p(nbt), M, C, eps, momentum, _stream())
+
+
+def bn_apply(x, mi, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_image=0):
+    lib().call('rgda_bn_apply', x.data_ptr(), _ld(x), mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(res),
+               _ld(res) if res is not None else 0, _p(nscale), rows_per_image, y.data_ptr(), _ld(y), M, C,
+               int(relu), _stream())
+
+
+def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0):
+    lib().call('rgda_bn_bwd_reduce', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, x.data_ptr(), _ld(x),
+               mi.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), M, C, int(relu), _stream())
+
+
+def bn_bwd_apply(g, y, x, mi, gamma, sums, dx, M, C, relu, gmask=None, dgamma=None, dbeta=None, nscale=None,
+                 rows_per_image=0):
+    lib().call('rgda_bn_bwd_apply', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, x.data_ptr(), _ld(x),
+               mi.data_ptr(), gamma.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), dx.data_ptr(), _ld(dx),
+               _p(gmask), _ld(gmask) if gmask is not None else 0, _p(dgamma), _p(dbeta), M, C, int(relu), _stream())
+
+
+def maxpool_fwd(x, y, idx, N, H, W, C, Ho, Wo):
+    lib().call('rgda_maxpool_fwd', x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, C, Ho, Wo, _stream())
+
+
+def maxpool_bwd(gy, idx, gx, N, H, W, C, Ho, Wo):
+    lib().call('rgda_maxpool_bwd', gy.data_ptr(), idx.data_ptr(), gx.data_ptr(), N, H, W, C, Ho, Wo, _stream())
+
+
+def instnorm_fwd(x, y0, y1, feat, mi, N, HW, C, eps=1e-5):
+    ldy = _ld(y0) if y0 is not None else (_ld(y1) if y1 is not None else 0)
+    lib().call('rgda_instnorm_fwd', x.data_ptr(), _ld(x), _p(y0), _p(y1), ldy, _p(feat), mi.data_ptr(), N, HW, C, eps,
+               _stream())
+
+
+def instnorm_bwd(ga, gb, gc, x, mi, dx, N, HW, C):
+    ldg = _ld(ga) if ga is not None else (_ld(gb) if gb is not None else 0)
+    lib().call('rgda_instnorm_bwd', _p(ga), _p(gb), ldg, _p(gc), x.data_ptr(), _ld(x), mi.data_ptr(), dx.data_ptr(),
+               _ld(dx), N, HW, C, _stream())
+
+
+def spatial_mix(inp, Mx, out, N, I, J, C, accumulate=False):
+    assert Mx.shape == (I, J) and Mx.is_contiguous() and Mx.dtype == torch.float32
+    lib().call('rgda_spatial_mix', inp.data_ptr(), _ld(inp), Mx.data_ptr(), out.data_ptr(), _ld(out), N, I, J, C,
+               int(accumulate), int(out.dtype == torch.float32), _stream())
+
+
+def classifier_fwd(hidden, w, bias, logits, N, HW, C, ncls):
+    lib().call('rgda_classifier_fwd', hidden.data_ptr(), _ld(hidden), w.data_ptr(), bias.data_ptr(), logits.data_ptr(),
+               N, HW, C, ncls, _stream())
+
+
+def classifier_bwd(hidden, w, glogits, dhidden, dw, db, N, HW, C, ncls):
+    lib().call('rgda_classifier_bwd', hidden.data_ptr(), _ld(hidden), w.data_ptr(), glogits.data_ptr(),
+               dhidden.data_ptr(), _ld(dhidden), dw.data_ptr(), db.data_ptr(), N, HW, C, ncls, _stream())
+
+
+def sumsq(g, out, ws):
+    lib().call('rgda_sumsq', g.data_ptr(), g.numel(), out.data_ptr(), ws.data_ptr(), _stream())
+
+
+def sgd_step(p, g, v, shadow, p_bf16, gnorm_sq, lr_dev, momentum, weight_decay, max_norm, gscale, ema_decay,
+             first_step):
+    lib().call('rgda_sgd_step', p.data_ptr(), g.data_ptr(), v.data_ptr(), _p(shadow), _p(p_bf16), gnorm_sq.data_ptr(),
+               lr_dev.data_ptr(), p.numel(), momentum, weight_decay, max_norm, gscale, ema_decay, int(first_step),
+               _stream())
+
+
+def weight_transpose_bf16(w, wt, Co, T, Ci):
+    lib().call('rgda_weight_transpose_bf16', w.data_ptr(), wt.data_ptr(), Co, T, Ci, _stream())
+
+
+def cast_bf16(src, dst):
+    lib().call('rgda_cast_bf16', src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
+
+
+def pad_cast_bf16(src, dst, R, K, Kp):
+    lib().call('rgda_pad_cast_bf16', src.data_ptr(), dst.data_ptr(), R, K, Kp, _stream())
+
+
+def unpad_acc_f32(src, dst, R, K, Kp):
+    lib().call('rgda_unpad_acc_f32', src.data_ptr(), dst.data_ptr(), R, K, Kp, _stream())
+
+
+def add_bf16(a, b, out, M, C):
+    lib().call('rgda_add_bf16', a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), out.data_ptr(), _ld(out), M, C, _stream())

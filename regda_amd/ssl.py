@@ -1,0 +1,113 @@
+"""The self-training (SSL) inner loop of tools/train_ssl_reg.py:198-241 as ONE fused, sync-free step.
+
+Same composition and hyper-parameters as the reference loop --
+    model(src), model(tgt) -> label_refine -> pseudo_selection -> Homogenizer (LRH) -> update_prototype
+    -> loss_calc x2 -> backward -> clip_grad_norm_(32) -> SGD(momentum .9, wd 5e-4)
+-- but driven directly over the HIP kernel plans (no autograd graph, no host sync, no .item()):
+flat gradient buffer, bucketed RCCL all-reduce overlapped with the second backward pass, and one fused
+clip + SGD (+ EMA shadow + bf16 weight mirror) kernel.  Optionally the soft target labels come from an
+online EMA teacher (regda/utils/ema.py semantics: parameters averaged, BN buffers shared) instead of
+the offline `.pt` files of the reference (BASELINE.json north_star; SURVEY.md header table).
+"""
+import torch
+
+from . import ops
+from .ddp import FlatGradReducer
+
+
+class SSLStep:
+    def __init__(self, model, prototypes, class_num=6, ignore_label=-1, momentum=0.9, weight_decay=5e-4,
+                 max_norm=32.0, cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996, refine_temp=2.0,
+                 sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=8 << 20,
+                 process_group=None):
+        self.model = model
+        self.C, self.ig = class_num, ignore_label
+        self.momentum, self.wd, self.max_norm = momentum, weight_decay, max_norm
+        self.top, self.low, self.percent = cutoff_top, cutoff_low, percent
+        self.pdecay, self.temp = proto_decay, refine_temp
+        self.sam_refine, self.refine_label = sam_refine, refine_label
+        self.max_regions = max_regions
+        dev = model.device
+        self.prototypes = prototypes.to(dev).float().contiguous().clone()
+        self.mom = torch.zeros_like(model.flat_p)
+        self.lr_dev = torch.zeros(1, device=dev)
+        self.gn = torch.zeros(1, device=dev)
+        self.gn_ws = torch.zeros(1024, device=dev)
+        self.first = True
+        self.lrh_ws = None
+        self.ema_decay = ema_decay
+        self.teacher = None
+        if ema_decay is not None:
+            self.teacher = model.make_teacher()
+        bounds = model.param_boundaries()
+        self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
+        self.world = self.reducer.world
+        self.group = process_group
+
+    # ------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, images_s, label_s, images_t, soft_t, regs_t, lr):
+        """One SSL iteration.  Returns device tensors (loss_source, loss_target, grad_norm_sq): nothing here
+        synchronises with the host."""
+        m = self.model
+        m.train()
+        m._maybe_sync()
+        self.lr_dev.fill_(float(lr))
+        m.flat_g.zero_()
+        Ts, Tt = m.new_tape(), m.new_tape()
+        s1, s2, feat_s = m._forward_plan(images_s, Ts)
+        t1, t2, feat_t = m._forward_plan(images_t, Tt)
+        if soft_t is None:
+            soft_t = self.teacher_probs(images_t)
+        # ---- label path (a5-a8)
+        if self.refine_label:
+            soft, cm = ops.label_refine(feat_t, self.prototypes, t1, t2, soft_t, self.temp, return_ws=True)
+            hard = ops.pseudo_select(soft, self.top, self.low, self.ig, classmax_ws=cm, check=False)
+        else:
+            hard = ops.pseudo_select(soft_t, self.top, self.low, self.ig, check=False)
+        if self.sam_refine:
+            regs = regs_t.squeeze(1) if regs_t.dim() == 4 else regs_t
+            self._lrh_flag_off = (regs.shape[0] * self.max_regions * (self.C + 1)) * 4
+            need = self._lrh_flag_off + 16
+            if self.lrh_ws is None or self.lrh_ws.numel() < need:
+                self.lrh_ws = torch.empty(need, dtype=torch.uint8, device=m.device)
+            hard = ops.lrh(hard, regs.contiguous(), self.percent, self.C, self.ig, self.max_regions, check=False,
+                           ws=self.lrh_ws)
+        ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
+        if self.world > 1:      # keep the prototypes identical on every rank
+            torch.distributed.all_reduce(self.prototypes, group=self.group)
+            self.prototypes.div_(self.world)
+        # ---- losses + d(loss)/d(logits)
+        loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
+        loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
+        # ---- backward: source first, the all-reduce buckets are released during the second pass
+        self.reducer.reset()
+        m._backward_plan(Ts, gs1, gs2)
+        m._backward_plan(Tt, gt1, gt2, on_progress=self.reducer.ready_down_to)
+        self.reducer.finish()
+        # ---- clip + SGD (+ EMA) in one pass over the flat buffers
+        ops.sumsq(m.flat_g, self.gn, self.gn_ws)
+        shadow = self.teacher.flat_p if self.teacher is not None else None
+        ops.sgd_step(m.flat_p, m.flat_g, self.mom, shadow, m.flat_pb, self.gn, self.lr_dev, self.momentum, self.wd,
+                     self.max_norm, self.reducer.gscale, self.ema_decay if shadow is not None else 0.0, self.first)
+        self.first = False
+        m.sync_derived_weights()
+        m._synced_version = m.flat_p._version
+        self.last_hard = hard
+        return loss_s, loss_t, self.gn
+
+    @torch.no_grad()
+    def teacher_probs(self, images_t):
+        """Eval-mode forward of the EMA teacher (Encoder.py:152-155 on the shadow weights)."""
+        t = self.teacher
+        t.refresh_from_master()
+        t.eval()
+        x1, x2, _ = t._forward_plan(images_t.contiguous().float(), None)
+        return ops.teacher_probs(x1, x2, tuple(images_t.shape[-2:]))
+
+    def lrh_flag(self):
+        """Deferred check of the LRH kernel's flag word (host sync): region id / label range errors."""
+        if self.lrh_ws is None:
+            return 0
+        o = self._lrh_flag_off
+        return int(self.lrh_ws[o:o + 4].view(torch.int32).item())

@@ -1,0 +1,315 @@
+"""GPU: every conv-stack kernel (through the C ABI) against a plain PyTorch fp32 reference of the same
+op computed on the bf16-rounded operands.  Tolerances: outputs are bf16 (relative 2^-8 per rounding);
+weight gradients are fp32 accumulations of bf16 products."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from regda_amd import ops
+    return ops
+
+
+def to_pxc(x):       # NCHW f32 -> [N*H*W, C] bf16 (cuda)
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(-1, c).to(BF).cuda().contiguous()
+
+
+def from_pxc(t, n, h, w):
+    return t.float().cpu().reshape(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+def rbf(x):          # round to bf16 and back
+    return x.to(BF).float()
+
+
+def relerr(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 16, 16, 64, 64, 3, 1, 1, 1),
+    (2, 16, 16, 128, 256, 1, 1, 0, 1),
+    (1, 32, 32, 256, 128, 3, 1, 2, 2),
+    (2, 17, 13, 64, 128, 3, 2, 1, 1),
+    (2, 16, 16, 64, 72, 1, 2, 0, 1),
+    (8, 32, 32, 256, 256, 3, 1, 1, 1),
+    (1, 4, 4, 512, 512, 3, 1, 1, 1),
+    (3, 1, 1, 2048, 512, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    N, H, W, Cin, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = rbf(torch.randn(N, Cin, H, W, generator=g))
+    w = rbf(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
+    Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
+    Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
+    ref = F.conv2d(x, w, None, s, p, d)
+    xg = to_pxc(x)
+    wg = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin).to(BF).cuda().contiguous()
+    y = torch.zeros(N * Ho * Wo, Cout, dtype=BF, device='cuda')
+    stats = torch.zeros(2, Cout, device='cuda')
+    ops.conv2d(xg, wg, y, N, H, W, Ho, Wo, k, k, s, p, d, 0, None, stats)
+    out = from_pxc(y, N, Ho, Wo)
+    assert relerr(out, ref) < 1e-2, 'forward'
+    # BatchNorm statistics fused in the epilogue (of the bf16-rounded outputs)
+    yf = y.float()
+    torch.testing.assert_close(stats[0].cpu(), yf.sum(0).cpu(), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(stats[1].cpu(), (yf * yf).sum(0).cpu(), rtol=1e-3, atol=1e-2)
+    # data gradient = conv in mode 1 with [Cin][tap][Cout] weights (+ residual add in the epilogue)
+    dy = rbf(torch.randn(N, Cout, Ho, Wo, generator=g))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, s, p, d).backward(dy)
+    dyg = to_pxc(dy)
+    wt = w.permute(1, 2, 3, 0).reshape(Cin, k * k, Cout).to(BF).cuda().contiguous()
+    res = rbf(torch.randn(N, Cin, H, W, generator=g))
+    dx = torch.zeros(N * H * W, Cin, dtype=BF, device='cuda')
+    if Cout % 64 == 0:
+        ops.conv2d(dyg, wt, dx, N, Ho, Wo, H, W, k, k, s, p, d, 1, to_pxc(res), None)
+        assert relerr(from_pxc(dx, N, H, W), xr.grad + res) < 1.5e-2, 'dgrad'
+    # weight gradient (accumulating: run twice -> 2x)
+    dw = torch.zeros(Cout, k * k, Cin, device='cuda')
+    ops.conv2d_wgrad(xg, dyg, dw, N, H, W, Ho, Wo, k, k, s, p, d)
+    ops.conv2d_wgrad(xg, dyg, dw, N, H, W, Ho, Wo, k, k, s, p, d)
+    dwr = wr.grad.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin) * 2
+    assert relerr(dw.cpu(), dwr) < 2e-3, 'wgrad'
+
+
+def test_conv_strided_views_and_row_tail(ops):
+    """ld > C on both sides (channel-slice views of a concat buffer) and M not a tile multiple."""
+    g = torch.Generator().manual_seed(4)
+    N, H, W, Cin, Cout = 1, 9, 7, 64, 64
+    x = rbf(torch.randn(N, Cin, H, W, generator=g))
+    w = rbf(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1)
+    big = torch.zeros(N * H * W, 192, dtype=BF, device='cuda')
+    big[:, 64:128] = to_pxc(x)
+    outb = torch.full((N * H * W, 256), 7.0, dtype=BF, device='cuda')
+    ops.conv2d(big[:, 64:128], w.reshape(Cout, 1, Cin).to(BF).cuda(), outb[:, 128:192], N, H, W, H, W, 1, 1, 1, 0, 1)
+    assert relerr(from_pxc(outb[:, 128:192], N, H, W), F.conv2d(x, w)) < 1e-2
+    assert (outb[:, :128] == 7).all() and (outb[:, 192:] == 7).all()
+
+
+def test_stem_im2col_and_gemm(ops):
+    g = torch.Generator().manual_seed(1)
+    N, H, W = 2, 32, 48
+    img = torch.randn(N, 3, H, W, generator=g)
+    w = rbf(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    Ho, Wo = H // 2, W // 2
+    col = torch.empty(N * Ho * Wo, 192, dtype=BF, device='cuda')
+    ops.stem_im2col(img.cuda(), col, N, H, W, Ho, Wo)
+    wp = torch.zeros(64, 192, dtype=BF, device='cuda')
+    ops.pad_cast_bf16(w.permute(0, 2, 3, 1).reshape(64, 147).contiguous().cuda(), wp, 64, 147, 192)
+    y = torch.empty(N * Ho * Wo, 64, dtype=BF, device='cuda')
+    ops.conv2d(col, wp.reshape(64, 1, 192), y, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
+    ref = F.conv2d(rbf(img), w, None, 2, 3)
+    assert relerr(from_pxc(y, N, Ho, Wo), ref) < 1e-2
+
+
+def test_batchnorm_fwd_bwd(ops):
+    g = torch.Generator().manual_seed(2)
+    N, C, H, W = 4, 64, 8, 8
+    M = N * H * W
+    x = rbf(torch.randn(N, C, H, W, generator=g) * 2 + 0.5)
+    res = rbf(torch.randn(N, C, H, W, generator=g))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm2, rv2 = rm.clone(), rv.clone()
+    yr = F.relu(F.batch_norm(xr, rm2, rv2, gr, br, True, 0.1, 1e-5) + res)
+    go = rbf(torch.randn(N, C, H, W, generator=g))
+    yr.backward(go)
+    xg = to_pxc(x)
+    stats = torch.zeros(2, C, device='cuda')
+    ops.bn_stats(xg, stats, M, C)
+    mi = torch.empty(2, C, device='cuda')
+    rmg, rvg, nbt = rm.cuda(), rv.cuda(), torch.zeros((), dtype=torch.int64, device='cuda')
+    ops.bn_finalize(stats, mi, rmg, rvg, nbt, M, C)
+    torch.testing.assert_close(rmg.cpu(), rm2, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rvg.cpu(), rv2, rtol=1e-4, atol=1e-5)
+    assert int(nbt) == 1
+    y = torch.empty(M, C, dtype=BF, device='cuda')
+    ops.bn_apply(xg, mi, gamma.cuda(), beta.cuda(), y, M, C, True, to_pxc(res))
+    assert relerr(from_pxc(y, N, H, W), yr.detach()) < 1e-2
+    sums = torch.empty(2, C, device='cuda')
+    gg = to_pxc(go)
+    ops.bn_bwd_reduce(gg, y, xg, mi, sums, M, C, True)
+    dx = torch.empty(M, C, dtype=BF, device='cuda')
+    gm = torch.empty(M, C, dtype=BF, device='cuda')
+    dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_bwd_apply(gg, y, xg, mi, gamma.cuda(), sums, dx, M, C, True, gm, dgam, dbet)
+    assert relerr(from_pxc(dx, N, H, W), xr.grad) < 2e-2
+    assert relerr(dgam.cpu(), gr.grad) < 1e-2 and relerr(dbet.cpu(), br.grad) < 1e-2
+    # gmask = gradient reaching the residual branch
+    assert relerr(from_pxc(gm, N, H, W), go * (yr.detach() > 0)) < 1e-2
+    # eval-mode finalize
+    mi2 = torch.empty(2, C, device='cuda')
+    ops.bn_finalize(None, mi2, rmg, rvg, None, M, C)
+    torch.testing.assert_close(mi2[1].cpu(), 1 / torch.sqrt(rvg.cpu() + 1e-5), rtol=1e-5, atol=1e-6)
+
+
+def test_bn_dropout_scale(ops):
+    g = torch.Generator().manual_seed(9)
+    N, C, HW = 2, 64, 16
+    M = N * HW
+    x = rbf(torch.randn(M, C, generator=g))
+    mi = torch.stack([torch.zeros(C), torch.ones(C)]).cuda()
+    ns = (torch.rand(N, C, generator=g) > 0.3).float() / 0.9
+    y = torch.empty(M, C, dtype=BF, device='cuda')
+    one, zero = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_apply(x.to(BF).cuda(), mi, one, zero, y, M, C, True, None, ns.cuda(), HW)
+    ref = F.relu(x).reshape(N, HW, C) * ns[:, None, :]
+    assert relerr(y.float().cpu().reshape(N, HW, C), ref) < 1e-2
+
+
+def test_maxpool(ops):
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = 2, 64, 12, 10
+    x = rbf(torch.randn(N, C, H, W, generator=g)).clamp(min=0)        # post-ReLU: many ties at 0
+    x = (x * 4).round() / 4                                            # ... and ties at non-zero values
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    go = rbf(torch.randn_like(yr))
+    yr.backward(go)
+    Ho, Wo = yr.shape[-2:]
+    y = torch.empty(N * Ho * Wo, C, dtype=BF, device='cuda')
+    idx = torch.empty(N * Ho * Wo, C, dtype=torch.uint8, device='cuda')
+    ops.maxpool_fwd(to_pxc(x), y, idx, N, H, W, C, Ho, Wo)
+    assert torch.equal(from_pxc(y, N, Ho, Wo), yr.detach())
+    gx = torch.empty(N * H * W, C, dtype=BF, device='cuda')
+    ops.maxpool_bwd(to_pxc(go), idx, gx, N, H, W, C, Ho, Wo)
+    assert relerr(from_pxc(gx, N, H, W), xr.grad) < 1e-2
+
+
+def test_instnorm(ops):
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 2, 128, 5, 7
+    HW = H * W
+    x = rbf(torch.randn(N, C, H, W, generator=g) * 3 + 1)
+    xr = x.clone().requires_grad_(True)
+    yr = F.instance_norm(xr, eps=1e-5)
+    ga, gb = rbf(torch.randn(N, C, H, W, generator=g)), rbf(torch.randn(N, C, H, W, generator=g))
+    gc = torch.randn(N, C, H, W, generator=g)
+    yr.backward(ga + gb + gc)
+    cat = torch.zeros(N * HW, 256, dtype=BF, device='cuda')
+    feat = torch.empty(N, C, H, W, device='cuda')
+    mi = torch.empty(N, 2, C, device='cuda')
+    ops.instnorm_fwd(to_pxc(x), cat[:, :C], None, feat, mi, N, HW, C)
+    torch.testing.assert_close(feat.cpu(), yr.detach(), rtol=1e-4, atol=1e-4)
+    assert relerr(from_pxc(cat[:, :C], N, H, W), yr.detach()) < 1e-2
+    dx = torch.empty(N * HW, C, dtype=BF, device='cuda')
+    gcp = gc.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda()
+    ops.instnorm_bwd(to_pxc(ga), to_pxc(gb), gcp, to_pxc(x), mi, dx, N, HW, C)
+    assert relerr(from_pxc(dx, N, H, W), xr.grad) < 2e-2
+
+
+def test_spatial_mix_pool_and_upsample(ops):
+    from regda_amd.models.Encoder import pool_matrix, upsample_matrix
+    g = torch.Generator().manual_seed(6)
+    N, C, H, W = 2, 64, 32, 32
+    x = rbf(torch.randn(N, C, H, W, generator=g))
+    xg = to_pxc(x)
+    for s in (1, 2, 3, 6):
+        P = pool_matrix(H, W, s)
+        q = torch.empty(N * s * s, C, dtype=BF, device='cuda')
+        ops.spatial_mix(xg, P.cuda(), q, N, s * s, H * W, C)
+        refq = F.adaptive_avg_pool2d(x, s)
+        assert relerr(from_pxc(q, N, s, s), refq) < 1e-2, s
+        U = upsample_matrix(s, s, H, W)
+        up = torch.empty(N * H * W, C, dtype=BF, device='cuda')
+        ops.spatial_mix(q, U.cuda(), up, N, H * W, s * s, C)
+        refu = F.interpolate(from_pxc(q, N, s, s), (H, W), mode='bilinear', align_corners=False)
+        assert relerr(from_pxc(up, N, H, W), refu) < 1e-2, s
+
+
+def test_classifier(ops):
+    g = torch.Generator().manual_seed(7)
+    N, C, H, W = 2, 512, 4, 4
+    hid = rbf(torch.randn(N, C, H, W, generator=g))
+    w, b = torch.randn(6, C, generator=g) * 0.05, torch.randn(6, generator=g)
+    hr, wr, br_ = hid.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out = F.conv2d(hr, wr[:, :, None, None], br_)
+    gl = torch.randn_like(out)
+    out.backward(gl)
+    hg = to_pxc(hid)
+    logits = torch.empty(N, 6, H, W, device='cuda')
+    ops.classifier_fwd(hg, w.cuda(), b.cuda(), logits, N, H * W, C, 6)
+    torch.testing.assert_close(logits.cpu(), out.detach(), rtol=1e-4, atol=1e-4)
+    dh = torch.empty(N * H * W, C, dtype=BF, device='cuda')
+    dw, db = torch.zeros(6, C, device='cuda'), torch.zeros(6, device='cuda')
+    ops.classifier_bwd(hg, w.cuda(), gl.cuda(), dh, dw, db, N, H * W, C, 6)
+    assert relerr(from_pxc(dh, N, H, W), hr.grad) < 1e-2
+    torch.testing.assert_close(dw.cpu(), wr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), br_.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_optimizer_kernels(ops):
+    g = torch.Generator().manual_seed(8)
+    n = 4096 * 3 + 8
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
+    v = torch.zeros(n)
+    sh = p.clone()
+    pd, gd, vd, sd = p.cuda(), gr.cuda(), v.cuda(), sh.cuda()
+    pb = torch.empty(n, dtype=BF, device='cuda')
+    gn, ws = torch.empty(1, device='cuda'), torch.empty(1024, device='cuda')
+    lr = torch.tensor([0.01], device='cuda')
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    for step in range(2):
+        ops.sumsq(gd, gn, ws)
+        assert gn.item() == pytest.approx((gr.double() ** 2).sum().item(), rel=1e-5)
+        ops.sgd_step(pd, gd, vd, sd, pb, gn, lr, 0.9, 5e-4, 32.0, 1.0, 0.99, step == 0)
+        pr.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 32.0)
+        opt.step()
+        sh = 0.01 * pr.detach() + 0.99 * sh
+    torch.testing.assert_close(pd.cpu(), pr.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sd.cpu(), sh, rtol=1e-5, atol=1e-6)
+    assert torch.equal(pb.cpu(), pd.cpu().to(BF))
+    w = torch.randn(40, 9, 24, generator=g)
+    wt = torch.empty(24, 9, 40, dtype=BF, device='cuda')
+    ops.weight_transpose_bf16(w.cuda(), wt, 40, 9, 24)
+    assert torch.equal(wt.cpu(), w.permute(2, 1, 0).to(BF))
+
+
+@pytest.mark.parametrize('C,N,HW', [(512, 4, 64), (64, 2, 16)])
+def test_batchnorm_bwd_with_dropout_scale(ops, C, N, HW):
+    """conv_last BN + ReLU + Dropout2d (per (image, channel) scale) backward vs autograd."""
+    g = torch.Generator().manual_seed(12)
+    M = N * HW
+    x = rbf(torch.randn(M, C, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    ns = (torch.rand(N, C, generator=g) > 0.1).float() / 0.9
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    xn = xr.reshape(N, HW, C).permute(0, 2, 1)                    # (N, C, HW)
+    yr = F.relu(F.batch_norm(xn, None, None, gr, br, True, 0.1, 1e-5)) * ns[:, :, None]
+    go = rbf(torch.randn(N, C, HW, generator=g))
+    yr.backward(go)
+    xg = x.to(BF).cuda()
+    stats = torch.zeros(2, C, device='cuda')
+    ops.bn_stats(xg, stats, M, C)
+    mi = torch.empty(2, C, device='cuda')
+    ops.bn_finalize(stats, mi, None, None, None, M, C)
+    y = torch.empty(M, C, dtype=BF, device='cuda')
+    ops.bn_apply(xg, mi, gamma.cuda(), beta.cuda(), y, M, C, True, None, ns.cuda(), HW)
+    ref_y = yr.detach().permute(0, 2, 1).reshape(M, C)
+    assert relerr(y.float().cpu(), ref_y) < 1e-2
+    gg = go.permute(0, 2, 1).reshape(M, C).to(BF).cuda().contiguous()
+    sums = torch.empty(2, C, device='cuda')
+    ops.bn_bwd_reduce(gg, y, xg, mi, sums, M, C, True, ns.cuda(), HW)
+    dx = torch.empty(M, C, dtype=BF, device='cuda')
+    dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_bwd_apply(gg, y, xg, mi, gamma.cuda(), sums, dx, M, C, True, None, dgam, dbet, ns.cuda(), HW)
+    assert relerr(dx.float().cpu(), xr.grad) < 2e-2
+    assert relerr(dgam.cpu(), gr.grad) < 1e-2 and relerr(dbet.cpu(), br.grad) < 1e-2

@@ -1,0 +1,82 @@
+"""CPU: the N>1 gradient exchange (regda_amd/ddp.py) with the gloo backend, world_size 2, plus the
+bucket planner.  The same class drives RCCL on the GPUs."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from regda_amd.ddp import FlatGradReducer, make_buckets
+
+
+def test_bucket_plan_covers_buffer_in_reverse():
+    b = make_buckets([100, 300, 350, 900], 1000, 200)
+    assert b[0] == (900, 1000) or b[0][1] == 1000
+    # contiguous, descending, complete
+    assert b[-1][0] == 0
+    for (a0, a1), (b0, b1) in zip(b, b[1:]):
+        assert b1 == a0 and a0 < a1
+    assert sum(e - s for s, e in b) == 1000
+    assert make_buckets([], 10, 4) == [(0, 10)]
+    # every bucket except the last-issued reaches the minimum size
+    assert all(e - s >= 200 for s, e in b[:-1])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n = 10000
+    g = torch.Generator().manual_seed(rank)
+    flat = torch.randn(n, generator=g)
+    mine = flat.clone()
+    red = FlatGradReducer(flat, [1000, 2500, 6000, 9000], bucket_elems=2000)
+    red.reset()
+    # backward progresses from the end of the buffer to the start
+    for off in (9000, 6000, 2500, 1000):
+        red.ready_down_to(off)
+    red.finish()
+    others = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(others, mine)
+    expect = sum(others)
+    ok = torch.allclose(flat, expect, rtol=1e-6, atol=1e-6)
+    # the scale folded into the optimizer turns the sum into the mean
+    ok = ok and abs(red.gscale - 1.0 / world) < 1e-12
+    # a second step reuses the reducer
+    flat.copy_(mine)
+    red.reset()
+    red.finish()
+    ok = ok and torch.allclose(flat, expect, rtol=1e-6, atol=1e-6)
+    q.put((rank, bool(ok), len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_reducer_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert all(nb >= 3 for _, _, nb in res)
+
+
+def test_single_process_reducer_is_a_noop():
+    flat = torch.arange(10.0)
+    red = FlatGradReducer(flat, [5], bucket_elems=2)
+    red.reset()
+    red.ready_down_to(5)
+    red.finish()
+    assert torch.equal(flat, torch.arange(10.0)) and red.gscale == 1.0

@@ -1,0 +1,97 @@
+"""CPU: host-side logic that needs no GPU -- lr schedule mirror, config surface, spatial matrices,
+synthetic data contracts, fail-loud behaviour without a GPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def test_lr_schedule_matches_reference_golden(gold):
+    from regda_amd.utils.tools import adjust_learning_rate
+    g = gold('lr_ema.npz')
+
+    class Cfg:
+        LEARNING_RATE, POWER, NUM_STEPS, PREHEAT_STEPS = 1e-2, 0.9, 6000 * 1.5, int(6000 / 20)
+
+    class Opt:
+        param_groups = [dict(lr=0.0)]
+    for it, lr in zip(g['its'], g['lrs']):
+        o = Opt()
+        assert adjust_learning_rate(o, int(it), Cfg) == pytest.approx(float(lr), rel=1e-12, abs=0)
+        assert o.param_groups[0]['lr'] == pytest.approx(float(lr), rel=1e-12, abs=0)
+
+
+def test_config_surface():
+    from regda_amd.utils.tools import import_config
+    import os, tempfile
+    cwd = os.getcwd()
+    for name in ('st.regda.2potsdam', 'st.regda.2vaihingen'):
+        cfg = import_config(name, create=False, copy=False, postfix='/ssl')
+        for attr in ('MODEL IGNORE_LABEL MOMENTUM SNAPSHOT_DIR WEIGHT_DECAY LEARNING_RATE STAGE1_STEPS STAGE2_STEPS '
+                     'STAGE3_STEPS NUM_STEPS PREHEAT_STEPS POWER EVAL_EVERY GENE_EVERY CUTOFF_TOP CUTOFF_LOW '
+                     'TARGET_DATA_CONFIG SOURCE_DATA_CONFIG TARGET_SET DATASETS').split():
+            assert hasattr(cfg, attr), (name, attr)
+        assert cfg.MODEL == 'ResNet101' and cfg.IGNORE_LABEL == -1 and cfg.STAGE3_STEPS == 6000
+        assert cfg.CUTOFF_TOP == 0.8 and cfg.CUTOFF_LOW == 0.6 and cfg.LEARNING_RATE == 1e-2
+        assert cfg.SNAPSHOT_DIR.endswith('/ssl')
+        assert cfg.TARGET_DATA_CONFIG['batch_size'] == 8 and cfg.SOURCE_DATA_CONFIG['batch_size'] == 8
+    assert os.getcwd() == cwd
+
+
+def test_spatial_matrices_match_torch():
+    from regda_amd.models.Encoder import pool_matrix, upsample_matrix
+    g = torch.Generator().manual_seed(0)
+    for (h, w) in [(32, 32), (4, 4), (7, 5)]:
+        x = torch.randn(2, 3, h, w, generator=g)
+        for s in (1, 2, 3, 6):
+            P = pool_matrix(h, w, s)
+            got = (P @ x.reshape(2, 3, h * w).transpose(1, 2)).transpose(1, 2).reshape(2, 3, s, s)
+            torch.testing.assert_close(got, F.adaptive_avg_pool2d(x, s), rtol=1e-5, atol=1e-6)
+            q = torch.randn(2, 3, s, s, generator=g)
+            U = upsample_matrix(s, s, h, w)
+            up = (U @ q.reshape(2, 3, s * s).transpose(1, 2)).transpose(1, 2).reshape(2, 3, h, w)
+            torch.testing.assert_close(up, F.interpolate(q, (h, w), mode='bilinear', align_corners=False),
+                                       rtol=1e-5, atol=1e-6)
+
+
+def test_synthetic_batch_contract():
+    from regda_amd.synthetic import make_batch
+    b = make_batch(b=2, size=64, seed=1, device='cpu')
+    assert b['images_s'].shape == (2, 3, 64, 64) and b['images_s'].dtype == torch.float32
+    assert b['images_t'].max() <= 1.0                       # target tensors are clamped (aug/augmentation.py:118-122)
+    assert b['label_s'].dtype == torch.int64 and b['label_s'].min() >= -1 and b['label_s'].max() <= 5
+    assert b['regs_t'].shape == (2, 1, 64, 64) and b['regs_t'].dtype == torch.int64 and b['regs_t'].min() == 0
+    torch.testing.assert_close(b['soft_t'].sum(1), torch.ones(2, 64, 64), rtol=1e-5, atol=1e-5)
+    b2 = make_batch(b=2, size=64, seed=1, device='cpu')
+    assert all(torch.equal(b[k], b2[k]) for k in b)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only behaviour')
+def test_no_cpu_fallback():
+    from regda_amd.models.Encoder import Deeplabv2
+    from regda_amd.utils.local_region_homog import Homogenizer
+    with pytest.raises(RuntimeError):
+        Deeplabv2(dict(backbone=dict(resnet_type='resnet101'), multi_layer=True, use_ppm=True, is_ins_norm=True,
+                       num_classes=6))
+    with pytest.raises(RuntimeError):
+        Homogenizer(0.5, 6, -1)(torch.zeros(1, 4, 4, dtype=torch.int64), torch.zeros(1, 4, 4, dtype=torch.int64))
+
+
+def test_ema_mirror_semantics(gold):
+    from regda_amd.utils.ema import ExponentialMovingAverage
+    g = gold('lr_ema.npz')
+    lin = torch.nn.Linear(3, 2)
+    m = torch.nn.Sequential(lin, torch.nn.BatchNorm1d(2))
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(g['w0']))
+    ema = ExponentialMovingAverage(m, 0.99)
+    ema.register()
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(g['w1']))
+    ema.update()
+    np.testing.assert_allclose(ema.shadow['0.weight'].numpy(), g['shadow'], rtol=1e-6)
+    assert sorted(ema.shadow.keys()) == list(g['shadow_keys'])
+    ema.apply_shadow()
+    np.testing.assert_allclose(lin.weight.detach().numpy(), g['shadow'], rtol=1e-6)
+    ema.restore()
+    np.testing.assert_allclose(lin.weight.detach().numpy(), g['w1'], rtol=1e-6)

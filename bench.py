@@ -53,7 +53,8 @@ def conv_flops_probe(step_fn):
         o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats)
         e1.record()
         co, taps, ci = w.shape
-        rec.append(('dgrad' if mode else 'fwd', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1))
+        rec.append(('dgrad' if mode else 'fwd', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1,
+                    (N * Ho * Wo, co, ci, taps, stride, dil)))
 
     def wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -61,7 +62,7 @@ def conv_flops_probe(step_fn):
         o_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil)
         e1.record()
         co, taps, ci = dw.shape
-        rec.append(('wgrad', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1))
+        rec.append(('wgrad', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1, (N * Ho * Wo, co, ci, taps, stride, dil)))
     ops.conv2d, ops.conv2d_wgrad = conv, wgrad
     try:
         step_fn()
@@ -69,7 +70,17 @@ def conv_flops_probe(step_fn):
     finally:
         ops.conv2d, ops.conv2d_wgrad = o_conv, o_wgrad
     kinds = {}
-    for kind, fl, e0, e1 in rec:
+    shapes = {}
+    for kind, fl, e0, e1, shp in rec:
+        q = shapes.setdefault((kind,) + shp, [0.0, 0.0, 0])
+        q[0] += fl
+        q[1] += e0.elapsed_time(e1)
+        q[2] += 1
+    if os.environ.get('RGDA_CONV_REPORT'):
+        with open(os.environ['RGDA_CONV_REPORT'], 'w') as f:
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                f.write('%-6s M=%-7d Co=%-5d Ci=%-5d taps=%d s=%d d=%d  n=%-3d ms=%8.3f  TF/s=%7.1f\n' % (k + (v[2], v[1], v[0] / 1e9 / max(v[1], 1e-9))))
+    for kind, fl, e0, e1, shp in rec:
         k = kinds.setdefault(kind, [0.0, 0.0, 0])
         k[0] += fl
         k[1] += e0.elapsed_time(e1)

@@ -27,6 +27,10 @@ extern "C" {
 #endif
 
 #define RGDA_ABI_VERSION 1
+/* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
+ * copy b % 8, i.e. the copy of the XCD it runs on, so the fp32 atomics stay inside one XCD's L2); consumers
+ * sum the copies.  A "stats"/"sums" buffer is therefore f32[RGDA_STAT_REPLICAS][2][C], zeroed by the caller. */
+#define RGDA_STAT_REPLICAS 8
 
 typedef void* rgda_stream_t; /* hipStream_t */
 
@@ -120,7 +124,7 @@ int rgda_class_count(const int64_t* label, int32_t* cnt, int64_t n, int c, rgda_
  *   wgt : [Cout][kh*kw][Cin] bf16  (mode 1: [Cin_of_fwd][kh*kw][Cout_of_fwd])
  *   y   : [N*Ho*Wo][ldy] bf16
  *   res : NULL or [N*Ho*Wo][ldres] bf16 added to the result before the store
- *   stats: NULL or f32[2][Cout]; per-channel sum and sum of squares of the
+ *   stats: NULL or f32[RGDA_STAT_REPLICAS][2][Cout]; per-channel sum and sum of squares of the
  *          (bf16-rounded) outputs are atomically accumulated (BatchNorm batch stats)
  *   mode 0: y[n,ho,wo] = sum x[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil] * w
  *   mode 1: y[n,ho,wo] = sum x[n, (ho+pad-kh*dil)/stride, (wo+pad-kw*dil)/stride] * w
@@ -142,7 +146,7 @@ int rgda_stem_im2col(const float* img, void* col, int N, int H, int W, int Ho, i
                      rgda_stream_t stream);
 
 /* BatchNorm2d (train) on PxC bf16, nn.BatchNorm2d defaults (eps 1e-5, momentum .1):
- *  finalize: stats f32[2][C] (sum,sumsq over M rows) -> mean/invstd f32[2][C] in `mi`,
+ *  finalize: stats f32[REPLICAS][2][C] (sum,sumsq over M rows) -> mean/invstd f32[2][C] in `mi`,
  *            running_mean/var/num_batches_tracked update.  If stats==NULL, eval mode:
  *            mi is filled from the running statistics.
  *  apply   : y = act( (x-mean)*invstd*gamma+beta [+ res] ) [* nscale[n][c]]
@@ -154,7 +158,8 @@ int rgda_bn_finalize(const float* stats, float* mi, float* running_mean, float* 
 int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, const float* beta,
                   const void* res, int ldres, const float* nscale, int rows_per_image, void* y,
                   int ldy, int64_t M, int C, int relu, rgda_stream_t stream);
-/* sums f32[2][C] must be zero on entry: sum(g'), sum(g' * xhat), g' = g*[y>0]*nscale */
+/* sums f32[REPLICAS][2][C] must be ZERO on entry (the caller clears one arena per backward pass):
+ * sums[0] += sum(g'), sums[1] += sum(g' * xhat), g' = g*[y>0]*nscale */
 int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
                        const float* mi, const float* nscale, int rows_per_image, float* sums,
                        int64_t M, int C, int relu, rgda_stream_t stream);

@@ -41,5 +41,6 @@ static __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+#define NREP RGDA_STAT_REPLICAS
 static inline hipStream_t to_stream(rgda_stream_t s) { return (hipStream_t)s; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a) {
             int which = t / BC, c = t % BC;
             float tot = red[(0 * 2 + which) * BC + c] + red[(1 * 2 + which) * BC + c] +
                         red[(2 * 2 + which) * BC + c] + red[(3 * 2 + which) * BC + c];
-            if (c0 + c < a.Cout) atomicAdd(&a.stats[which * a.Cout + c0 + c], tot);
+            if (c0 + c < a.Cout) atomicAdd(&a.stats[((blockIdx.x & (NREP - 1)) * 2 + which) * a.Cout + c0 + c], tot);
         }
     }
 }

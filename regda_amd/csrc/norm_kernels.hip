@@ -22,6 +22,18 @@ static RowLayout row_layout(int C) {
     return L;
 }
 
+// per-channel reductions: ~1024 workgroups, every thread sees at least 4 rows
+static int reduce_rows_per_block(long long M, const RowLayout& L) {
+    int ny = cdiv(L.vpr, L.vpb);
+    long long want = 512 / ny;
+    if (want < 1) want = 1;
+    long long rows = (M + want - 1) / want;
+    long long minrows = (long long)L.rpb * 4;
+    if (rows < minrows) rows = minrows;
+    rows = (rows + L.rpb - 1) / L.rpb * L.rpb;
+    return (int)rows;
+}
+
 static __device__ __forceinline__ void load8(const bf16_t* p, float (&f)[8]) {
     u16x8 v = *(const u16x8*)p;
 #pragma unroll
@@ -76,14 +88,14 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
         }
-    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, stats, stats + C, lds);
+    float* rep = stats + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NREP - 1)) * 2 * C;
+    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, rep, rep + C, lds);
 }
 
 extern "C" int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, int C, rgda_stream_t stream) {
     if (!x || !stats || M <= 0 || C <= 0 || (C & 7) || (ldx & 7)) return RGDA_ERR_ARG;
     RowLayout L = row_layout(C);
-    int rows_per_block = 256;
-    while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 4096) rows_per_block *= 2;
+    int rows_per_block = reduce_rows_per_block(M, L);
     dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
     bn_stats_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, stats, M, C, L.vpb, L.rpb, rows_per_block);
     RGDA_CHECK_LAUNCH();
@@ -96,8 +108,10 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, fl
     int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     if (stats) {
-        double mean = (double)stats[c] / M;
-        double var = (double)stats[C + c] / M - mean * mean;     // biased (normalisation)
+        double s0 = 0.0, s1 = 0.0;
+        for (int r = 0; r < NREP; ++r) { s0 += stats[(size_t)(2 * r) * C + c]; s1 += stats[(size_t)(2 * r + 1) * C + c]; }
+        double mean = s0 / M;
+        double var = s1 / M - mean * mean;     // biased (normalisation)
         if (var < 0) var = 0;
         mi[c] = (float)mean;
         mi[C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -225,7 +239,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
             for (int e = 0; e < 8; ++e) { s[e] += gf[e]; q[e] += gf[e] * ((xf[e] - mean[e]) * istd[e]); }
         }
     }
-    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, sums, sums + C, lds);
+    float* rep = sums + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NREP - 1)) * 2 * C;
+    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, rep, rep + C, lds);
 }
 
 extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
@@ -233,10 +248,8 @@ extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy
                                   int C, int relu, rgda_stream_t stream) {
     if (!g || !x || !mi || !sums || (relu && !y) || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || (ldx & 7)) return RGDA_ERR_ARG;
     hipStream_t st = to_stream(stream);
-    if (hipMemsetAsync(sums, 0, (size_t)2 * C * 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
     RowLayout L = row_layout(C);
-    int rows_per_block = 256;
-    while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 4096) rows_per_block *= 2;
+    int rows_per_block = reduce_rows_per_block(M, L);
     dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
     bn_bwd_reduce_kernel<<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mi,
                                                nscale, rows_per_image, sums, M, C, relu, L.vpb, L.rpb, rows_per_block);
@@ -264,16 +277,20 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
         istd[e] = mi[C + cg + e];
         float gi = gamma[cg + e] * istd[e];
         k0[e] = gi;
-        k1[e] = sums[cg + e] * invM;          // mean of g'
-        k2[e] = sums[C + cg + e] * invM;      // mean of g' * xhat
+        float t1 = 0.f, t2 = 0.f;
+        for (int r = 0; r < NREP; ++r) { t1 += sums[(size_t)(2 * r) * C + cg + e]; t2 += sums[(size_t)(2 * r + 1) * C + cg + e]; }
+        k1[e] = t1;
+        k2[e] = t2;
     }
     if (blockIdx.x == 0 && rl == 0 && dgamma) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            dgamma[cg + e] += sums[C + cg + e];
-            dbeta[cg + e] += sums[cg + e];
+            dgamma[cg + e] += k2[e];
+            dbeta[cg + e] += k1[e];
         }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { k1[e] *= invM; k2[e] *= invM; }
     long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     for (long long r = r0 + rl; r < r1; r += rpb) {
         float gf[8], xf[8];
@@ -564,17 +581,34 @@ extern "C" int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const 
 __global__ void __launch_bounds__(256) spatial_mix_kernel(const bf16_t* __restrict__ in, int ldin,
                                                           const float* __restrict__ Mx, void* out, int ldout, int I,
                                                           int J, int C, int accumulate, int out_f32) {
+    // block = (output row i, image n, 32 channel vectors) ; 8 thread slices split the J range
+    __shared__ float red[8][32][8];
     const int i = blockIdx.x, n = blockIdx.y;
+    const int cvl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int cv = blockIdx.z * 32 + cvl;
+    const bool cok = cv < C / 8;
     const float* mrow = Mx + (size_t)i * J;
-    for (int cv = threadIdx.x; cv < C / 8; cv += 256) {
+    {
         float acc[8] = {0};
-        for (int j = 0; j < J; ++j) {
-            float m = mrow[j];
-            if (m == 0.f) continue;
-            float f[8];
-            load8(in + ((size_t)n * J + j) * ldin + cv * 8, f);
+        if (cok)
+            for (int j = sl; j < J; j += 8) {
+                float m = mrow[j];
+                if (m == 0.f) continue;
+                float f[8];
+                load8(in + ((size_t)n * J + j) * ldin + cv * 8, f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += m * f[e];
+                for (int e = 0; e < 8; ++e) acc[e] += m * f[e];
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[sl][cvl][e] = acc[e];
+        __syncthreads();
+        if (sl != 0 || !cok) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a += red[q][cvl][e];
+            acc[e] = a;
         }
         size_t o = ((size_t)n * I + i) * ldout + cv * 8;
         if (out_f32) {
@@ -597,7 +631,7 @@ __global__ void __launch_bounds__(256) spatial_mix_kernel(const bf16_t* __restri
 extern "C" int rgda_spatial_mix(const void* in, int ldin, const float* Mx, void* out, int ldout, int N, int I, int J,
                                 int C, int accumulate, int out_f32, rgda_stream_t stream) {
     if (!in || !Mx || !out || N <= 0 || I <= 0 || J <= 0 || C <= 0 || (C & 7) || (ldin & 7) || (ldout & 7)) return RGDA_ERR_ARG;
-    dim3 grid(I, N);
+    dim3 grid(I, N, cdiv(C / 8, 32));
     spatial_mix_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)in, ldin, Mx, out, ldout, I, J, C, accumulate, out_f32);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;

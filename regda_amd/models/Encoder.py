@@ -25,6 +25,7 @@ BF = torch.bfloat16
 LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3),
           'resnet17t': (2, 1, 1, 2)}   # resnet17t: test-only shallow topology (same code paths, 6 blocks)
 POOL_SCALES = (1, 2, 3, 6)
+NREP = 8                # RGDA_STAT_REPLICAS (include/rgda_hip.h)
 STEM_KP = 192           # 7*7*3 = 147 im2col columns, zero padded to a multiple of 64
 
 
@@ -313,7 +314,7 @@ class Deeplabv2(nn.Module):
         return r
 
     def new_tape(self):
-        return {'stats_pool': _StatsPool(sum(2 * _pad64(b.c) for b in self.bns.values()) + 64, self.device)}
+        return {'stats_pool': _StatsPool(sum(NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, self.device)}
 
     def param_boundaries(self):
         """Element offsets (into flat_p / flat_g) where a residual block / head starts: legal bucket cuts."""
@@ -365,7 +366,7 @@ class Deeplabv2(nn.Module):
         M = N * Ho * Wo
         train = T is not None
         c = torch.empty(M, conv.co, dtype=BF, device=self.device)
-        stats = T['stats_pool'].take(2 * conv.co).view(2, conv.co) if train else None
+        stats = T['stats_pool'].take(NREP * 2 * conv.co) if train else None
         if geom is None:
             ops.conv2d(x, conv.wb if wb is None else wb, c, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad,
                        conv.dil, 0, None, stats)
@@ -387,7 +388,7 @@ class Deeplabv2(nn.Module):
     def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False):
         x, c, y, mi, (N, H, W, Ho, Wo), nscale = T[key]
         M, C = N * Ho * Wo, conv.co
-        sums = torch.empty(2, C, device=self.device)
+        sums = T['sums_pool'].take(NREP * 2 * C)
         ops.bn_bwd_reduce(g, y if relu else None, c, mi, sums, M, C, relu, nscale, Ho * Wo)
         dc = torch.empty(M, C, dtype=BF, device=self.device)
         gm = torch.empty(M, C, dtype=BF, device=self.device) if want_gmask else None
@@ -482,6 +483,7 @@ class Deeplabv2(nn.Module):
     # ------------------------------------------------------------------ backward plan
     def _backward_plan(self, T, g1, g2, on_progress=None):
         dev = self.device
+        T['sums_pool'] = _StatsPool(sum(NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)
         C, B = self.convs, self.bns
         y4, imi, (N, h, w) = T['inorm']
         HW, M = h * w, N * h * w

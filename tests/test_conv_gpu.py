@@ -58,14 +58,14 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     xg = to_pxc(x)
     wg = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin).to(BF).cuda().contiguous()
     y = torch.zeros(N * Ho * Wo, Cout, dtype=BF, device='cuda')
-    stats = torch.zeros(2, Cout, device='cuda')
+    stats = torch.zeros(8, 2, Cout, device='cuda')
     ops.conv2d(xg, wg, y, N, H, W, Ho, Wo, k, k, s, p, d, 0, None, stats)
     out = from_pxc(y, N, Ho, Wo)
     assert relerr(out, ref) < 1e-2, 'forward'
     # BatchNorm statistics fused in the epilogue (of the bf16-rounded outputs)
     yf = y.float()
-    torch.testing.assert_close(stats[0].cpu(), yf.sum(0).cpu(), rtol=1e-3, atol=1e-2)
-    torch.testing.assert_close(stats[1].cpu(), (yf * yf).sum(0).cpu(), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(stats.sum(0)[0].cpu(), yf.sum(0).cpu(), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(stats.sum(0)[1].cpu(), (yf * yf).sum(0).cpu(), rtol=1e-3, atol=1e-2)
     # data gradient = conv in mode 1 with [Cin][tap][Cout] weights (+ residual add in the epilogue)
     dy = rbf(torch.randn(N, Cout, Ho, Wo, generator=g))
     xr = x.clone().requires_grad_(True)
@@ -131,7 +131,7 @@ def test_batchnorm_fwd_bwd(ops):
     go = rbf(torch.randn(N, C, H, W, generator=g))
     yr.backward(go)
     xg = to_pxc(x)
-    stats = torch.zeros(2, C, device='cuda')
+    stats = torch.zeros(8, 2, C, device='cuda')
     ops.bn_stats(xg, stats, M, C)
     mi = torch.empty(2, C, device='cuda')
     rmg, rvg, nbt = rm.cuda(), rv.cuda(), torch.zeros((), dtype=torch.int64, device='cuda')
@@ -142,7 +142,7 @@ def test_batchnorm_fwd_bwd(ops):
     y = torch.empty(M, C, dtype=BF, device='cuda')
     ops.bn_apply(xg, mi, gamma.cuda(), beta.cuda(), y, M, C, True, to_pxc(res))
     assert relerr(from_pxc(y, N, H, W), yr.detach()) < 1e-2
-    sums = torch.empty(2, C, device='cuda')
+    sums = torch.zeros(8, 2, C, device='cuda')
     gg = to_pxc(go)
     ops.bn_bwd_reduce(gg, y, xg, mi, sums, M, C, True)
     dx = torch.empty(M, C, dtype=BF, device='cuda')
@@ -297,7 +297,7 @@ def test_batchnorm_bwd_with_dropout_scale(ops, C, N, HW):
     go = rbf(torch.randn(N, C, HW, generator=g))
     yr.backward(go)
     xg = x.to(BF).cuda()
-    stats = torch.zeros(2, C, device='cuda')
+    stats = torch.zeros(8, 2, C, device='cuda')
     ops.bn_stats(xg, stats, M, C)
     mi = torch.empty(2, C, device='cuda')
     ops.bn_finalize(stats, mi, None, None, None, M, C)
@@ -306,7 +306,7 @@ def test_batchnorm_bwd_with_dropout_scale(ops, C, N, HW):
     ref_y = yr.detach().permute(0, 2, 1).reshape(M, C)
     assert relerr(y.float().cpu(), ref_y) < 1e-2
     gg = go.permute(0, 2, 1).reshape(M, C).to(BF).cuda().contiguous()
-    sums = torch.empty(2, C, device='cuda')
+    sums = torch.zeros(8, 2, C, device='cuda')
     ops.bn_bwd_reduce(gg, y, xg, mi, sums, M, C, True, ns.cuda(), HW)
     dx = torch.empty(M, C, dtype=BF, device='cuda')
     dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')

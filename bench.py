@@ -47,10 +47,10 @@ def conv_flops_probe(step_fn):
     rec = []
     o_conv, o_wgrad = ops.conv2d, ops.conv2d_wgrad
 
-    def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None):
+    def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats)
+        o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups)
         e1.record()
         co, taps, ci = w.shape
         rec.append(('dgrad' if mode else 'fwd', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1,

@@ -131,8 +131,8 @@ int rgda_class_count(const int64_t* label, int32_t* cnt, int64_t n, int c, rgda_
  *           (terms with a non-integer or out-of-range source are zero)
  * Requires Cin % 32 == 0, Cout % 8 == 0, ld* % 8 == 0. */
 int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res,
-                int ldres, float* stats, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream);
+                int ldres, float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo,
+                int Cout, int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream);
 
 /* Weight gradient: dw[co][tap][ci] (f32, row stride taps*Cin) +=
  *   sum_p dy[p][co] * x[src(p,tap)][ci]   (same geometry as mode 0 above). */
@@ -150,25 +150,29 @@ int rgda_stem_im2col(const float* img, void* col, int N, int H, int W, int Ho, i
  *            running_mean/var/num_batches_tracked update.  If stats==NULL, eval mode:
  *            mi is filled from the running statistics.
  *  apply   : y = act( (x-mean)*invstd*gamma+beta [+ res] ) [* nscale[n][c]]
- *  bwd     : two passes (reduce, apply) -- see kernels. */
+ *  bwd     : two passes (reduce, apply) -- see kernels.
+ * `groups` (>= 1): the M rows are `groups` equal blocks of rows (the source and the target batch of one
+ * SSL step run through the network together) that are normalised INDEPENDENTLY, like the reference's two
+ * separate forward calls; stats / sums are laid out [groups][REPLICAS][2][C], mi [groups][2][C]; running
+ * statistics are updated group after group. */
 int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, int C, rgda_stream_t stream);
 int rgda_bn_finalize(const float* stats, float* mi, float* running_mean, float* running_var,
-                     int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum,
-                     rgda_stream_t stream);
+                     int64_t* num_batches_tracked, int64_t M, int C, int groups, float eps,
+                     float momentum, rgda_stream_t stream);
 int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, const float* beta,
                   const void* res, int ldres, const float* nscale, int rows_per_image, void* y,
-                  int ldy, int64_t M, int C, int relu, rgda_stream_t stream);
+                  int ldy, int64_t M, int C, int relu, int groups, rgda_stream_t stream);
 /* sums f32[REPLICAS][2][C] must be ZERO on entry (the caller clears one arena per backward pass):
  * sums[0] += sum(g'), sums[1] += sum(g' * xhat), g' = g*[y>0]*nscale */
 int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
                        const float* mi, const float* nscale, int rows_per_image, float* sums,
-                       int64_t M, int C, int relu, rgda_stream_t stream);
+                       int64_t M, int C, int relu, int groups, rgda_stream_t stream);
 /* dx = gamma*invstd*(g' - sum(g')/M - xhat*sum(g' xhat)/M); gmask (optional) = g';
  * dgamma += sum(g' xhat), dbeta += sum(g') (f32, accumulated) */
 int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
                       const float* mi, const float* gamma, const float* nscale,
                       int rows_per_image, const float* sums, void* dx, int lddx, void* gmask,
-                      int ldgm, float* dgamma, float* dbeta, int64_t M, int C, int relu,
+                      int ldgm, float* dgamma, float* dbeta, int64_t M, int C, int relu, int groups,
                       rgda_stream_t stream);
 
 /* MaxPool2d(3,2,1) on PxC bf16 (regda/_resnets.py:153); idx = argmax tap (uint8). */

@@ -14,6 +14,9 @@
 //     ds_read_b64_tr_b16 transposing reads (4 k-rows x 16 columns per 16-lane group).
 // Epilogue (forward): accumulators -> bf16 -> LDS -> 16-byte coalesced row stores, with the
 // optional residual add and the per-channel sum / sum-of-squares of BatchNorm folded in.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 struct ConvArgs {
@@ -26,6 +29,7 @@ struct ConvArgs {
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, mode;
     int M;
     int tiles_c, tiles_p;
+    int rows_per_group;   // BatchNorm statistics are kept per group of rows (src / tgt batch)
 };
 
 static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -52,30 +56,46 @@ static __device__ __forceinline__ void src_coord(int mode, int base, int t, int 
     }
 }
 
-template <int BC, int BP>
-__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a) {
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int BC, int BP, int STAGES = 3>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only
     constexpr int FI = BC / 64, FJ = BP / 64;
-    constexpr int WL = BC / 32, XL = BP / 32;          // 16-byte loads per thread per tile
+    constexpr int WL = BC / 32, XL = BP / 32;          // LDS-DMA instructions per wave per tile (1 KiB each)
+    constexpr int LD = WL + XL;
     constexpr int TILE = (BC + BP) * 128;               // bytes of one K tile (64 channels)
     constexpr int CSTR = BC * 2 + 16;                   // epilogue row stride (bytes)
     constexpr int EPI = BP * CSTR + 4 * BC * 2 * 4;
-    constexpr int SMEM = (2 * TILE > EPI) ? 2 * TILE : EPI;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    constexpr int SMEM = (STAGES * TILE > EPI) ? STAGES * TILE : EPI;
+    __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wc = wave & 1, wp = wave >> 1;
     const int logical = xcd_remap(blockIdx.x, a.tiles_c * a.tiles_p);
     const int c0 = (logical % a.tiles_c) * BC;
     const int m0 = (logical / a.tiles_c) * BP;
     const int taps = a.KH * a.KW;
-    const int v = t & 7, r0 = t >> 3;
+    // LDS-DMA geometry: instruction q of this wave fills rows q*32 + wave*8 .. +8 of the tile; lane -> (row, slot).
+    // Loads are buffer_load_dwordx4 ... lds: per-lane 32-bit byte offset (fixed for W rows, recomputed once
+    // per filter tap for the gathered pixel rows) + ONE scalar offset per K tile; rows that are padding /
+    // out of range carry an out-of-range offset and the hardware deposits zeros (tests/test_hw_semantics_gpu.py).
+    const int lrow8 = lane >> 3, lslot = lane & 7;
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (int)((size_t)a.Cout * taps * a.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2), 0x00020000);
 
     // ---- per-thread pixel rows (fixed for the whole K loop)
-    int xn[XL], xh[XL], xw[XL];
+    int xn[XL], xh[XL], xw[XL], xsw[XL];
     bool xm[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-        int m = m0 + r0 + 32 * i;
+        int r = i * 32 + wave * 8 + lrow8;
+        int m = m0 + r;
         xm[i] = m < a.M;
         int mm = xm[i] ? m : 0;
         int n = mm / (a.Ho * a.Wo), rem = mm % (a.Ho * a.Wo);
@@ -83,20 +103,19 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a) {
         xn[i] = n * a.H * a.W;
         if (a.mode == 0) { xh[i] = ho * a.stride - a.pad; xw[i] = wo * a.stride - a.pad; }
         else             { xh[i] = ho + a.pad;            xw[i] = wo + a.pad; }
+        xsw[i] = (lslot ^ ((r >> 1) & 7)) * 16;           // swizzle lives on the SOURCE side (LDS image is lane-linear)
     }
-    const bf16_t* wrow[WL];
-    bool wm[WL];
+    int wvo[WL];
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-        int co = c0 + r0 + 32 * i;
-        wm[i] = co < a.Cout;
-        wrow[i] = a.w + (size_t)(wm[i] ? co : 0) * taps * a.Cin + v * 8;
+        int r = i * 32 + wave * 8 + lrow8;
+        int co = c0 + r;
+        wvo[i] = (co < a.Cout) ? (co * taps * a.Cin * 2 + (lslot ^ ((r >> 1) & 7)) * 16) : OOB;
     }
 
     // ---- loader state
     int tap = 0, kh = 0, kw = 0, ci0 = 0;
-    size_t xoff[XL];
-    bool xok[XL];
+    int xvo[XL];
     auto retap = [&]() {
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
@@ -104,19 +123,20 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a) {
             bool okh, okw;
             src_coord(a.mode, xh[i], kh, a.dil, a.stride, a.H, hi, okh);
             src_coord(a.mode, xw[i], kw, a.dil, a.stride, a.W, wi, okw);
-            xok[i] = xm[i] && okh && okw;
-            xoff[i] = xok[i] ? ((size_t)(xn[i] + hi * a.W + wi) * a.ldx + v * 8) : 0;
+            xvo[i] = (xm[i] && okh && okw) ? ((xn[i] + hi * a.W + wi) * a.ldx * 2 + xsw[i]) : OOB;
         }
     };
     retap();
-    u16x8 wreg[WL], xreg[XL];
-    auto gload = [&]() {
-        const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto issue = [&](int stage) {
+        unsigned char* wb = smem + stage * TILE + wave * 1024;
+        const int so_w = (tap * a.Cin + ci0) * 2, so_x = ci0 * 2;
 #pragma unroll
         for (int i = 0; i < WL; ++i)
-            wreg[i] = wm[i] ? *(const u16x8*)(wrow[i] + (size_t)tap * a.Cin + ci0) : zero;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * 4096), 16, wvo[i], so_w, 0, 0);
+        unsigned char* xb = wb + BC * 128;
 #pragma unroll
-        for (int i = 0; i < XL; ++i) xreg[i] = xok[i] ? *(const u16x8*)(a.x + xoff[i] + ci0) : zero;
+        for (int i = 0; i < XL; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(xb + i * 4096), 16, xvo[i], so_x, 0, 0);
     };
     auto advance = [&]() {
         ci0 += 64;
@@ -125,20 +145,6 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a) {
             ++tap;
             if (++kw == a.KW) { kw = 0; ++kh; }
             retap();
-        }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* wb = smem + buf * TILE;
-        unsigned char* xb = wb + BC * 128;
-#pragma unroll
-        for (int i = 0; i < WL; ++i) {
-            int r = r0 + 32 * i;
-            *(u16x8*)(wb + r * 128 + ((v ^ ((r >> 1) & 7)) << 4)) = wreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            int r = r0 + 32 * i;
-            *(u16x8*)(xb + r * 128 + ((v ^ ((r >> 1) & 7)) << 4)) = xreg[i];
         }
     };
 
@@ -151,14 +157,22 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT = taps * (a.Cin >> 6);
-    gload();
-    lstore(0);
-    __syncthreads();
+    issue(0);
+#pragma unroll
+    for (int p = 1; p < STAGES - 1; ++p)
+        if (p < KT) { advance(); issue(p); }
     const int lrow = lane & 31, lk = lane >> 5;
+    int stage = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) { advance(); gload(); }
-        const unsigned char* wb = smem + (kt & 1) * TILE;
+        // tile kt has landed once only the loads of the (up to STAGES-2) younger tiles are outstanding
+        const int younger = min(KT - 1 - kt, STAGES - 2);
+        if (younger >= 2) WAIT_VMCNT(2 * LD); else if (younger == 1) WAIT_VMCNT(LD); else WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < KT) {
+            advance();
+            issue(stage >= 1 ? stage - 1 : STAGES - 1);      // (kt + STAGES - 1) % STAGES
+        }
+        const unsigned char* wb = smem + stage * TILE;
         const unsigned char* xb = wb + BC * 128;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -179,9 +193,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a) {
                 for (int j = 0; j < FJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (more) lstore((kt + 1) & 1);
-        __syncthreads();
+        stage = (stage == STAGES - 1) ? 0 : stage + 1;
     }
+    __syncthreads();
 
     // ---- epilogue: accumulators -> bf16 C tile [pixel][cout] in LDS
 #pragma unroll
@@ -248,14 +262,16 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs a) {
             int which = t / BC, c = t % BC;
             float tot = red[(0 * 2 + which) * BC + c] + red[(1 * 2 + which) * BC + c] +
                         red[(2 * 2 + which) * BC + c] + red[(3 * 2 + which) * BC + c];
-            if (c0 + c < a.Cout) atomicAdd(&a.stats[((blockIdx.x & (NREP - 1)) * 2 + which) * a.Cout + c0 + c], tot);
+            if (c0 + c < a.Cout)
+                atomicAdd(&a.stats[(((size_t)(m0 / a.rows_per_group) * NREP + (blockIdx.x & (NREP - 1))) * 2 + which) * a.Cout + c0 + c], tot);
         }
     }
+#endif
 }
 
 extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                           float* stats, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
-                           int stride, int pad, int dil, int mode, rgda_stream_t stream) {
+                           float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                           int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream) {
     if (!x || !wgt || !y) return RGDA_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || dil <= 0 || pad < 0 || (mode != 0 && mode != 1))
@@ -272,15 +288,39 @@ extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int
     a.M = (int)M;
     hipStream_t st = to_stream(stream);
     // tile choice: fill 256 CUs (2 workgroups each); prefer the big tile when it still gives >= 512 groups
+    if (stat_groups < 1) stat_groups = 1;
+    if (M % stat_groups) return RGDA_ERR_ARG;
+    a.rows_per_group = (int)(M / stat_groups);
+    // tile choice: the biggest tile that still gives every CU a workgroup (bigger tile = more FLOP per byte
+    // pulled L2 -> LDS, which is what bounds these kernels: ~80 GB/s per CU, DESIGN.md "conv roofline")
     int bc = (Cout <= 64) ? 64 : 128;
-    long long big = (long long)cdiv(M, 128) * cdiv(Cout, bc);
-    int bp = (big >= 384) ? 128 : 64;
+    int bp = 64;
+    const int cands[3] = {256, 128, 64};
+    for (int k = 0; k < 3; ++k) {
+        int c = cands[k];
+        if (bc == 64 && c == 256) continue;
+        if ((long long)cdiv(M, c) * cdiv(Cout, bc) >= 240 || c == 64) { bp = c; break; }
+    }
+    if (stats && stat_groups > 1) {     // a tile may not straddle two statistics groups
+        while (bp > 64 && (a.rows_per_group % bp)) bp >>= 1;
+        if (a.rows_per_group % bp) return RGDA_ERR_UNSUPPORTED;
+    }
+    int stages = 3;
+    if (const char* e = getenv("RGDA_TILE")) sscanf(e, "%d,%d,%d", &bc, &bp, &stages);   // tuning experiments only
     a.tiles_c = cdiv(Cout, bc);
     a.tiles_p = cdiv(M, bp);
     int grid = a.tiles_c * a.tiles_p;
-    if (bc == 128 && bp == 128) conv_igemm_kernel<128, 128><<<grid, 256, 0, st>>>(a);
+    if (bc == 128 && bp == 256) conv_igemm_kernel<128, 256, 3><<<grid, 256, 0, st>>>(a);
+    else if (bc == 256 && bp == 128) conv_igemm_kernel<256, 128, 3><<<grid, 256, 0, st>>>(a);
+    else if (bc == 128 && bp == 128 && stages == 2) conv_igemm_kernel<128, 128, 2><<<grid, 256, 0, st>>>(a);
+    else if (bc == 128 && bp == 128 && stages == 4) conv_igemm_kernel<128, 128, 4><<<grid, 256, 0, st>>>(a);
+    else if (bc == 128 && bp == 128) conv_igemm_kernel<128, 128><<<grid, 256, 0, st>>>(a);
+    else if (bc == 128 && bp == 64 && stages == 2) conv_igemm_kernel<128, 64, 2><<<grid, 256, 0, st>>>(a);
+    else if (bc == 128 && bp == 64 && stages == 4) conv_igemm_kernel<128, 64, 4><<<grid, 256, 0, st>>>(a);
     else if (bc == 128 && bp == 64) conv_igemm_kernel<128, 64><<<grid, 256, 0, st>>>(a);
     else if (bc == 64 && bp == 128) conv_igemm_kernel<64, 128><<<grid, 256, 0, st>>>(a);
+    else if (stages == 4) conv_igemm_kernel<64, 64, 4><<<grid, 256, 0, st>>>(a);
+    else if (stages == 2) conv_igemm_kernel<64, 64, 2><<<grid, 256, 0, st>>>(a);
     else conv_igemm_kernel<64, 64><<<grid, 256, 0, st>>>(a);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
@@ -301,15 +341,18 @@ struct WgradArgs {
 };
 
 template <int BCO, int BCI>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
     constexpr int FI = BCO / 64, FJ = BCI / 64;
-    constexpr int SA = BCO * 2 + 64, SB = BCI * 2 + 64;   // LDS row strides (bytes): +64 B pad
-    constexpr int TILE = 64 * (SA + SB);
-    constexpr int VA = BCO / 8, VB = BCI / 8;             // 16-byte vectors per row
-    constexpr int LA = 64 * VA / 256, LB = 64 * VB / 256; // loads per thread per tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE];
+    constexpr int RA = BCO * 2, RB = BCI * 2;             // LDS row bytes (64 pixel rows per K tile)
+    constexpr int TA = 64 * RA, TB = 64 * RB, TILE = TA + TB;
+    constexpr int LA = TA / 4096, LB = TB / 4096;         // LDS-DMA instructions per wave per tile
+    constexpr int LD = LA + LB;
+    constexpr int STAGES = 3;
+    __shared__ __attribute__((aligned(256))) unsigned char smem[STAGES * TILE];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wi = wave & 1, wj = wave >> 1;
     const int taps = a.KH * a.KW;
     int bid = blockIdx.x;
@@ -323,45 +366,66 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
     const int kt_end = min(kt_beg + a.kt_per_split, (a.M + 63) >> 6);
     const bool pointwise = (taps == 1 && a.stride == 1 && a.pad == 0);
 
-    const int va = t % VA, ra = t / VA;     // dY tile: rows ra + (256/VA)*i
-    const int vb = t % VB, rb = t / VB;
-    const bool aok = (co0 + va * 8) < a.Cout;
-    const bool bok = (ci0 + vb * 8) < a.Cin;
-
-    u16x8 areg[LA], breg[LB];
-    auto gload = [&](int kt) {
-        const u16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    // LDS image: [64 pixel rows][RA bytes], lane-linear per 1 KiB instruction; the 64-byte granules of a
+    // row are XOR-swizzled with the row index so that the 4 pixel rows a transposing read touches fall
+    // into 4 different 64-byte bank slots (the permutation is applied to the SOURCE address).
+    //   256-byte rows: 4 rows / instruction, slot p = lane & 15, granule' = granule ^ (row & 3)
+    //   128-byte rows: 8 rows / instruction, slot p = lane & 7,  granule' = granule ^ ((row >> 1) & 1)
+    constexpr int RPA = 1024 / RA, RPB = 1024 / RB;       // rows per instruction
+    const int ra = lane / (RA / 16), pa = lane % (RA / 16);
+    const int rb = lane / (RB / 16), pb = lane % (RB / 16);
+    constexpr int OOB = (int)0x80000000;
+    // buffer descriptors sized to the last valid byte: pixel rows >= M fall out of range -> zeros
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((((size_t)a.M - 1) * a.lddy + a.Cout) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2), 0x00020000);
+    auto swz = [](int row, int slot, int rowbytes) {
+        int f = (rowbytes == 256) ? (row & 3) : ((row >> 1) & 1);
+        return (((slot >> 2) ^ f) << 2) | (slot & 3);
+    };
+    int avo[LA], brow[LB], bcolb[LB], bvo[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        int row = (i * 4 + wave) * RPA + ra;
+        int col = co0 + swz(row, pa, RA) * 8;
+        avo[i] = (col < a.Cout) ? ((row * a.lddy + col) * 2) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        brow[i] = (i * 4 + wave) * RPB + rb;
+        int col = ci0 + swz(brow[i], pb, RB) * 8;
+        bcolb[i] = (col < a.Cin) ? col * 2 : OOB;
+        bvo[i] = (col < a.Cin) ? ((brow[i] * a.ldx + col) * 2) : OOB;
+    }
+    auto issue = [&](int kt, int stage) {
         const int mb = kt << 6;
+        unsigned char* ab = smem + stage * TILE + wave * 1024;
+        const int so_a = mb * a.lddy * 2;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            int m = mb + ra + (256 / VA) * i;
-            areg[i] = (aok && m < a.M) ? *(const u16x8*)(a.dy + (size_t)m * a.lddy + co0 + va * 8) : zero;
-        }
+        for (int i = 0; i < LA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(ab + i * 4096), 16, avo[i], so_a, 0, 0);
+        unsigned char* bb = ab + TA;
+        if (pointwise) {
+            const int so_b = mb * a.ldx * 2;
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            int m = mb + rb + (256 / VB) * i;
-            bool ok = bok && m < a.M;
-            size_t src = (size_t)m;
-            if (!pointwise && ok) {
+            for (int i = 0; i < LB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bb + i * 4096), 16, bvo[i], so_b, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                int m = mb + brow[i];
                 int n, rem, ho, wo;
                 if (a.howo_shift >= 0) { n = m >> a.howo_shift; rem = m & ((1 << a.howo_shift) - 1); }
                 else { n = m / (a.Ho * a.Wo); rem = m % (a.Ho * a.Wo); }
                 if (a.wo_shift >= 0) { ho = rem >> a.wo_shift; wo = rem & ((1 << a.wo_shift) - 1); }
                 else { ho = rem / a.Wo; wo = rem % a.Wo; }
                 int hi = ho * a.stride - a.pad + kh * a.dil, wi2 = wo * a.stride - a.pad + kw * a.dil;
-                ok = hi >= 0 && hi < a.H && wi2 >= 0 && wi2 < a.W;
-                src = (size_t)(n * a.H + hi) * a.W + wi2;
+                bool ok = (m < a.M) && (bcolb[i] != OOB) && hi >= 0 && hi < a.H && wi2 >= 0 && wi2 < a.W;
+                int vo = ok ? (((n * a.H + hi) * a.W + wi2) * a.ldx * 2 + bcolb[i]) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bb + i * 4096), 16, vo, 0, 0, 0);
             }
-            breg[i] = ok ? *(const u16x8*)(a.x + src * a.ldx + ci0 + vb * 8) : zero;
         }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* ab = smem + buf * TILE;
-        unsigned char* bb = ab + 64 * SA;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) *(u16x8*)(ab + (ra + (256 / VA) * i) * SA + va * 16) = areg[i];
-#pragma unroll
-        for (int i = 0; i < LB; ++i) *(u16x8*)(bb + (rb + (256 / VB) * i) * SB + vb * 16) = breg[i];
     };
 
     f32x16 acc[FI][FJ];
@@ -373,36 +437,43 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kt_beg < kt_end) {
-        gload(kt_beg);
-        lstore(0);
-        __syncthreads();
+        issue(kt_beg, 0);
+        if (kt_beg + 1 < kt_end) issue(kt_beg + 1, 1);
         // transposing-read lane geometry: 16-lane group g reads a [4 k][16 col] block
         const int g = lane >> 4, la = lane & 15;
-        const int krow = (g >> 1) * 8 + (la >> 2);
-        const int kcol = (g & 1) * 16 + (la & 3) * 4;
+        const int krow = (g >> 1) * 8 + (la >> 2);          // + kk*16 (+4 for the second half)
+        const int kcol2 = ((g & 1) * 16 + (la & 3) * 4) * 2;  // byte offset inside a 64-byte granule pair
+        int stage = 0;
         for (int kt = kt_beg; kt < kt_end; ++kt) {
-            const bool more = kt + 1 < kt_end;
-            if (more) gload(kt + 1);
-            const int buf = (kt - kt_beg) & 1;
-            const unsigned char* ab = smem + buf * TILE;
-            const unsigned char* bb = ab + 64 * SA;
+            if (kt + 1 < kt_end) WAIT_VMCNT(LD); else WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < kt_end) issue(kt + 2, stage >= 1 ? stage - 1 : STAGES - 1);
+            const unsigned char* ab = smem + stage * TILE;
+            const unsigned char* bb = ab + TA;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 bf16x8 af[FI], bfr[FJ];
+                const int r0 = kk * 16 + krow, r1 = r0 + 4;
 #pragma unroll
                 for (int i = 0; i < FI; ++i) {
-                    const unsigned char* p = ab + (kk * 16 + krow) * SA + (wi * (BCO / 2) + i * 32 + kcol) * 2;
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * SA));
+                    int byte = (wi * (BCO / 2) + i * 32) * 2 + kcol2;           // column byte offset in the row
+                    int f0 = (RA == 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (RA == 256) ? (r1 & 3) : ((r1 >> 1) & 1);
+                    const unsigned char* p0 = ab + r0 * RA + ((((byte >> 6) ^ f0) << 6) | (byte & 63));
+                    const unsigned char* p1 = ab + r1 * RA + ((((byte >> 6) ^ f1) << 6) | (byte & 63));
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
                     u16x8 v8 = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
                                 (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
                     af[i] = __builtin_bit_cast(bf16x8, v8);
                 }
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
-                    const unsigned char* p = bb + (kk * 16 + krow) * SB + (wj * (BCI / 2) + j * 32 + kcol) * 2;
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * SB));
+                    int byte = (wj * (BCI / 2) + j * 32) * 2 + kcol2;
+                    int f0 = (RB == 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (RB == 256) ? (r1 & 3) : ((r1 >> 1) & 1);
+                    const unsigned char* p0 = bb + r0 * RB + ((((byte >> 6) ^ f0) << 6) | (byte & 63));
+                    const unsigned char* p1 = bb + r1 * RB + ((((byte >> 6) ^ f1) << 6) | (byte & 63));
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
                     u16x8 v8 = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
                                 (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
                     bfr[j] = __builtin_bit_cast(bf16x8, v8);
@@ -413,8 +484,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
                     for (int j = 0; j < FJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
-            if (more) lstore(buf ^ 1);
-            __syncthreads();
+            stage = (stage == STAGES - 1) ? 0 : stage + 1;
         }
     }
     // ---- split-K reduction: fp32 atomics straight into the gradient buffer (128 B per half-wave)
@@ -431,6 +501,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs a) {
                 if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * taps + tap) * a.Cin + ci, acc[i][j][r]);
             }
         }
+#endif
 }
 
 static int ilog2_exact(int v) {
@@ -461,10 +532,13 @@ extern "C" int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldd
     a.tiles_co = cdiv(Cout, bco);
     a.tiles_ci = cdiv(Cin, bci);
     int tiles = a.tiles_co * a.tiles_ci * kh * kw;
+    // split-K over the pixel dimension: ~512 workgroups, but never fewer than 16 K tiles per split (the
+    // 3-stage pipeline fill/drain and the fp32 atomics of the 64 KiB result tile must be amortised)
     int KT = cdiv(M, 64);
-    int splits = cdiv(1024, tiles);
-    if (splits > KT / 4) splits = KT / 4;
+    int splits = cdiv(512, tiles);
+    if (splits > KT / 16) splits = KT / 16;
     if (splits < 1) splits = 1;
+    if (const char* e = getenv("RGDA_WGRAD_SPLITS")) splits = atoi(e);                   // tuning experiments only
     a.kt_per_split = cdiv(KT, splits);
     a.splits = cdiv(KT, a.kt_per_split);
     int grid = tiles * a.splits;

@@ -104,37 +104,42 @@ extern "C" int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, in
 
 // ------------------------------------------------------------------ BN finalize
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, float* mi, float* rm, float* rv,
-                                                          long long* nbt, double M, int C, float eps, float mom) {
+                                                          long long* nbt, double M, int C, int groups, float eps,
+                                                          float mom) {
     int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    if (stats) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int r = 0; r < NREP; ++r) { s0 += stats[(size_t)(2 * r) * C + c]; s1 += stats[(size_t)(2 * r + 1) * C + c]; }
-        double mean = s0 / M;
-        double var = s1 / M - mean * mean;     // biased (normalisation)
-        if (var < 0) var = 0;
-        mi[c] = (float)mean;
-        mi[C + c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (rm) {
-            double unb = (M > 1) ? var * M / (M - 1.0) : var;   // unbiased (running update)
-            rm[c] = (1.f - mom) * rm[c] + mom * (float)mean;
-            rv[c] = (1.f - mom) * rv[c] + mom * (float)unb;
+    for (int g = 0; g < groups; ++g) {          // group after group: the reference runs src then tgt
+        const float* st = stats ? stats + (size_t)g * NREP * 2 * C : nullptr;
+        float* m = mi + (size_t)g * 2 * C;
+        if (st) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int r = 0; r < NREP; ++r) { s0 += st[(size_t)(2 * r) * C + c]; s1 += st[(size_t)(2 * r + 1) * C + c]; }
+            double mean = s0 / M;
+            double var = s1 / M - mean * mean;     // biased (normalisation)
+            if (var < 0) var = 0;
+            m[c] = (float)mean;
+            m[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (rm) {
+                double unb = (M > 1) ? var * M / (M - 1.0) : var;   // unbiased (running update)
+                rm[c] = (1.f - mom) * rm[c] + mom * (float)mean;
+                rv[c] = (1.f - mom) * rv[c] + mom * (float)unb;
+            }
+            if (c == 0 && nbt) *nbt += 1;
+        } else {
+            m[c] = rm[c];
+            m[C + c] = 1.f / sqrtf(rv[c] + eps);
         }
-        if (c == 0 && nbt) *nbt += 1;
-    } else {
-        mi[c] = rm[c];
-        mi[C + c] = 1.f / sqrtf(rv[c] + eps);
     }
 }
 
 extern "C" int rgda_bn_finalize(const float* stats, float* mi, float* running_mean, float* running_var,
-                                int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum,
-                                rgda_stream_t stream) {
-    if (!mi || C <= 0 || (!stats && (!running_mean || !running_var))) return RGDA_ERR_ARG;
-    if (stats && M < 2) return RGDA_ERR_ARG;   // "Expected more than 1 value per channel when training"
+                                int64_t* num_batches_tracked, int64_t M, int C, int groups, float eps,
+                                float momentum, rgda_stream_t stream) {
+    if (!mi || C <= 0 || groups < 1 || (M % groups) || (!stats && (!running_mean || !running_var))) return RGDA_ERR_ARG;
+    if (stats && M / groups < 2) return RGDA_ERR_ARG;   // "Expected more than 1 value per channel when training"
     bn_finalize_kernel<<<cdiv(C, 256), 256, 0, to_stream(stream)>>>(stats, mi, running_mean, running_var,
-                                                                      (long long*)num_batches_tracked, (double)M, C,
-                                                                      eps, momentum);
+                                                                      (long long*)num_batches_tracked,
+                                                                      (double)(M / groups), C, groups, eps, momentum);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
@@ -145,10 +150,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ beta, const bf16_t* __restrict__ res,
                                                        int ldres, const float* __restrict__ nscale, int rpi,
                                                        bf16_t* __restrict__ y, int ldy, long long M, int C, int relu,
-                                                       int vpb, int rpb, int rows_per_block) {
+                                                       int vpb, int rpb, int rows_per_block, int bpg) {
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
     if (cg >= C) return;
+    const int grp = blockIdx.x / bpg, chunk = blockIdx.x % bpg;     // M = rows of ONE group
+    mi += (size_t)grp * 2 * C;
     float mean[8], sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -156,7 +163,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
         sc[e] = mi[C + cg + e] * gamma[cg + e];
         sh[e] = beta[cg + e];
     }
-    long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
+    long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
     for (long long r = r0 + rl; r < r1; r += rpb) {
         float f[8];
         load8(x + r * ldx + cg, f);
@@ -181,24 +189,27 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
     }
 }
 
-static void elementwise_grid(long long M, int C, RowLayout& L, int& rows_per_block, dim3& grid) {
+// M = rows of ONE group; grid.x = blocks-per-group * groups
+static void elementwise_grid(long long M, int C, int groups, RowLayout& L, int& rows_per_block, int& bpg, dim3& grid) {
     L = row_layout(C);
     rows_per_block = L.rpb * 8;
-    while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 8192) rows_per_block *= 2;
-    grid = dim3(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
+    while ((long long)cdiv(M, rows_per_block) * groups * cdiv(L.vpr, L.vpb) > 8192) rows_per_block *= 2;
+    bpg = cdiv(M, rows_per_block);
+    grid = dim3(bpg * groups, cdiv(L.vpr, L.vpb));
 }
 
 extern "C" int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, const float* beta,
                              const void* res, int ldres, const float* nscale, int rows_per_image, void* y, int ldy,
-                             int64_t M, int C, int relu, rgda_stream_t stream) {
+                             int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
     if (!x || !mi || !gamma || !beta || !y || M <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7)) return RGDA_ERR_ARG;
     if (res && (ldres & 7)) return RGDA_ERR_ARG;
     if (nscale && rows_per_image <= 0) return RGDA_ERR_ARG;
-    RowLayout L; int rpbk; dim3 grid;
-    elementwise_grid(M, C, L, rpbk, grid);
+    if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
+    RowLayout L; int rpbk, bpg; dim3 grid;
+    elementwise_grid(M / groups, C, groups, L, rpbk, bpg, grid);
     bn_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, mi, gamma, beta, (const bf16_t*)res,
-                                                          ldres, nscale, rows_per_image, (bf16_t*)y, ldy, M, C, relu,
-                                                          L.vpb, L.rpb, rpbk);
+                                                          ldres, nscale, rows_per_image, (bf16_t*)y, ldy, M / groups, C,
+                                                          relu, L.vpb, L.rpb, rpbk, bpg);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
@@ -209,17 +220,21 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ x, int ldx,
                                                             const float* __restrict__ mi, const float* __restrict__ nscale,
                                                             int rpi, float* sums, long long M, int C, int relu, int vpb,
-                                                            int rpb, int rows_per_block) {
+                                                            int rpb, int rows_per_block, int bpg) {
     __shared__ float lds[256 * 16];
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
     const bool cok = cg < C;
+    const int grp = blockIdx.x / bpg, chunk = blockIdx.x % bpg;     // M = rows of ONE group
+    mi += (size_t)grp * 2 * C;
+    sums += (size_t)grp * NREP * 2 * C;
     float s[8] = {0}, q[8] = {0};
     if (cok) {
         float mean[8], istd[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mean[e] = mi[cg + e]; istd[e] = mi[C + cg + e]; }
-        long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+        long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
+        long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
         for (long long r = r0 + rl; r < r1; r += rpb) {
             float gf[8], xf[8];
             load8(g + r * ldg + cg, gf);
@@ -245,14 +260,19 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
 
 extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
                                   const float* mi, const float* nscale, int rows_per_image, float* sums, int64_t M,
-                                  int C, int relu, rgda_stream_t stream) {
+                                  int C, int relu, int groups, rgda_stream_t stream) {
     if (!g || !x || !mi || !sums || (relu && !y) || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || (ldx & 7)) return RGDA_ERR_ARG;
+    if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     hipStream_t st = to_stream(stream);
     RowLayout L = row_layout(C);
-    int rows_per_block = reduce_rows_per_block(M, L);
-    dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
+    const long long Mg = M / groups;
+    int rows_per_block = reduce_rows_per_block(Mg * groups, L);
+    if (rows_per_block > Mg) rows_per_block = (int)((Mg + L.rpb - 1) / L.rpb * L.rpb);
+    int bpg = cdiv(Mg, rows_per_block);
+    dim3 grid(bpg * groups, cdiv(L.vpr, L.vpb));
     bn_bwd_reduce_kernel<<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mi,
-                                               nscale, rows_per_image, sums, M, C, relu, L.vpb, L.rpb, rows_per_block);
+                                               nscale, rows_per_image, sums, Mg, C, relu, L.vpb, L.rpb, rows_per_block,
+                                               bpg);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
@@ -265,10 +285,13 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const float* __restrict__ sums, bf16_t* __restrict__ dx,
                                                            int lddx, bf16_t* __restrict__ gmask, int ldgm, float* dgamma,
                                                            float* dbeta, long long M, int C, int relu, int vpb, int rpb,
-                                                           int rows_per_block) {
+                                                           int rows_per_block, int bpg) {
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
     if (cg >= C) return;
+    const int grp = blockIdx.x / bpg, chunk = blockIdx.x % bpg;     // M = rows of ONE group
+    mi += (size_t)grp * 2 * C;
+    sums += (size_t)grp * NREP * 2 * C;
     float mean[8], istd[8], k0[8], k1[8], k2[8];
     const float invM = 1.f / (float)M;
 #pragma unroll
@@ -282,16 +305,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
         k1[e] = t1;
         k2[e] = t2;
     }
-    if (blockIdx.x == 0 && rl == 0 && dgamma) {
+    if (chunk == 0 && rl == 0 && dgamma) {      // one workgroup per group folds that group's sums into the grads
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            dgamma[cg + e] += k2[e];
-            dbeta[cg + e] += k1[e];
+            atomicAdd(dgamma + cg + e, k2[e]);
+            atomicAdd(dbeta + cg + e, k1[e]);
         }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { k1[e] *= invM; k2[e] *= invM; }
-    long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
+    long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
     for (long long r = r0 + rl; r < r1; r += rpb) {
         float gf[8], xf[8];
         load8(g + r * ldg + cg, gf);
@@ -318,16 +342,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
 extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
                                  const float* mi, const float* gamma, const float* nscale, int rows_per_image,
                                  const float* sums, void* dx, int lddx, void* gmask, int ldgm, float* dgamma,
-                                 float* dbeta, int64_t M, int C, int relu, rgda_stream_t stream) {
+                                 float* dbeta, int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
     if (!g || !x || !mi || !gamma || !sums || !dx || (relu && !y) || M <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
     if ((ldg & 7) || (ldx & 7) || (lddx & 7) || (gmask && (ldgm & 7)) || ((dgamma == nullptr) != (dbeta == nullptr)))
         return RGDA_ERR_ARG;
-    RowLayout L; int rpbk; dim3 grid;
-    elementwise_grid(M, C, L, rpbk, grid);
+    if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
+    RowLayout L; int rpbk, bpg; dim3 grid;
+    elementwise_grid(M / groups, C, groups, L, rpbk, bpg, grid);
     bn_bwd_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy,
                                                               (const bf16_t*)x, ldx, mi, gamma, nscale, rows_per_image,
                                                               sums, (bf16_t*)dx, lddx, (bf16_t*)gmask, ldgm, dgamma,
-                                                              dbeta, M, C, relu, L.vpb, L.rpb, rpbk);
+                                                              dbeta, M / groups, C, relu, L.vpb, L.rpb, rpbk, bpg);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

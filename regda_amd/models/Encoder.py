@@ -313,8 +313,10 @@ class Deeplabv2(nn.Module):
         self.sync_weights()
         return r
 
-    def new_tape(self):
-        return {'stats_pool': _StatsPool(sum(NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, self.device)}
+    def new_tape(self, groups=1):
+        return {'groups': groups,
+                'stats_pool': _StatsPool(sum(groups * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64,
+                                         self.device)}
 
     def param_boundaries(self):
         """Element offsets (into flat_p / flat_g) where a residual block / head starts: legal bucket cuts."""
@@ -361,39 +363,55 @@ class Deeplabv2(nn.Module):
             self._mat_cache[key] = d
         return self._mat_cache[key]
 
+    def _conv_stats(self, x, w, c, stats, G, N, H, W, Ho, Wo, k, stride, pad, dil):
+        """Forward conv with BatchNorm statistics per row group; falls back to one launch per group when the
+        groups are not a multiple of the pixel tile (tiny PPM maps)."""
+        if G == 1 or stats is None:
+            ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, None, stats, 1)
+            return
+        try:
+            ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, None, stats, G)
+        except ValueError:
+            Ng, C = N // G, c.shape[1]
+            st = stats.view(G, -1)
+            for g in range(G):
+                ops.conv2d(x[g * Ng * H * W:(g + 1) * Ng * H * W], w, c[g * Ng * Ho * Wo:(g + 1) * Ng * Ho * Wo], Ng, H,
+                           W, Ho, Wo, k, k, stride, pad, dil, 0, None, st[g], 1)
+
     def _cbr_fwd(self, T, key, conv, bn, x, N, H, W, relu, res=None, nscale=None, wb=None, geom=None):
         Ho, Wo = conv.out_hw(H, W) if geom is None else geom
         M = N * Ho * Wo
         train = T is not None
+        G = T['groups'] if train else 1
         c = torch.empty(M, conv.co, dtype=BF, device=self.device)
-        stats = T['stats_pool'].take(NREP * 2 * conv.co) if train else None
+        stats = T['stats_pool'].take(G * NREP * 2 * conv.co) if train else None
         if geom is None:
-            ops.conv2d(x, conv.wb if wb is None else wb, c, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad,
-                       conv.dil, 0, None, stats)
+            self._conv_stats(x, conv.wb if wb is None else wb, c, stats, G, N, H, W, Ho, Wo, conv.k, conv.stride,
+                             conv.pad, conv.dil)
         else:       # stem: GEMM over the im2col matrix
-            ops.conv2d(x, wb, c, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1, 0, None, stats)
-        mi = torch.empty(2, conv.co, device=self.device)
+            self._conv_stats(x, wb, c, stats, G, N, Ho, Wo, Ho, Wo, 1, 1, 0, 1)
+        mi = torch.empty(G, 2, conv.co, device=self.device)
         if train:
-            if M < 2:
+            if M // G < 2:
                 raise ValueError('Expected more than 1 value per channel when training')
-            ops.bn_finalize(stats, mi, bn.rm, bn.rv, bn.nbt, M, conv.co)
+            ops.bn_finalize(stats, mi, bn.rm, bn.rv, bn.nbt, M, conv.co, groups=G)
         else:
             ops.bn_finalize(None, mi, bn.rm, bn.rv, None, M, conv.co)
         y = torch.empty(M, conv.co, dtype=BF, device=self.device)
-        ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale, Ho * Wo)
+        ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale, Ho * Wo, groups=G)
         if train:
             T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale)
         return y, Ho, Wo
 
     def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False):
         x, c, y, mi, (N, H, W, Ho, Wo), nscale = T[key]
-        M, C = N * Ho * Wo, conv.co
-        sums = T['sums_pool'].take(NREP * 2 * C)
-        ops.bn_bwd_reduce(g, y if relu else None, c, mi, sums, M, C, relu, nscale, Ho * Wo)
+        M, C, G = N * Ho * Wo, conv.co, T['groups']
+        sums = T['sums_pool'].take(G * NREP * 2 * C)
+        ops.bn_bwd_reduce(g, y if relu else None, c, mi, sums, M, C, relu, nscale, Ho * Wo, groups=G)
         dc = torch.empty(M, C, dtype=BF, device=self.device)
         gm = torch.empty(M, C, dtype=BF, device=self.device) if want_gmask else None
         ops.bn_bwd_apply(g, y if relu else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm, bn.dgamma, bn.dbeta,
-                         nscale, Ho * Wo)
+                         nscale, Ho * Wo, groups=G)
         if stem:
             self.stem_gtmp.zero_()
             ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
@@ -409,13 +427,19 @@ class Deeplabv2(nn.Module):
 
     # ------------------------------------------------------------------ forward plan
     def _forward_plan(self, x, T):
+        """x: one NCHW image batch, or a list of equally shaped batches that run through the network together
+        as BatchNorm groups (the source and the target batch of an SSL step)."""
         dev = self.device
-        N, _, H, W = x.shape
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        Ng, _, H, W = xs[0].shape
+        N = Ng * len(xs)
+        assert T is None or T['groups'] == len(xs)
         C = self.convs
         B = self.bns
         H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         col = torch.empty(N * H1 * W1, STEM_KP, dtype=BF, device=dev)
-        ops.stem_im2col(x, col, N, H, W, H1, W1)
+        for gi, xg in enumerate(xs):
+            ops.stem_im2col(xg, col[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], Ng, H, W, H1, W1)
         a0, _, _ = self._cbr_fwd(T, 'stem', C['encoder.resnet.conv1'], B['encoder.resnet.bn1'], col, N, H, W, True,
                                  wb=self.stem_wb, geom=(H1, W1))
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
@@ -450,7 +474,7 @@ class Deeplabv2(nn.Module):
         mats = self._mats(h, w)
         if T is not None:
             if self._drop_override is not None:
-                masks = [m.to(dev).float() / 0.9 for m in self._drop_override]
+                masks = [m.to(dev).float().repeat(N // m.shape[0], 1) / 0.9 for m in self._drop_override]
             else:
                 masks = [(torch.rand(N, 512, device=dev) >= 0.1).float() / 0.9 for _ in range(2)]
         else:
@@ -483,7 +507,7 @@ class Deeplabv2(nn.Module):
     # ------------------------------------------------------------------ backward plan
     def _backward_plan(self, T, g1, g2, on_progress=None):
         dev = self.device
-        T['sums_pool'] = _StatsPool(sum(NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)
+        T['sums_pool'] = _StatsPool(sum(T['groups'] * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)
         C, B = self.convs, self.bns
         y4, imi, (N, h, w) = T['inorm']
         HW, M = h * w, N * h * w

@@ -163,13 +163,14 @@ def _ld(t):
     return t.stride(0)
 
 
-def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None):
-    """x [N*H*W, Cin(view)], w bf16 [Cout, kh*kw, Cin] contiguous, y [N*Ho*Wo, Cout(view)]."""
+def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1):
+    """x [N*H*W, Cin(view)], w bf16 [Cout, kh*kw, Cin] contiguous, y [N*Ho*Wo, Cout(view)].
+    stats: f32 [stat_groups][8][2][Cout] accumulators (zeroed by the caller)."""
     Cout, taps, Cin = w.shape
     assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
     lib().call('rgda_conv2d', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
-               _ld(res) if res is not None else 0, _p(stats), N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil,
-               mode, _stream())
+               _ld(res) if res is not None else 0, _p(stats), stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
+               pad, dil, mode, _stream())
 
 
 def conv2d_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
@@ -188,26 +189,28 @@ def bn_stats(x, stats, M, C):
     lib().call('rgda_bn_stats', x.data_ptr(), _ld(x), stats.data_ptr(), M, C, _stream())
 
 
-def bn_finalize(stats, mi, rm, rv, nbt, M, C, eps=1e-5, momentum=0.1):
-    lib().call('rgda_bn_finalize', _p(stats), mi.data_ptr(), _p(rm), _p(rv), _p(nbt), M, C, eps, momentum, _stream())
+def bn_finalize(stats, mi, rm, rv, nbt, M, C, eps=1e-5, momentum=0.1, groups=1):
+    lib().call('rgda_bn_finalize', _p(stats), mi.data_ptr(), _p(rm), _p(rv), _p(nbt), M, C, groups, eps, momentum,
+               _stream())
 
 
-def bn_apply(x, mi, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_image=0):
+def bn_apply(x, mi, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_image=0, groups=1):
     lib().call('rgda_bn_apply', x.data_ptr(), _ld(x), mi.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(res),
                _ld(res) if res is not None else 0, _p(nscale), rows_per_image, y.data_ptr(), _ld(y), M, C,
-               int(relu), _stream())
+               int(relu), groups, _stream())
 
 
-def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0):
+def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0, groups=1):
     lib().call('rgda_bn_bwd_reduce', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, x.data_ptr(), _ld(x),
-               mi.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), M, C, int(relu), _stream())
+               mi.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), M, C, int(relu), groups, _stream())
 
 
 def bn_bwd_apply(g, y, x, mi, gamma, sums, dx, M, C, relu, gmask=None, dgamma=None, dbeta=None, nscale=None,
-                 rows_per_image=0):
+                 rows_per_image=0, groups=1):
     lib().call('rgda_bn_bwd_apply', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, x.data_ptr(), _ld(x),
                mi.data_ptr(), gamma.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), dx.data_ptr(), _ld(dx),
-               _p(gmask), _ld(gmask) if gmask is not None else 0, _p(dgamma), _p(dbeta), M, C, int(relu), _stream())
+               _p(gmask), _ld(gmask) if gmask is not None else 0, _p(dgamma), _p(dbeta), M, C, int(relu), groups,
+               _stream())
 
 
 def maxpool_fwd(x, y, idx, N, H, W, C, Ho, Wo):

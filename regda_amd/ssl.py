@@ -54,9 +54,14 @@ class SSLStep:
         m._maybe_sync()
         self.lr_dev.fill_(float(lr))
         m.flat_g.zero_()
-        Ts, Tt = m.new_tape(), m.new_tape()
-        s1, s2, feat_s = m._forward_plan(images_s, Ts)
-        t1, t2, feat_t = m._forward_plan(images_t, Tt)
+        # source and target batch go through the network TOGETHER (twice the GEMM rows per launch), as two
+        # BatchNorm groups: statistics, running-stat updates and gradients stay per domain like the
+        # reference's two separate forward calls (train_ssl_reg.py:210-212)
+        nb = images_s.shape[0]
+        T = m.new_tape(groups=2)
+        x1, x2, feat = m._forward_plan([images_s.contiguous().float(), images_t.contiguous().float()], T)
+        s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
+        feat_s, feat_t = feat[:nb], feat[nb:]
         if soft_t is None:
             soft_t = self.teacher_probs(images_t)
         # ---- label path (a5-a8)
@@ -80,10 +85,9 @@ class SSLStep:
         # ---- losses + d(loss)/d(logits)
         loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
         loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
-        # ---- backward: source first, the all-reduce buckets are released during the second pass
+        # ---- backward (both domains in one pass); all-reduce buckets are released as it moves down the net
         self.reducer.reset()
-        m._backward_plan(Ts, gs1, gs2)
-        m._backward_plan(Tt, gt1, gt2, on_progress=self.reducer.ready_down_to)
+        m._backward_plan(T, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]), on_progress=self.reducer.ready_down_to)
         self.reducer.finish()
         # ---- clip + SGD (+ EMA) in one pass over the flat buffers
         ops.sumsq(m.flat_g, self.gn, self.gn_ws)

@@ -49,3 +49,65 @@ extern "C" int probe_run_tr(const void* T, int stride, void* out, void* stream) 
     probe_tr<<<1, 64, 16 * stride * 2, (hipStream_t)stream>>>((const unsigned short*)T, stride, (unsigned short*)out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// buffer_load_dwordx4 ... lds with an out-of-range voffset: does the LDS slot receive zeros?
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+__global__ void probe_buflds(const float* g, int nbytes, float4* out, int oob_lane) {
+    __shared__ float4 lds[64];
+    lds[threadIdx.x] = make_float4(-1.f, -1.f, -1.f, -1.f);
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, nbytes, 0x00020000);
+    int voff = (int)threadIdx.x * 16;
+    if ((int)threadIdx.x == oob_lane) voff = 0x7fffff00;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds), 16, voff, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    out[threadIdx.x] = lds[threadIdx.x];
+}
+extern "C" int probe_run_buflds(const void* g, int nbytes, void* out, int oob_lane, void* stream) {
+    probe_buflds<<<1, 64, 0, (hipStream_t)stream>>>((const float*)g, nbytes, (float4*)out, oob_lane);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---- bandwidth probes: how fast can ONE CU pull L2-resident data (a) into LDS with LDS-DMA, (b) into VGPRs
+template <int MODE, int DEPTH>
+__global__ void __launch_bounds__(256) probe_bw(const float4* __restrict__ src, int tile_bytes, int iters, float* sink) {
+    __shared__ __attribute__((aligned(256))) unsigned char lds[96 * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    // every block reads the same `tile_bytes` window again and again (L2 resident), 1 KiB per wave-instruction
+    const int per_wave = tile_bytes / nwaves / 1024;      // instructions per wave per tile
+    float4 acc = make_float4(0, 0, 0, 0);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 1 << 30, 0x00020000);
+    for (int it = 0; it < iters; ++it) {
+        int base = ((it * 7 + blockIdx.x) & 63) * tile_bytes;     // walk over 64 tiles (stays in L2)
+        if (MODE == 0) {
+            for (int q = 0; q < per_wave; ++q) {
+                int off = base + (q * nwaves + wave) * 1024 + lane * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + ((it % DEPTH) * tile_bytes + (q * nwaves + wave) * 1024) % (96 * 1024)), 16, off, 0, 0, 0);
+            }
+            if (DEPTH == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * 4) : "memory");
+        } else {
+            for (int q = 0; q < per_wave; ++q) {
+                float4 v = src[(base + (q * nwaves + wave) * 1024 + lane * 16) / 16];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (MODE == 0) acc.x = ((float*)lds)[threadIdx.x];
+    if (acc.x + acc.y + acc.z + acc.w == 12345.f) sink[0] = acc.x;
+}
+extern "C" int probe_run_bw(int mode, int depth, int blocks, int threads, const void* src, int tile_bytes, int iters,
+                            void* sink, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0 && depth == 1) probe_bw<0, 1><<<blocks, threads, 0, st>>>((const float4*)src, tile_bytes, iters, (float*)sink);
+    else if (mode == 0 && depth == 2) probe_bw<0, 2><<<blocks, threads, 0, st>>>((const float4*)src, tile_bytes, iters, (float*)sink);
+    else if (mode == 0 && depth == 4) probe_bw<0, 4><<<blocks, threads, 0, st>>>((const float4*)src, tile_bytes, iters, (float*)sink);
+    else if (mode == 0) probe_bw<0, 8><<<blocks, threads, 0, st>>>((const float4*)src, tile_bytes, iters, (float*)sink);
+    else probe_bw<1, 1><<<blocks, threads, 0, st>>>((const float4*)src, tile_bytes, iters, (float*)sink);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

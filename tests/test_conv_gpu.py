@@ -59,7 +59,7 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     wg = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin).to(BF).cuda().contiguous()
     y = torch.zeros(N * Ho * Wo, Cout, dtype=BF, device='cuda')
     stats = torch.zeros(8, 2, Cout, device='cuda')
-    ops.conv2d(xg, wg, y, N, H, W, Ho, Wo, k, k, s, p, d, 0, None, stats)
+    ops.conv2d(xg, wg, y, N, H, W, Ho, Wo, k, k, s, p, d, 0, None, stats, 1)
     out = from_pxc(y, N, Ho, Wo)
     assert relerr(out, ref) < 1e-2, 'forward'
     # BatchNorm statistics fused in the epilogue (of the bf16-rounded outputs)

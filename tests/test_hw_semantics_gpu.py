@@ -46,3 +46,17 @@ def test_ds_read_tr16_b64_semantics(stride):
         os.makedirs('gpurun_out', exist_ok=True)
         np.save(f'gpurun_out/tr_probe_{stride}.npy', out)
     assert np.array_equal(out, exp)
+
+
+def test_buffer_load_lds_out_of_range_writes_zeros():
+    """conv kernels feed padded / out-of-range operand rows by giving the LDS-DMA an out-of-range
+    buffer offset: the hardware must deposit zeros in the LDS slot (not skip it)."""
+    dll = ctypes.CDLL(SO)
+    src = torch.arange(256, dtype=torch.float32, device='cuda') + 1
+    out = torch.zeros(64, 4, device='cuda')
+    st = dll.probe_run_buflds(ctypes.c_void_p(src.data_ptr()), ctypes.c_int(1024), ctypes.c_void_p(out.data_ptr()),
+                              ctypes.c_int(5), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    exp = src.reshape(64, 4).clone()
+    exp[5] = 0
+    assert torch.equal(out.cpu(), exp.cpu()), out[:8]

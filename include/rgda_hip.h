@@ -186,10 +186,10 @@ int rgda_maxpool_bwd(const void* gy, const uint8_t* idx, void* gx, int N, int H,
  * mi f32[N][2][C] mean/invstd saved for backward. */
 int rgda_instnorm_fwd(const void* x, int ldx, void* y0, void* y1, int ldy, float* feat_nchw,
                       float* mi, int N, int HW, int C, float eps, rgda_stream_t stream);
-/* g = ga + gb (+ gc f32) (any may be NULL); dx bf16 */
-int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const float* gc, const void* x,
-                      int ldx, const float* mi, void* dx, int lddx, int N, int HW, int C,
-                      rgda_stream_t stream);
+/* g = ga + gb + gc (bf16 PxC, any may be NULL; ga/gb share ldg); dx bf16 */
+int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const void* gc, int ldgc,
+                      const void* x, int ldx, const float* mi, void* dx, int lddx, int N, int HW,
+                      int C, rgda_stream_t stream);
 
 /* Spatial linear map shared by AdaptiveAvgPool2d / bilinear(align_corners=False)
  * and their transposes (regda/models/Encoder.py:16-18,48-51):
@@ -197,6 +197,12 @@ int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const float* gc, 
  * in: bf16 [N*J][ldin]; out: bf16 [N*I][ldout] (out_f32 != 0: f32). */
 int rgda_spatial_mix(const void* in, int ldin, const float* Mx, void* out, int ldout, int N, int I,
                      int J, int C, int accumulate, int out_f32, rgda_stream_t stream);
+
+/* out[n][i][c] = sum over nsrc <= 4 sources of sum_j mats[q][i][j] * ins[q][n][j][c]  (bf16 out, no accumulate):
+ * the summed backward of the four adaptive-average-pool branches of one PPM head pair in a single pass.
+ * ins/ldins/mats/Js are HOST arrays of length nsrc (device pointers inside). */
+int rgda_spatial_mix_multi(int nsrc, const void* const* ins, const int* ldins, const float* const* mats,
+                           const int* Js, void* out, int ldout, int N, int I, int C, rgda_stream_t stream);
 
 /* 1x1 classifier with bias (regda/models/Encoder.py:40): hidden [M][ldh] bf16 ->
  * logits NCHW f32 (N,ncls,HW); backward gives dhidden (bf16), dW f32[ncls][C] +=, db += */

@@ -291,21 +291,18 @@ extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int
     if (stat_groups < 1) stat_groups = 1;
     if (M % stat_groups) return RGDA_ERR_ARG;
     a.rows_per_group = (int)(M / stat_groups);
-    // tile choice: the biggest tile that still gives every CU a workgroup (bigger tile = more FLOP per byte
-    // pulled L2 -> LDS, which is what bounds these kernels: ~80 GB/s per CU, DESIGN.md "conv roofline")
+    // tile choice (measured on MI355X, tests/dev_conv_bench.py): the L2 -> LDS path sustains <= ~80 GB/s per
+    // CU, so the long-K head convolutions want the largest tile that still gives every CU a workgroup
+    // (128 x 256: 85 FLOP per byte); everything else runs fastest on 128 x 64 tiles, two workgroups per CU.
     int bc = (Cout <= 64) ? 64 : 128;
     int bp = 64;
-    const int cands[3] = {256, 128, 64};
-    for (int k = 0; k < 3; ++k) {
-        int c = cands[k];
-        if (bc == 64 && c == 256) continue;
-        if ((long long)cdiv(M, c) * cdiv(Cout, bc) >= 240 || c == 64) { bp = c; break; }
-    }
+    const long long ktot = (long long)kh * kw * Cin;
+    if (bc == 128 && ktot >= 4096 && (long long)cdiv(M, 256) * cdiv(Cout, bc) >= 240) bp = 256;
     if (stats && stat_groups > 1) {     // a tile may not straddle two statistics groups
         while (bp > 64 && (a.rows_per_group % bp)) bp >>= 1;
         if (a.rows_per_group % bp) return RGDA_ERR_UNSUPPORTED;
     }
-    int stages = 3;
+    int stages = (bc == 64) ? 2 : 3;
     if (const char* e = getenv("RGDA_TILE")) sscanf(e, "%d,%d,%d", &bc, &bp, &stages);   // tuning experiments only
     a.tiles_c = cdiv(Cout, bc);
     a.tiles_p = cdiv(M, bp);

@@ -526,7 +526,7 @@ extern "C" int rgda_instnorm_fwd(const void* x, int ldx, void* y0, void* y1, int
 }
 
 __global__ void __launch_bounds__(256) instnorm_bwd_kernel(const bf16_t* __restrict__ ga, const bf16_t* __restrict__ gb,
-                                                           int ldg, const float* __restrict__ gc,
+                                                           int ldg, const bf16_t* __restrict__ gc, int ldgc,
                                                            const bf16_t* __restrict__ x, int ldx,
                                                            const float* __restrict__ mi, bf16_t* __restrict__ dx, int lddx,
                                                            int HW, int C) {
@@ -551,9 +551,9 @@ __global__ void __launch_bounds__(256) instnorm_bwd_kernel(const bf16_t* __restr
         if (gb) { load8(gb + row * ldg + cg, t8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] += t8[e]; }
-        if (gc) {
+        if (gc) { load8(gc + row * ldgc + cg, t8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] += gc[row * C + cg + e]; }
+            for (int e = 0; e < 8; ++e) g[e] += t8[e]; }
     };
     float s[8] = {0}, q[8] = {0};
     if (cok)
@@ -589,13 +589,15 @@ __global__ void __launch_bounds__(256) instnorm_bwd_kernel(const bf16_t* __restr
         }
 }
 
-extern "C" int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const float* gc, const void* x, int ldx,
-                                 const float* mi, void* dx, int lddx, int N, int HW, int C, rgda_stream_t stream) {
+extern "C" int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const void* gc, int ldgc, const void* x,
+                                 int ldx, const float* mi, void* dx, int lddx, int N, int HW, int C,
+                                 rgda_stream_t stream) {
     if (!x || !mi || !dx || (!ga && !gb && !gc) || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (lddx & 7) ||
-        ((ga || gb) && (ldg & 7)))
+        ((ga || gb) && (ldg & 7)) || (gc && (ldgc & 7)))
         return RGDA_ERR_ARG;
     dim3 grid(cdiv(C, 64), N);
-    instnorm_bwd_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)ga, (const bf16_t*)gb, ldg, gc,
+    instnorm_bwd_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)ga, (const bf16_t*)gb, ldg,
+                                                              (const bf16_t*)gc, ldgc,
                                                               (const bf16_t*)x, ldx, mi, (bf16_t*)dx, lddx, HW, C);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
@@ -658,6 +660,48 @@ extern "C" int rgda_spatial_mix(const void* in, int ldin, const float* Mx, void*
     if (!in || !Mx || !out || N <= 0 || I <= 0 || J <= 0 || C <= 0 || (C & 7) || (ldin & 7) || (ldout & 7)) return RGDA_ERR_ARG;
     dim3 grid(I, N, cdiv(C / 8, 32));
     spatial_mix_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)in, ldin, Mx, out, ldout, I, J, C, accumulate, out_f32);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// out[n][i][c] = sum_q sum_j Mq[i][j] * inq[n][j][c] for up to 4 (matrix, tensor) pairs with small J (the
+// transposed adaptive-pool maps of the four PPM scales): one pass, one bf16 store per output vector.
+struct MixSrc { const bf16_t* in; const float* Mx; int ldin; int J; };
+struct MixSrc4 { MixSrc s[4]; int n; };
+__global__ void __launch_bounds__(256) spatial_mix_multi_kernel(MixSrc4 src, bf16_t* __restrict__ out, int ldout, int I,
+                                                                int C) {
+    const int i = blockIdx.x, n = blockIdx.y;
+    for (int cv = threadIdx.x; cv < C / 8; cv += 256) {
+        float acc[8] = {0};
+        for (int q = 0; q < src.n; ++q) {
+            const MixSrc& m = src.s[q];
+            const float* mrow = m.Mx + (size_t)i * m.J;
+            for (int j = 0; j < m.J; ++j) {
+                float w = mrow[j];
+                if (w == 0.f) continue;
+                float f[8];
+                load8(m.in + ((size_t)n * m.J + j) * m.ldin + cv * 8, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * f[e];
+            }
+        }
+        store8(out + ((size_t)n * I + i) * ldout + cv * 8, acc);
+    }
+}
+
+extern "C" int rgda_spatial_mix_multi(int nsrc, const void* const* ins, const int* ldins, const float* const* mats,
+                                      const int* Js, void* out, int ldout, int N, int I, int C, rgda_stream_t stream) {
+    if (nsrc < 1 || nsrc > 4 || !ins || !ldins || !mats || !Js || !out || N <= 0 || I <= 0 || C <= 0 || (C & 7) ||
+        (ldout & 7))
+        return RGDA_ERR_ARG;
+    MixSrc4 src;
+    src.n = nsrc;
+    for (int q = 0; q < nsrc; ++q) {
+        if (!ins[q] || !mats[q] || Js[q] <= 0 || (ldins[q] & 7)) return RGDA_ERR_ARG;
+        src.s[q].in = (const bf16_t*)ins[q]; src.s[q].Mx = mats[q]; src.s[q].ldin = ldins[q]; src.s[q].J = Js[q];
+    }
+    dim3 grid(I, N);
+    spatial_mix_multi_kernel<<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)out, ldout, I, C);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

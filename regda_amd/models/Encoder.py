@@ -480,12 +480,16 @@ class Deeplabv2(nn.Module):
         else:
             masks = [None, None]
         logits = []
+        pooled_all = []
+        for s in POOL_SCALES:       # both heads pool the same instance-normalised map: do it once
+            pooled = torch.empty(N * s * s, 2048, dtype=BF, device=dev)
+            ops.spatial_mix(cats[0][:, :2048], mats[s][0], pooled, N, s * s, HW, 2048)
+            pooled_all.append(pooled)
         for hi, head in enumerate(('layer5', 'layer6')):
             cat = cats[hi]
             for i, s in enumerate(POOL_SCALES):
                 P, Pt, U, Ut = mats[s]
-                pooled = torch.empty(N * s * s, 2048, dtype=BF, device=dev)
-                ops.spatial_mix(cat[:, :2048], P, pooled, N, s * s, HW, 2048)
+                pooled = pooled_all[i]
                 q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'], pooled,
                                         N, s, s, True)
                 ops.spatial_mix(q, U, cat[:, 2048 + 512 * i: 2048 + 512 * (i + 1)], N, HW, s * s, 512)
@@ -512,8 +516,8 @@ class Deeplabv2(nn.Module):
         y4, imi, (N, h, w) = T['inorm']
         HW, M = h * w, N * h * w
         mats = self._mats(h, w)
-        dfeat = torch.zeros(M, 2048, device=dev)
         dcats = []
+        dpools = [None] * len(POOL_SCALES)
         dbg = getattr(self, '_debug_grads', None)
 
         def nchw(t, hh, ww):
@@ -532,12 +536,15 @@ class Deeplabv2(nn.Module):
                 P, Pt, U, Ut = mats[s]
                 dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
                 ops.spatial_mix(dcat[:, 2048 + 512 * i: 2048 + 512 * (i + 1)], Ut, dq, N, s * s, HW, 512)
-                dpool, _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'], dq, True)
-                ops.spatial_mix(dpool, Pt, dfeat, N, HW, s * s, 2048, accumulate=True)
+                # the second head's data-gradient is added onto the first head's in the conv epilogue
+                dpools[i], _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'], dq,
+                                             True, dx_res=dpools[i])
             dcats.append(dcat)
+        gpool = torch.empty(M, 2048, dtype=BF, device=dev)
+        ops.spatial_mix_multi(dpools, [mats[s][1] for s in POOL_SCALES], gpool, N, HW, 2048)
         g = torch.empty(M, 2048, dtype=BF, device=dev)
-        ops.instnorm_bwd(dcats[0][:, :2048], dcats[1][:, :2048], dfeat, y4, imi, g, N, HW, 2048)
-        del dcats, dfeat
+        ops.instnorm_bwd(dcats[0][:, :2048], dcats[1][:, :2048], gpool, y4, imi, g, N, HW, 2048)
+        del dcats, gpool
         if on_progress is not None:
             on_progress(self._offset_of('layer5.ppm.0.1'))
         hh, ww = h, w

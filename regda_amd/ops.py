@@ -229,8 +229,21 @@ def instnorm_fwd(x, y0, y1, feat, mi, N, HW, C, eps=1e-5):
 
 def instnorm_bwd(ga, gb, gc, x, mi, dx, N, HW, C):
     ldg = _ld(ga) if ga is not None else (_ld(gb) if gb is not None else 0)
-    lib().call('rgda_instnorm_bwd', _p(ga), _p(gb), ldg, _p(gc), x.data_ptr(), _ld(x), mi.data_ptr(), dx.data_ptr(),
-               _ld(dx), N, HW, C, _stream())
+    lib().call('rgda_instnorm_bwd', _p(ga), _p(gb), ldg, _p(gc), _ld(gc) if gc is not None else 0, x.data_ptr(),
+               _ld(x), mi.data_ptr(), dx.data_ptr(), _ld(dx), N, HW, C, _stream())
+
+
+def spatial_mix_multi(ins, mats, out, N, I, C):
+    """out[n][i][:] = sum_q mats[q][i,:] @ ins[q][n]  (q <= 4 sources, bf16 out)."""
+    import ctypes
+    n = len(ins)
+    P = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ins])
+    L = (ctypes.c_int * n)(*[_ld(t) for t in ins])
+    Mt = (ctypes.c_void_p * n)(*[m.data_ptr() for m in mats])
+    J = (ctypes.c_int * n)(*[m.shape[1] for m in mats])
+    for m in mats:
+        assert m.shape[0] == I and m.is_contiguous() and m.dtype == torch.float32
+    lib().call('rgda_spatial_mix_multi', n, P, L, Mt, J, out.data_ptr(), _ld(out), N, I, C, _stream())
 
 
 def spatial_mix(inp, Mx, out, N, I, J, C, accumulate=False):

@@ -4,6 +4,10 @@ import torch
 from regda_amd import ops
 BF = torch.bfloat16
 SHAPES = [  # N,H,W,Cin,Cout,k,s,p,d
+    (16, 32, 32, 512, 2048, 1, 1, 0, 1),
+    (16, 64, 64, 128, 512, 1, 1, 0, 1),
+    (16, 128, 128, 64, 256, 1, 1, 0, 1),
+    (16, 128, 128, 64, 64, 3, 1, 1, 1),
     (16, 32, 32, 4096, 512, 3, 1, 1, 1),
     (16, 32, 32, 256, 256, 3, 1, 1, 1),
     (16, 32, 32, 1024, 256, 1, 1, 0, 1),

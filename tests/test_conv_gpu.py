@@ -201,7 +201,7 @@ def test_instnorm(ops):
     yr = F.instance_norm(xr, eps=1e-5)
     ga, gb = rbf(torch.randn(N, C, H, W, generator=g)), rbf(torch.randn(N, C, H, W, generator=g))
     gc = torch.randn(N, C, H, W, generator=g)
-    yr.backward(ga + gb + gc)
+    yr.backward(ga + gb + rbf(gc))
     cat = torch.zeros(N * HW, 256, dtype=BF, device='cuda')
     feat = torch.empty(N, C, H, W, device='cuda')
     mi = torch.empty(N, 2, C, device='cuda')
@@ -209,8 +209,8 @@ def test_instnorm(ops):
     torch.testing.assert_close(feat.cpu(), yr.detach(), rtol=1e-4, atol=1e-4)
     assert relerr(from_pxc(cat[:, :C], N, H, W), yr.detach()) < 1e-2
     dx = torch.empty(N * HW, C, dtype=BF, device='cuda')
-    gcp = gc.permute(0, 2, 3, 1).reshape(-1, C).contiguous().cuda()
-    ops.instnorm_bwd(to_pxc(ga), to_pxc(gb), gcp, to_pxc(x), mi, dx, N, HW, C)
+    gc = rbf(gc)
+    ops.instnorm_bwd(to_pxc(ga), to_pxc(gb), to_pxc(gc), to_pxc(x), mi, dx, N, HW, C)
     assert relerr(from_pxc(dx, N, H, W), xr.grad) < 2e-2
 
 
@@ -231,6 +231,22 @@ def test_spatial_mix_pool_and_upsample(ops):
         ops.spatial_mix(q, U.cuda(), up, N, H * W, s * s, C)
         refu = F.interpolate(from_pxc(q, N, s, s), (H, W), mode='bilinear', align_corners=False)
         assert relerr(from_pxc(up, N, H, W), refu) < 1e-2, s
+
+
+def test_spatial_mix_multi(ops):
+    from regda_amd.models.Encoder import pool_matrix
+    g = torch.Generator().manual_seed(16)
+    N, C, H, W = 2, 64, 8, 8
+    ins, mats, ref = [], [], 0
+    for s in (1, 2, 3, 6):
+        t = rbf(torch.randn(N, s * s, C, generator=g))
+        Pt = pool_matrix(H, W, s).t().contiguous()
+        ins.append(t.reshape(N * s * s, C).to(BF).cuda())
+        mats.append(Pt.cuda())
+        ref = ref + torch.einsum('ij,njc->nic', Pt, t)
+    out = torch.empty(N * H * W, C, dtype=BF, device='cuda')
+    ops.spatial_mix_multi(ins, mats, out, N, H * W, C)
+    assert relerr(out.float().cpu().reshape(N, H * W, C), ref) < 1e-2
 
 
 def test_classifier(ops):

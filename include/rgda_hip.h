@@ -162,6 +162,13 @@ int rgda_bn_finalize(const float* stats, float* mi, float* running_mean, float* 
 int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, const float* beta,
                   const void* res, int ldres, const float* nscale, int rows_per_image, void* y,
                   int ldy, int64_t M, int C, int relu, int groups, rgda_stream_t stream);
+/* bn_finalize + bn_apply in one launch (the training forward): statistics -> (mean, invstd) -> y, `mi` and the
+ * running statistics are written by one designated workgroup per channel block. */
+int rgda_bn_train_apply(const void* x, int ldx, const float* stats, float* mi, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                        const float* beta, const void* res, int ldres, const float* nscale,
+                        int rows_per_image, void* y, int ldy, int64_t M, int C, int relu, int groups,
+                        float eps, float momentum, rgda_stream_t stream);
 /* sums f32[REPLICAS][2][C] must be ZERO on entry (the caller clears one arena per backward pass):
  * sums[0] += sum(g'), sums[1] += sum(g' * xhat), g' = g*[y>0]*nscale */
 int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
@@ -229,6 +236,9 @@ int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf1
 
 /* w [Co][T][Ci] f32 -> wt [Ci][T][Co] bf16 (weights for the data-gradient pass). */
 int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, rgda_stream_t stream);
+/* every transpose of a model in one launch: device table[n][6] int64 = {src f32*, dst bf16*, Co, T, Ci,
+ * first_block}; a conv owns ceil(Ci/32)*ceil(Co/32)*T consecutive blocks starting at first_block. */
+int rgda_weight_transpose_batched(const int64_t* table, int n, int64_t total_blocks, rgda_stream_t stream);
 int rgda_cast_bf16(const float* src, void* dst, int64_t n, rgda_stream_t stream);
 /* rows of K f32 -> rows of Kp bf16, zero padded (stem weights [64][147] -> [64][192]); and the
  * reverse accumulation dst[R][K] f32 += src[R][Kp] f32 for the stem weight gradient. */

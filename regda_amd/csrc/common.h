@@ -18,17 +18,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 static __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-static __device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even: the hardware conversion of gfx950 (v_cvt_pk_bf16_f32)
 static __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    f32x2_t v = {lo, hi};
+    bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned, b);
 }
+static __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -30,6 +30,7 @@ struct ConvArgs {
     int M;
     int tiles_c, tiles_p;
     int rows_per_group;   // BatchNorm statistics are kept per group of rows (src / tgt batch)
+    unsigned long long* dbg;   // optional per-workgroup phase timestamps (tuning builds only)
 };
 
 static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -157,6 +158,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT = taps * (a.Cin >> 6);
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, twait = 0, tbar = 0;
+    if (a.dbg) tq0 = __builtin_readcyclecounter();
     issue(0);
 #pragma unroll
     for (int p = 1; p < STAGES - 1; ++p)
@@ -166,36 +169,46 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
     for (int kt = 0; kt < KT; ++kt) {
         // tile kt has landed once only the loads of the (up to STAGES-2) younger tiles are outstanding
         const int younger = min(KT - 1 - kt, STAGES - 2);
+        unsigned long long tw0 = 0;
+        if (a.dbg) tw0 = __builtin_readcyclecounter();
         if (younger >= 2) WAIT_VMCNT(2 * LD); else if (younger == 1) WAIT_VMCNT(LD); else WAIT_VMCNT(0);
+        if (a.dbg) { unsigned long long tw1 = __builtin_readcyclecounter(); twait += tw1 - tw0; tw0 = tw1; }
         __builtin_amdgcn_s_barrier();
+        if (a.dbg) tbar += __builtin_readcyclecounter() - tw0;
+        if (a.dbg && kt == 0) tq1 = __builtin_readcyclecounter();
         if (kt + STAGES - 1 < KT) {
             advance();
             issue(stage >= 1 ? stage - 1 : STAGES - 1);      // (kt + STAGES - 1) % STAGES
         }
         const unsigned char* wb = smem + stage * TILE;
         const unsigned char* xb = wb + BC * 128;
+        // all fragments of the K tile are fetched up front (4 k-steps x (FI+FJ) x 16 B per lane), then the MFMAs
+        // run back to back: the LDS latency is paid once per K tile instead of once per k-step
+        bf16x8 af[4][FI], bfr[4][FJ];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[FI], bfr[FJ];
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
                 int r = wc * (BC / 2) + i * 32 + lrow;
-                af[i] = *(const bf16x8*)(wb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
+                af[kk][i] = *(const bf16x8*)(wb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < FJ; ++j) {
                 int r = wp * (BP / 2) + j * 32 + lrow;
-                bfr[j] = *(const bf16x8*)(xb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
+                bfr[kk][j] = *(const bf16x8*)(xb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
             }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
         stage = (stage == STAGES - 1) ? 0 : stage + 1;
     }
     __syncthreads();
+    if (a.dbg) tq2 = __builtin_readcyclecounter();
 
     // ---- epilogue: accumulators -> bf16 C tile [pixel][cout] in LDS
 #pragma unroll
@@ -230,7 +243,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
             if (a.res) {
                 u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) val[e] = f2bf(bf2f(val[e]) + bf2f(rv[e]));
+                for (int e = 0; e < 8; e += 2) {
+                    unsigned pk = pack2bf(bf2f(val[e]) + bf2f(rv[e]), bf2f(val[e + 1]) + bf2f(rv[e + 1]));
+                    val[e] = (bf16_t)(pk & 0xffffu);
+                    val[e + 1] = (bf16_t)(pk >> 16);
+                }
             }
             if (a.stats) {
 #pragma unroll
@@ -266,6 +283,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
                 atomicAdd(&a.stats[(((size_t)(m0 / a.rows_per_group) * NREP + (blockIdx.x & (NREP - 1))) * 2 + which) * a.Cout + c0 + c], tot);
         }
     }
+    if (a.dbg && t == 0) {
+        unsigned long long tq3 = __builtin_readcyclecounter();
+        a.dbg[blockIdx.x * 4 + 0] = tq0; a.dbg[blockIdx.x * 4 + 1] = tq1;
+        a.dbg[blockIdx.x * 4 + 2] = tq2; a.dbg[blockIdx.x * 4 + 3] = tq3;
+        a.dbg[(gridDim.x + blockIdx.x) * 4 + 0] = twait; a.dbg[(gridDim.x + blockIdx.x) * 4 + 1] = tbar;
+    }
 #endif
 }
 
@@ -291,6 +314,8 @@ extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int
     if (stat_groups < 1) stat_groups = 1;
     if (M % stat_groups) return RGDA_ERR_ARG;
     a.rows_per_group = (int)(M / stat_groups);
+    a.dbg = nullptr;
+    if (const char* e = getenv("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
     // tile choice (measured on MI355X, tests/dev_conv_bench.py): the L2 -> LDS path sustains <= ~80 GB/s per
     // CU, so the long-K head convolutions want the largest tile that still gives every CU a workgroup
     // (128 x 256: 85 FLOP per byte); everything else runs fastest on 128 x 64 tiles, two workgroups per CU.
@@ -501,6 +526,159 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 #endif
 }
 
+// ======================================================================================
+// weight gradient of 3x3 / stride-1 / "same" convolutions, all nine taps fused
+//   One workgroup owns dW[64 cout][9 taps][64 cin].  A K tile is 64 pixels = R image rows x WT columns; its
+//   dY rows [64][64 cout] and ONE halo tile of the input [(R+2D) x (WT+2D) pixels][64 cin] are DMA'd to LDS and
+//   the nine taps read the halo tile at nine shifted row offsets: 25 KB per 4.7 MFLOP = 188 FLOP per byte pulled
+//   from L2 (the generic kernel: 64), and the dY tile is read once instead of nine times.
+// ======================================================================================
+template <int WT, int D>
+__global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int R = 64 / WT;                       // image rows per K tile
+    constexpr int HR = R + 2 * D, HC = WT + 2 * D;   // halo tile (pixels)
+    constexpr int NH = HR * HC, NHP = (NH + 31) / 32 * 32;
+    constexpr int TA = 64 * 128, TB = NHP * 128, TILE = TA + TB;
+    constexpr int LA = 2, LB = NHP / 32;             // LDS-DMA instructions per wave per tile (8 rows each)
+    constexpr int LD = LA + LB;
+    constexpr int STAGES = 3;
+    __shared__ __attribute__((aligned(256))) unsigned char smem[STAGES * TILE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wi = wave & 1, wj = wave >> 1;
+    int bid = blockIdx.x;
+    const int split = bid % a.splits; bid /= a.splits;
+    const int tco = bid % a.tiles_co;
+    const int tci = bid / a.tiles_co;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const int tpr = a.W / WT, tpi = tpr * (a.H / R);        // K tiles per image row-band / per image
+    const int KT = a.N * tpi;
+    const int kt_beg = split * a.kt_per_split, kt_end = min(kt_beg + a.kt_per_split, KT);
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)((((size_t)a.M - 1) * a.lddy + a.Cout) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2), 0x00020000);
+
+    // lane geometry of a DMA instruction: 8 rows x 8 slots of 16 B; 128-byte rows, granule swizzle (row>>1)&1
+    const int lr = lane >> 3, ls = lane & 7;
+    auto swz = [](int row, int slot) { return (((slot >> 2) ^ ((row >> 1) & 1)) << 2) | (slot & 3); };
+    int avo[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        int row = (i * 4 + wave) * 8 + lr;
+        int col = co0 + swz(row, ls) * 8;
+        avo[i] = (col < a.Cout) ? ((row * a.lddy + col) * 2) : OOB;
+    }
+    int bhr[LB], bhc[LB], bcol[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        int h = (i * 4 + wave) * 8 + lr;
+        int col = ci0 + swz(h, ls) * 8;
+        bool ok = (h < NH) && (col < a.Cin);
+        bhr[i] = ok ? (h / HC - D) : -100000;             // row / column of the halo pixel relative to the tile origin
+        bhc[i] = h % HC - D;
+        bcol[i] = col * 2;
+    }
+    auto issue = [&](int kt, int stage) {
+        const int n = kt / tpi, rem = kt % tpi;
+        const int y0 = (rem / tpr) * R, x0 = (rem % tpr) * WT;
+        unsigned char* ab = smem + stage * TILE + wave * 1024;
+        const int so_a = ((n * a.H + y0) * a.W + x0) * a.lddy * 2;
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(ab + i * 4096), 16, avo[i], so_a, 0, 0);
+        unsigned char* bb = ab + TA;
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            int y = y0 + bhr[i], x = x0 + bhc[i];
+            bool ok = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+            int vo = ok ? (((n * a.H + y) * a.W + x) * a.ldx * 2 + bcol[i]) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bb + i * 4096), 16, vo, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    if (kt_beg < kt_end) {
+        issue(kt_beg, 0);
+        if (kt_beg + 1 < kt_end) issue(kt_beg + 1, 1);
+        const int g = lane >> 4, la = lane & 15;
+        const int klane = (g >> 1) * 8 + (la >> 2);                    // pixel of this lane inside a 16-pixel k step
+        const int cbyte = ((g & 1) * 16 + (la & 3) * 4) * 2;           // column byte inside the wave's 32 columns
+        const int abyte = wi * 64 + cbyte, bbyte = wj * 64 + cbyte;    // 32 columns = 64 bytes per wave half
+        auto tr = [&](const unsigned char* base, int row, int byte) {
+            const unsigned char* p = base + row * 128 + ((((byte >> 6) ^ ((row >> 1) & 1)) << 6) | (byte & 63));
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+        };
+        auto pack = [](s16x4 lo, s16x4 hi) {
+            u16x8 v8 = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                        (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+            return __builtin_bit_cast(bf16x8, v8);
+        };
+        int stage = 0;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) WAIT_VMCNT(LD); else WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < kt_end) issue(kt + 2, stage >= 1 ? stage - 1 : STAGES - 1);
+            const unsigned char* ab = smem + stage * TILE;
+            const unsigned char* bb = ab + TA;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                // the 16 pixels of this k step lie in one image row of the tile (WT >= 16)
+                constexpr int dummy = 0; (void)dummy;
+                const int r_kk = (kk * 16) / WT, c_kk = (kk * 16) % WT;
+                const int k0 = kk * 16 + klane;
+                bf16x8 af = pack(tr(ab, k0, abyte), tr(ab, k0 + 4, abyte));
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int h0 = (r_kk + kh * D) * HC + c_kk + kw * D + klane;
+                        bf16x8 bfr = pack(tr(bb, h0, bbyte), tr(bb, h0 + 4, bbyte));
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[kh * 3 + kw], 0, 0, 0);
+                    }
+            }
+            stage = (stage == STAGES - 1) ? 0 : stage + 1;
+        }
+    }
+    const int lcol = lane & 31, lk = lane >> 5;
+    const int ci = ci0 + wj * 32 + lcol;
+    if (ci < a.Cin) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * 9 + q) * a.Cin + ci, acc[q][r]);
+            }
+    }
+#endif
+}
+
+template <int WT, int D>
+static void launch_wgrad3x3(WgradArgs& a, hipStream_t st) {
+    constexpr int R = 64 / WT;
+    a.tiles_co = cdiv(a.Cout, 64);
+    a.tiles_ci = cdiv(a.Cin, 64);
+    int tiles = a.tiles_co * a.tiles_ci;
+    int KT = a.N * (a.H / R) * (a.W / WT);
+    // every split adds 147 KB of fp32 atomics (9 x 64 x 64 results): ~256 workgroups, >= 16 K tiles each
+    int splits = cdiv(256, tiles);
+    if (splits > KT / 16) splits = KT / 16;
+    if (splits < 1) splits = 1;
+    if (const char* e = getenv("RGDA_WGRAD_SPLITS")) splits = atoi(e);
+    a.kt_per_split = cdiv(KT, splits);
+    a.splits = cdiv(KT, a.kt_per_split);
+    conv_wgrad3x3_kernel<WT, D><<<tiles * a.splits, 256, 0, st>>>(a);
+}
+
 static int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;
@@ -525,6 +703,22 @@ extern "C" int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldd
     a.M = (int)M;
     a.howo_shift = ilog2_exact(Ho * Wo);
     a.wo_shift = ilog2_exact(Wo);
+    hipStream_t st0 = to_stream(stream);
+    // tap-fused path: 3x3, stride 1, "same" padding, the map tiles into 64-pixel row blocks
+    if (kh == 3 && kw == 3 && stride == 1 && pad == dil && Ho == H && Wo == W && cdiv(Cout, 64) * cdiv(Cin, 64) >= 8 &&
+        !getenv("RGDA_WGRAD_GENERIC")) {
+        int wt = (W >= 64) ? 64 : W;
+        if ((wt == 64 || wt == 32 || wt == 16) && (W % wt) == 0 && (H % (64 / wt)) == 0 && (dil == 1 || dil == 2)) {
+            if (wt == 64 && dil == 1) launch_wgrad3x3<64, 1>(a, st0);
+            else if (wt == 64) launch_wgrad3x3<64, 2>(a, st0);
+            else if (wt == 32 && dil == 1) launch_wgrad3x3<32, 1>(a, st0);
+            else if (wt == 32) launch_wgrad3x3<32, 2>(a, st0);
+            else if (dil == 1) launch_wgrad3x3<16, 1>(a, st0);
+            else launch_wgrad3x3<16, 2>(a, st0);
+            RGDA_CHECK_LAUNCH();
+            return RGDA_OK;
+        }
+    }
     int bco = (Cout <= 64) ? 64 : 128, bci = (Cin <= 64) ? 64 : 128;
     a.tiles_co = cdiv(Cout, bco);
     a.tiles_ci = cdiv(Cin, bci);

@@ -40,10 +40,9 @@ static __device__ __forceinline__ void load8(const bf16_t* p, float (&f)[8]) {
     for (int e = 0; e < 8; ++e) f[e] = bf2f(v[e]);
 }
 static __device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
-    u16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = f2bf(f[e]);
-    *(u16x8*)p = v;
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    *(uint4*)p = v;
 }
 
 // reduce two 8-vectors over the row lanes of a block and atomically add to out0[c], out1[c]
@@ -144,24 +143,96 @@ extern "C" int rgda_bn_finalize(const float* stats, float* mi, float* running_me
     return RGDA_OK;
 }
 
+// per-channel batch statistics of one row group from the replicated (sum, sumsq) accumulators
+static __device__ __forceinline__ void group_stats(const float* __restrict__ stats, int grp, int C, int cg, float invM,
+                                                   float eps, float (&mean)[8], float (&istd)[8], float (&var)[8]) {
+    const float* st = stats + (size_t)grp * NREP * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < NREP; ++r) { s0 += st[(size_t)(2 * r) * C + cg + e]; s1 += st[(size_t)(2 * r + 1) * C + cg + e]; }
+        float m = s0 * invM;
+        float v = fmaxf(s1 * invM - m * m, 0.f);
+        mean[e] = m;
+        var[e] = v;
+        istd[e] = 1.f / sqrtf(v + eps);
+    }
+}
+
 // ------------------------------------------------------------------ BN apply (forward)
 __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict__ x, int ldx,
                                                        const float* __restrict__ mi, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const bf16_t* __restrict__ res,
                                                        int ldres, const float* __restrict__ nscale, int rpi,
                                                        bf16_t* __restrict__ y, int ldy, long long M, int C, int relu,
-                                                       int vpb, int rpb, int rows_per_block, int bpg) {
+                                                       int vpb, int rpb, int rows_per_block, int bpg,
+                                                       const float* __restrict__ stats, float* mi_out, float* rm,
+                                                       float* rv, long long* nbt, int groups, float eps, float mom) {
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
-    if (cg >= C) return;
     const int grp = blockIdx.x / bpg, chunk = blockIdx.x % bpg;     // M = rows of ONE group
-    mi += (size_t)grp * 2 * C;
-    float mean[8], sc[8], sh[8];
+    __shared__ float smean[2048], sistd[2048];
+    if (stats) {
+        // train mode with the finalize step folded in: the workgroup rebuilds mean / invstd of its vpb*8 channels
+        // from the conv epilogue's replicated accumulators, one channel per thread, and shares them through LDS
+        const float invM = 1.f / (float)M;
+        const float* st = stats + (size_t)grp * NREP * 2 * C;
+        for (int c = threadIdx.x; c < vpb * 8; c += 256) {
+            int cc = blockIdx.y * vpb * 8 + c;
+            if (cc < C) {
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        mean[e] = mi[cg + e];
-        sc[e] = mi[C + cg + e] * gamma[cg + e];
-        sh[e] = beta[cg + e];
+                for (int r = 0; r < NREP; ++r) { s0 += st[(size_t)(2 * r) * C + cc]; s1 += st[(size_t)(2 * r + 1) * C + cc]; }
+                float m = s0 * invM;
+                smean[c] = m;
+                sistd[c] = 1.f / sqrtf(fmaxf(s1 * invM - m * m, 0.f) + eps);
+            }
+        }
+        __syncthreads();
+    }
+    if (cg >= C) return;
+    float mean[8], sc[8], sh[8];
+    if (stats) {
+        // one designated workgroup per channel block also publishes (mean, invstd) for the backward pass and
+        // updates the running statistics, group after group
+        float istd[8];
+        const float invM = 1.f / (float)M;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mean[e] = smean[cvl * 8 + e];
+            istd[e] = sistd[cvl * 8 + e];
+            sc[e] = istd[e] * gamma[cg + e];
+            sh[e] = beta[cg + e];
+        }
+        if (chunk == 0 && rl == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mi_out[(size_t)grp * 2 * C + cg + e] = mean[e];
+                mi_out[(size_t)grp * 2 * C + C + cg + e] = istd[e];
+            }
+            if (grp == 0 && rm) {
+                const float unb = (M > 1) ? (float)M / (float)(M - 1) : 1.f;
+                for (int g = 0; g < groups; ++g) {
+                    float m2[8], i2[8], v2[8];
+                    group_stats(stats, g, C, cg, invM, eps, m2, i2, v2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        rm[cg + e] = (1.f - mom) * rm[cg + e] + mom * m2[e];
+                        rv[cg + e] = (1.f - mom) * rv[cg + e] + mom * v2[e] * unb;
+                    }
+                }
+                if (cg == 0 && nbt) *nbt += groups;
+            }
+        }
+    } else {
+        mi += (size_t)grp * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mean[e] = mi[cg + e];
+            sc[e] = mi[C + cg + e] * gamma[cg + e];
+            sh[e] = beta[cg + e];
+        }
     }
     long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
@@ -190,9 +261,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
 }
 
 // M = rows of ONE group; grid.x = blocks-per-group * groups
-static void elementwise_grid(long long M, int C, int groups, RowLayout& L, int& rows_per_block, int& bpg, dim3& grid) {
+static void elementwise_grid(long long M, int C, int groups, RowLayout& L, int& rows_per_block, int& bpg, dim3& grid,
+                             int rows_mult = 8) {
     L = row_layout(C);
-    rows_per_block = L.rpb * 8;
+    rows_per_block = L.rpb * rows_mult;
     while ((long long)cdiv(M, rows_per_block) * groups * cdiv(L.vpr, L.vpb) > 8192) rows_per_block *= 2;
     bpg = cdiv(M, rows_per_block);
     grid = dim3(bpg * groups, cdiv(L.vpr, L.vpb));
@@ -209,7 +281,30 @@ extern "C" int rgda_bn_apply(const void* x, int ldx, const float* mi, const floa
     elementwise_grid(M / groups, C, groups, L, rpbk, bpg, grid);
     bn_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, mi, gamma, beta, (const bf16_t*)res,
                                                           ldres, nscale, rows_per_image, (bf16_t*)y, ldy, M / groups, C,
-                                                          relu, L.vpb, L.rpb, rpbk, bpg);
+                                                          relu, L.vpb, L.rpb, rpbk, bpg, nullptr, nullptr, nullptr,
+                                                          nullptr, nullptr, groups, 0.f, 0.f);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+extern "C" int rgda_bn_train_apply(const void* x, int ldx, const float* stats, float* mi, float* running_mean,
+                                   float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                                   const float* beta, const void* res, int ldres, const float* nscale,
+                                   int rows_per_image, void* y, int ldy, int64_t M, int C, int relu, int groups,
+                                   float eps, float momentum, rgda_stream_t stream) {
+    if (!x || !stats || !mi || !gamma || !beta || !y || M <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7)) return RGDA_ERR_ARG;
+    if (res && (ldres & 7)) return RGDA_ERR_ARG;
+    if (nscale && rows_per_image <= 0) return RGDA_ERR_ARG;
+    if (groups < 1 || (M % groups) || M / groups < 2) return RGDA_ERR_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return RGDA_ERR_ARG;
+    RowLayout L; int rpbk, bpg; dim3 grid;
+    // fatter workgroups than the plain apply: each one first rebuilds its channels' statistics (128 loads/thread)
+    elementwise_grid(M / groups, C, groups, L, rpbk, bpg, grid);
+    bn_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, nullptr, gamma, beta, (const bf16_t*)res,
+                                                          ldres, nscale, rows_per_image, (bf16_t*)y, ldy, M / groups, C,
+                                                          relu, L.vpb, L.rpb, rpbk, bpg, stats, mi, running_mean,
+                                                          running_var, (long long*)num_batches_tracked, groups, eps,
+                                                          momentum);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

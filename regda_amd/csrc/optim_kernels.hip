@@ -137,6 +137,45 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float* __re
     }
 }
 
+// all transposes of a model in ONE launch: table[n][6] int64 = {src, dst, Co, T, Ci, first_block}, blocks of a
+// conv = ceil(Ci/32) * ceil(Co/32) * T, first_block ascending
+__global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const long long* __restrict__ table, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {                       // last entry with first_block <= b
+        int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 6 + 5] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = table + lo * 6;
+    const float* w = (const float*)e[0];
+    bf16_t* wt = (bf16_t*)e[1];
+    const int Co = (int)e[2], T = (int)e[3], Ci = (int)e[4];
+    int rel = (int)(b - e[5]);
+    const int nci = (Ci + 31) / 32, nco = (Co + 31) / 32;
+    const int bx = rel % nci; rel /= nci;
+    const int by = rel % nco;
+    const int tap = rel / nco;
+    const int co0 = by * 32, ci0 = bx * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + tap) * Ci + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int ci = ci0 + r, co = co0 + tx;
+        if (ci < Ci && co < Co) wt[((size_t)ci * T + tap) * Co + co] = f2bf(tile[tx][r]);
+    }
+}
+
+extern "C" int rgda_weight_transpose_batched(const int64_t* table, int n, int64_t total_blocks, rgda_stream_t stream) {
+    if (!table || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return RGDA_ERR_ARG;
+    weight_transpose_batched_kernel<<<(int)total_blocks, 256, 0, to_stream(stream)>>>((const long long*)table, n);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
 extern "C" int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, rgda_stream_t stream) {
     if (!w || !wt || Co <= 0 || T <= 0 || Ci <= 0) return RGDA_ERR_ARG;
     dim3 grid(cdiv(Ci, 32), cdiv(Co, 32), T);

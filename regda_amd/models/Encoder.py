@@ -261,6 +261,14 @@ class Deeplabv2(nn.Module):
             n = c.co * c.k * c.k * c.ci
             c.wtb = self.flat_wt[o:o + n].view(c.ci, c.k * c.k, c.co)
             o += _pad64(n)
+        rows, blk = [], 0
+        for c in self.convs.values():
+            if c.wtb is not None:
+                T = c.k * c.k
+                rows.append([c.w.data_ptr(), c.wtb.data_ptr(), c.co, T, c.ci, blk])
+                blk += ((c.ci + 31) // 32) * ((c.co + 31) // 32) * T
+        self._wt_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._wt_blocks = blk
         self.stem_wb = torch.zeros(64, 1, STEM_KP, dtype=BF, device=dev)
         self.stem_gtmp = torch.zeros(64, 1, STEM_KP, device=dev)
 
@@ -295,9 +303,7 @@ class Deeplabv2(nn.Module):
 
     def sync_derived_weights(self):
         """Transposed (data-gradient) copies + padded stem weights; the bf16 mirror is already fresh."""
-        for c in self.convs.values():
-            if c.wtb is not None:
-                ops.weight_transpose_bf16(c.w, c.wtb, c.co, c.k * c.k, c.ci)
+        ops.weight_transpose_batched(self._wt_table, self._wt_table.shape[0], self._wt_blocks)
         s = self.convs['encoder.resnet.conv1']
         ops.pad_cast_bf16(s.w, self.stem_wb, 64, 147, STEM_KP)
 
@@ -391,14 +397,15 @@ class Deeplabv2(nn.Module):
         else:       # stem: GEMM over the im2col matrix
             self._conv_stats(x, wb, c, stats, G, N, Ho, Wo, Ho, Wo, 1, 1, 0, 1)
         mi = torch.empty(G, 2, conv.co, device=self.device)
+        y = torch.empty(M, conv.co, dtype=BF, device=self.device)
         if train:
             if M // G < 2:
                 raise ValueError('Expected more than 1 value per channel when training')
-            ops.bn_finalize(stats, mi, bn.rm, bn.rv, bn.nbt, M, conv.co, groups=G)
+            ops.bn_train_apply(c, stats, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale,
+                               Ho * Wo, groups=G)
         else:
             ops.bn_finalize(None, mi, bn.rm, bn.rv, None, M, conv.co)
-        y = torch.empty(M, conv.co, dtype=BF, device=self.device)
-        ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale, Ho * Wo, groups=G)
+            ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale, Ho * Wo, groups=G)
         if train:
             T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale)
         return y, Ho, Wo

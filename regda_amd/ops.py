@@ -200,6 +200,13 @@ def bn_apply(x, mi, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_
                int(relu), groups, _stream())
 
 
+def bn_train_apply(x, stats, mi, rm, rv, nbt, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_image=0,
+                   groups=1, eps=1e-5, momentum=0.1):
+    lib().call('rgda_bn_train_apply', x.data_ptr(), _ld(x), stats.data_ptr(), mi.data_ptr(), _p(rm), _p(rv), _p(nbt),
+               gamma.data_ptr(), beta.data_ptr(), _p(res), _ld(res) if res is not None else 0, _p(nscale),
+               rows_per_image, y.data_ptr(), _ld(y), M, C, int(relu), groups, eps, momentum, _stream())
+
+
 def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0, groups=1):
     lib().call('rgda_bn_bwd_reduce', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, x.data_ptr(), _ld(x),
                mi.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), M, C, int(relu), groups, _stream())
@@ -275,6 +282,10 @@ def sgd_step(p, g, v, shadow, p_bf16, gnorm_sq, lr_dev, momentum, weight_decay, 
 
 def weight_transpose_bf16(w, wt, Co, T, Ci):
     lib().call('rgda_weight_transpose_bf16', w.data_ptr(), wt.data_ptr(), Co, T, Ci, _stream())
+
+
+def weight_transpose_batched(table, n, total_blocks):
+    lib().call('rgda_weight_transpose_batched', table.data_ptr(), n, total_blocks, _stream())
 
 
 def cast_bf16(src, dst):

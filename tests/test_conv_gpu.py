@@ -43,6 +43,12 @@ CASES = [
     (8, 32, 32, 256, 256, 3, 1, 1, 1),
     (1, 4, 4, 512, 512, 3, 1, 1, 1),
     (3, 1, 1, 2048, 512, 1, 1, 0, 1),
+    # tap-fused 3x3 weight-gradient geometries: 64-pixel K tiles of R rows x WT columns
+    (2, 64, 64, 128, 256, 3, 1, 1, 1),     # WT=64, R=1
+    (1, 8, 128, 256, 128, 3, 1, 1, 1),     # WT=64, two tiles per image row
+    (1, 16, 64, 128, 256, 3, 1, 2, 2),     # WT=64, dilation 2
+    (2, 8, 16, 256, 136, 3, 1, 2, 2),      # WT=16, R=4, dilation 2, ragged Cout
+    (3, 32, 32, 256, 128, 3, 1, 1, 1),     # WT=32, R=2, odd image count (split-K tail)
 ]
 
 

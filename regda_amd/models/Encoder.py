@@ -424,7 +424,17 @@ class Deeplabv2(nn.Module):
             ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
             ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
             return None, gm
-        ops.conv2d_wgrad(x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil)
+        side = T.get('wgrad_stream')
+        if side is None:
+            ops.conv2d_wgrad(x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil)
+        else:
+            # weight gradients are only needed by the optimizer: they run on a second HIP stream, next to the
+            # BN-backward / data-gradient chain of the layers below (which is what the critical path is)
+            side.wait_event(torch.cuda.current_stream().record_event())
+            with torch.cuda.stream(side):
+                ops.conv2d_wgrad(x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil)
+            dc.record_stream(side)
+            x.record_stream(side)
         dx = None
         if need_dx:
             dx = torch.empty(N * H * W, conv.ci, dtype=BF, device=self.device)
@@ -572,6 +582,8 @@ class Deeplabv2(nn.Module):
         ga0 = torch.empty(N * H1 * W1, 64, dtype=BF, device=dev)
         ops.maxpool_bwd(g, idx, ga0, N, H1, W1, 64, H2, W2)
         self._cbr_bwd(T, 'stem', C['encoder.resnet.conv1'], B['encoder.resnet.bn1'], ga0, True, stem=True)
+        if T.get('wgrad_stream') is not None:
+            torch.cuda.current_stream().wait_stream(T['wgrad_stream'])
 
     # ------------------------------------------------------------------ grads <-> torch
     def attach_grads(self):

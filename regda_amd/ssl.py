@@ -19,7 +19,7 @@ class SSLStep:
     def __init__(self, model, prototypes, class_num=6, ignore_label=-1, momentum=0.9, weight_decay=5e-4,
                  max_norm=32.0, cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996, refine_temp=2.0,
                  sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=8 << 20,
-                 process_group=None):
+                 process_group=None, overlap_wgrad=True):
         self.model = model
         self.C, self.ig = class_num, ignore_label
         self.momentum, self.wd, self.max_norm = momentum, weight_decay, max_norm
@@ -41,6 +41,7 @@ class SSLStep:
             self.teacher = model.make_teacher()
         bounds = model.param_boundaries()
         self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
+        self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
         self.world = self.reducer.world
         self.group = process_group
 
@@ -59,10 +60,20 @@ class SSLStep:
         # reference's two separate forward calls (train_ssl_reg.py:210-212)
         nb = images_s.shape[0]
         T = m.new_tape(groups=2)
+        main = torch.cuda.current_stream()
+        teacher_on_side = soft_t is None and self.wgrad_stream is not None
+        if teacher_on_side:
+            # the EMA teacher's forward is independent of the student's: it runs on the second stream, next to it
+            self.wgrad_stream.wait_stream(main)
+            with torch.cuda.stream(self.wgrad_stream):
+                soft_t = self.teacher_probs(images_t)
         x1, x2, feat = m._forward_plan([images_s.contiguous().float(), images_t.contiguous().float()], T)
         s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
         feat_s, feat_t = feat[:nb], feat[nb:]
-        if soft_t is None:
+        if teacher_on_side:
+            main.wait_stream(self.wgrad_stream)
+            soft_t.record_stream(main)
+        elif soft_t is None:
             soft_t = self.teacher_probs(images_t)
         # ---- label path (a5-a8)
         if self.refine_label:
@@ -87,7 +98,14 @@ class SSLStep:
         loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
         # ---- backward (both domains in one pass); all-reduce buckets are released as it moves down the net
         self.reducer.reset()
-        m._backward_plan(T, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]), on_progress=self.reducer.ready_down_to)
+        T['wgrad_stream'] = self.wgrad_stream
+
+        def progress(offset):
+            if self.world > 1:
+                if self.wgrad_stream is not None:       # a bucket needs the weight gradients of its layers too
+                    torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+                self.reducer.ready_down_to(offset)
+        m._backward_plan(T, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]), on_progress=progress)
         self.reducer.finish()
         # ---- clip + SGD (+ EMA) in one pass over the flat buffers
         ops.sumsq(m.flat_g, self.gn, self.gn_ws)

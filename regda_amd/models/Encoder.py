@@ -320,7 +320,7 @@ class Deeplabv2(nn.Module):
         return r
 
     def new_tape(self, groups=1):
-        return {'groups': groups,
+        return {'groups': groups, 'keep': [],
                 'stats_pool': _StatsPool(sum(groups * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64,
                                          self.device)}
 
@@ -430,11 +430,11 @@ class Deeplabv2(nn.Module):
         else:
             # weight gradients are only needed by the optimizer: they run on a second HIP stream, next to the
             # BN-backward / data-gradient chain of the layers below (which is what the critical path is)
-            side.wait_event(torch.cuda.current_stream().record_event())
-            with torch.cuda.stream(side):
+            side.wait_event(T['main_stream'].record_event())
+            with ops.use_stream(side):
                 ops.conv2d_wgrad(x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil)
-            dc.record_stream(side)
-            x.record_stream(side)
+            T['keep'].append((dc, x))        # keep the operands alive until the streams join (no record_stream:
+                                             # the step must stay capturable into a hipGraph)
         dx = None
         if need_dx:
             dx = torch.empty(N * H * W, conv.ci, dtype=BF, device=self.device)
@@ -583,7 +583,7 @@ class Deeplabv2(nn.Module):
         ops.maxpool_bwd(g, idx, ga0, N, H1, W1, 64, H2, W2)
         self._cbr_bwd(T, 'stem', C['encoder.resnet.conv1'], B['encoder.resnet.bn1'], ga0, True, stem=True)
         if T.get('wgrad_stream') is not None:
-            torch.cuda.current_stream().wait_stream(T['wgrad_stream'])
+            T['main_stream'].wait_stream(T['wgrad_stream'])
 
     # ------------------------------------------------------------------ grads <-> torch
     def attach_grads(self):

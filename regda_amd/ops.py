@@ -9,8 +9,31 @@ import torch
 from ._lib import lib
 
 
+_STREAM = None      # cached raw hipStream_t of the stream selected with use_stream() (saves ~8 us per launch)
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _STREAM if _STREAM is not None else torch.cuda.current_stream().cuda_stream
+
+
+class use_stream:
+    """`with ops.use_stream(s):` = `with torch.cuda.stream(s):` + caches the raw handle for the launches inside."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.ctx = torch.cuda.stream(stream)
+
+    def __enter__(self):
+        global _STREAM
+        self.prev = _STREAM
+        self.ctx.__enter__()
+        _STREAM = self.stream.cuda_stream
+        return self.stream
+
+    def __exit__(self, *a):
+        global _STREAM
+        _STREAM = self.prev
+        return self.ctx.__exit__(*a)
 
 
 def _p(t):

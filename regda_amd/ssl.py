@@ -42,6 +42,7 @@ class SSLStep:
         bounds = model.param_boundaries()
         self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
+        self._graph = None
         self.world = self.reducer.world
         self.group = process_group
 
@@ -50,10 +51,40 @@ class SSLStep:
     def step(self, images_s, label_s, images_t, soft_t, regs_t, lr):
         """One SSL iteration.  Returns device tensors (loss_source, loss_target, grad_norm_sq): nothing here
         synchronises with the host."""
-        m = self.model
-        m.train()
-        m._maybe_sync()
+        if self._graph is not None:
+            return self._replay(images_s, label_s, images_t, soft_t, regs_t, lr)
         self.lr_dev.fill_(float(lr))
+        with ops.use_stream(torch.cuda.current_stream()):
+            return self._step(images_s, label_s, images_t, soft_t, regs_t)
+
+    def capture(self, images_s, label_s, images_t, soft_t, regs_t):
+        """Capture one whole step (both streams) into a hipGraph; later `step()` calls replay it.  The step is a
+        static launch sequence over fixed shapes, so replay removes the ~20 ms of per-step host launch work.
+        Call after at least one eager step (momentum initialisation is a different kernel variant)."""
+        assert not self.first, 'run one eager step before capture()'
+        if self.world > 1:
+            raise RuntimeError('whole-step graphs are single-GPU; the multi-GPU path stays eager')
+        self._static = [None if t is None else t.clone() for t in (images_s, label_s, images_t, soft_t, regs_t)]
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            with ops.use_stream(torch.cuda.current_stream()):
+                self._out = self._step(*self._static)
+        self._graph = g
+
+    def _replay(self, images_s, label_s, images_t, soft_t, regs_t, lr):
+        for dst, src in zip(self._static, (images_s, label_s, images_t, soft_t, regs_t)):
+            if dst is not None and src is not dst:
+                dst.copy_(src, non_blocking=True)
+        self.lr_dev.fill_(float(lr))
+        self._graph.replay()
+        return self._out
+
+    def _step(self, images_s, label_s, images_t, soft_t, regs_t):
+        m = self.model
+        if not m.training:
+            m.train()
+        m._maybe_sync()
         m.flat_g.zero_()
         # source and target batch go through the network TOGETHER (twice the GEMM rows per launch), as two
         # BatchNorm groups: statistics, running-stat updates and gradients stay per domain like the
@@ -65,14 +96,13 @@ class SSLStep:
         if teacher_on_side:
             # the EMA teacher's forward is independent of the student's: it runs on the second stream, next to it
             self.wgrad_stream.wait_stream(main)
-            with torch.cuda.stream(self.wgrad_stream):
+            with ops.use_stream(self.wgrad_stream):
                 soft_t = self.teacher_probs(images_t)
         x1, x2, feat = m._forward_plan([images_s.contiguous().float(), images_t.contiguous().float()], T)
         s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
         feat_s, feat_t = feat[:nb], feat[nb:]
         if teacher_on_side:
             main.wait_stream(self.wgrad_stream)
-            soft_t.record_stream(main)
         elif soft_t is None:
             soft_t = self.teacher_probs(images_t)
         # ---- label path (a5-a8)
@@ -99,11 +129,12 @@ class SSLStep:
         # ---- backward (both domains in one pass); all-reduce buckets are released as it moves down the net
         self.reducer.reset()
         T['wgrad_stream'] = self.wgrad_stream
+        T['main_stream'] = main
 
         def progress(offset):
             if self.world > 1:
                 if self.wgrad_stream is not None:       # a bucket needs the weight gradients of its layers too
-                    torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+                    main.wait_stream(self.wgrad_stream)
                 self.reducer.ready_down_to(offset)
         m._backward_plan(T, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]), on_progress=progress)
         self.reducer.finish()

@@ -1,0 +1,98 @@
+"""GPU: the fused SSL step (regda_amd/ssl.py) end to end against the CPU oracle step (oracle/step.py), which is
+itself pinned to the reference's step by tests/test_oracle_golden.py::test_full_step_small."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import labels as olab
+from oracle import model as omodel
+from oracle.step import CpuStep
+
+pytestmark = pytest.mark.gpu
+
+
+def build(rt):
+    from regda_amd.models.Encoder import Deeplabv2
+    return Deeplabv2(dict(backbone=dict(resnet_type=rt, output_stride=16, pretrained=False), multi_layer=True,
+                          cascade=False, use_ppm=True, ppm=dict(num_classes=6, use_aux=False, fc_dim=2048),
+                          inchannels=2048, num_classes=6, is_ins_norm=True))
+
+
+def test_fused_step_matches_oracle_step():
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=6)
+    b = make_batch(b=4, size=128, seed=11, device='cpu')
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(1))
+    ones = torch.ones(4, 512)
+    cpu = CpuStep(sd, protos, resnet_type=rt, lr=1e-3)
+    ref = cpu.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], (ones, ones), (ones, ones))
+    m = build(rt)
+    m.load_state_dict(sd, strict=True)
+    m.set_drop_masks(ones, ones)
+    st = SSLStep(m, protos)
+    g = {k: v.cuda() for k, v in b.items()}
+    ls, lt, gn = st.step(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'], 1e-3)
+    # losses / gradient norm (stated tolerance: bf16 network)
+    assert ls.item() == pytest.approx(ref['loss_source'], rel=0.02)
+    assert lt.item() == pytest.approx(ref['loss_target'], rel=0.05, abs=0.02)
+    assert gn.sqrt().item() == pytest.approx(ref['grad_norm'], rel=0.06)
+    # pseudo labels: the integer path is exact GIVEN the same soft input; end to end the bf16 logits move a few
+    # borderline pixels across the threshold
+    hard = st.last_hard.cpu().numpy()
+    assert (hard != ref['hard'].numpy()).mean() < 0.03
+    regs = b['regs_t'].squeeze(1).numpy()
+    assert np.array_equal(hard[regs == 0], olab.homogenize(hard, regs, 0.5, 6, -1)[regs == 0])
+    assert st.lrh_flag() == 0
+    # prototypes and the SGD update
+    assert ((st.prototypes.cpu() - cpu.prototypes).norm() / cpu.prototypes.norm()).item() < 2e-3
+    named = dict(m.named_parameters())
+    k = 'encoder.resnet.conv1.weight'
+    d_ref = cpu.sd[k].detach() - sd[k]
+    d_got = named[k].detach().cpu() - sd[k]
+    cos = (d_ref.flatten() @ d_got.flatten() / (d_ref.norm() * d_got.norm())).item()
+    # the stem is the far end of the backward chain: the most amplified bf16 noise
+    assert cos > 0.93 and d_got.norm().item() == pytest.approx(d_ref.norm().item(), rel=0.1)
+    # BN buffers were updated twice (src, tgt) in one fused pass
+    assert int(m.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == 2
+    assert ((m.state_dict()['encoder.resnet.bn1.running_mean'].cpu() - cpu.sd['encoder.resnet.bn1.running_mean']).abs().max()
+            < 5e-3)
+
+
+def test_online_ema_teacher_and_reference_style_loop():
+    """(a) SSLStep with the online EMA teacher runs and keeps the shadow = EMA of the weights; (b) the reference-style
+    loop (model(), loss_calc, backward, clip, optim.SGD) works on the same model through torch.autograd."""
+    from regda_amd.gast.balance import CrossEntropy
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    from regda_amd.utils.tools import loss_calc
+    rt = 'resnet17t'
+    m = build(rt)
+    sd = omodel.init_state_dict(rt, 6, seed=8)
+    m.load_state_dict(sd, strict=True)
+    g = make_batch(b=2, size=64, seed=3, with_soft=False)
+    st = SSLStep(m, torch.randn(6, 2048), ema_decay=0.9)
+    w0 = m.flat_p.clone()
+    for i in range(2):
+        ls, lt, gn = st.step(g['images_s'], g['label_s'], g['images_t'], None, g['regs_t'], 1e-3)
+    assert torch.isfinite(ls) and torch.isfinite(lt) and torch.isfinite(gn)
+    w2 = m.flat_p
+    assert not torch.equal(w0, w2)
+    # shadow_2 = .1*w2 + .9*(.1*w1 + .9*w0): lies between w0 and w2, not equal to either
+    sh = st.teacher.flat_p
+    assert not torch.equal(sh, w2) and not torch.equal(sh, w0)
+    assert ((sh - w0).norm() < (w2 - w0).norm()).item()
+    # reference-style loop
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    m.train()
+    before = m.flat_p.clone()
+    x1, x2, feat = m(g['images_s'])
+    loss = loss_calc([x1, x2], g['label_s'], loss_fn=CrossEntropy(-1), multi=True)
+    opt.zero_grad()
+    loss.backward()
+    total = torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=32, norm_type=2)
+    opt.step()
+    assert torch.isfinite(total) and not torch.equal(before, m.flat_p)
+    x1b, _, _ = m(g['images_s'])          # weights were re-synced automatically (bf16 mirror / transposed copies)
+    assert not torch.equal(x1, x1b)

@@ -36,6 +36,7 @@ def parse():
     ap.add_argument('--no-teacher', action='store_true', help='offline soft labels (the reference\'s mode) instead of the online EMA teacher')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--serial', action='store_true', help='one stream only (clean per-kernel profiles)')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 34.5 vs 31.6 ms)')
     ap.add_argument('--cpu-batch', type=int, default=2)
     return ap.parse_args()
@@ -147,7 +148,7 @@ def main():
         model.sync_weights()
     protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
     teacher = not args.no_teacher
-    step = SSLStep(model, protos, ema_decay=0.999 if teacher else None)
+    step = SSLStep(model, protos, ema_decay=0.999 if teacher else None, overlap_wgrad=not args.serial)
     batch = make_batch(b=args.batch, size=args.size, seed=2333 + rank, with_soft=not teacher)
     soft = batch.get('soft_t')
     it = [0]
@@ -202,8 +203,10 @@ def main():
         'loss_source': losses[0], 'loss_target': losses[1], 'hip_graph': graphed,
     }
     if rank == 0 and world == 1 and not args.no_roofline:
-        step._graph = None          # the per-launch HIP-event probe needs the eager path
+        step._graph = None          # the per-launch HIP-event probe needs the eager path ...
+        side, step.wgrad_stream = step.wgrad_stream, None     # ... and one stream, so a launch's events bracket only itself
         gf, ms, kinds = conv_flops_probe(one)
+        step.wgrad_stream = side
         res['roofline'] = {'bound': 'mfma', 'achieved': gf / ms, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': gf / ms / MFMA_PEAK_TFLOPS, 'traffic': None,
                            'kernel': 'conv_igemm_kernel + conv_wgrad_kernel (all conv launches of one step, HIP events)',

@@ -60,26 +60,27 @@ static __device__ __forceinline__ void src_coord(int mode, int base, int t, int 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int BC, int BP, int STAGES = 3>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
+template <int BC, int BP, int STAGES = 3, int WC = 2, int WP = 2>
+__global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only
-    constexpr int FI = BC / 64, FJ = BP / 64;
-    constexpr int WL = BC / 32, XL = BP / 32;          // LDS-DMA instructions per wave per tile (1 KiB each)
+    constexpr int NW = WC * WP, NT = 64 * NW;            // waves / threads per workgroup
+    constexpr int FI = BC / WC / 32, FJ = BP / WP / 32;  // 32x32 accumulators per wave
+    constexpr int WL = BC / (NW * 8), XL = BP / (NW * 8);   // LDS-DMA instructions per wave per tile (1 KiB each)
     constexpr int LD = WL + XL;
     constexpr int TILE = (BC + BP) * 128;               // bytes of one K tile (64 channels)
     constexpr int CSTR = BC * 2 + 16;                   // epilogue row stride (bytes)
-    constexpr int EPI = BP * CSTR + 4 * BC * 2 * 4;
+    constexpr int EPI = BP * CSTR + NW * BC * 2 * 4;
     constexpr int SMEM = (STAGES * TILE > EPI) ? STAGES * TILE : EPI;
     __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wc = wave & 1, wp = wave >> 1;
+    const int wc = wave % WC, wp = wave / WC;
     const int logical = xcd_remap(blockIdx.x, a.tiles_c * a.tiles_p);
     const int c0 = (logical % a.tiles_c) * BC;
     const int m0 = (logical / a.tiles_c) * BP;
     const int taps = a.KH * a.KW;
-    // LDS-DMA geometry: instruction q of this wave fills rows q*32 + wave*8 .. +8 of the tile; lane -> (row, slot).
+    // LDS-DMA geometry: instruction q of this wave fills rows (q*NW + wave)*8 .. +8 of the tile; lane -> (row, slot).
     // Loads are buffer_load_dwordx4 ... lds: per-lane 32-bit byte offset (fixed for W rows, recomputed once
     // per filter tap for the gathered pixel rows) + ONE scalar offset per K tile; rows that are padding /
     // out of range carry an out-of-range offset and the hardware deposits zeros (tests/test_hw_semantics_gpu.py).
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
     bool xm[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-        int r = i * 32 + wave * 8 + lrow8;
+        int r = (i * NW + wave) * 8 + lrow8;
         int m = m0 + r;
         xm[i] = m < a.M;
         int mm = xm[i] ? m : 0;
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
     int wvo[WL];
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-        int r = i * 32 + wave * 8 + lrow8;
+        int r = (i * NW + wave) * 8 + lrow8;
         int co = c0 + r;
         wvo[i] = (co < a.Cout) ? (co * taps * a.Cin * 2 + (lslot ^ ((r >> 1) & 7)) * 16) : OOB;
     }
@@ -133,11 +134,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
         const int so_w = (tap * a.Cin + ci0) * 2, so_x = ci0 * 2;
 #pragma unroll
         for (int i = 0; i < WL; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * 4096), 16, wvo[i], so_w, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * NW * 1024), 16, wvo[i], so_w, 0, 0);
         unsigned char* xb = wb + BC * 128;
 #pragma unroll
         for (int i = 0; i < XL; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(xb + i * 4096), 16, xvo[i], so_x, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(xb + i * NW * 1024), 16, xvo[i], so_x, 0, 0);
     };
     auto advance = [&]() {
         ci0 += 64;
@@ -189,12 +190,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
-                int r = wc * (BC / 2) + i * 32 + lrow;
+                int r = wc * (BC / WC) + i * 32 + lrow;
                 af[kk][i] = *(const bf16x8*)(wb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < FJ; ++j) {
-                int r = wp * (BP / 2) + j * 32 + lrow;
+                int r = wp * (BP / WP) + j * 32 + lrow;
                 bfr[kk][j] = *(const bf16x8*)(xb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
             }
         }
@@ -215,10 +216,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
-            int px = wp * (BP / 2) + j * 32 + lrow;
+            int px = wp * (BP / WP) + j * 32 + lrow;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                int co = wc * (BC / 2) + i * 32 + 8 * g + 4 * lk;
+                int co = wc * (BC / WC) + i * 32 + 8 * g + 4 * lk;
                 uint2 pk;
                 pk.x = pack2bf(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]);
                 pk.y = pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
         }
     __syncthreads();
     constexpr int VPR = BC / 8;              // 16-byte vectors per C row
-    constexpr int RPP = 256 / VPR;           // rows per pass
+    constexpr int RPP = NT / VPR;            // rows per pass
     const int cv = t % VPR, rr = t / VPR;
     const int co = c0 + cv * 8;
     const bool cok = co < a.Cout;
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
                 q[e] += __shfl_xor(q[e], o, 64);
             }
         }
-        float* red = (float*)(smem + BP * CSTR);     // [4 waves][2][BC]
+        float* red = (float*)(smem + BP * CSTR);     // [NW waves][2][BC]
         if (lane < VPR) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -277,8 +278,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
         if (t < 2 * BC) {
             int which = t / BC, c = t % BC;
-            float tot = red[(0 * 2 + which) * BC + c] + red[(1 * 2 + which) * BC + c] +
-                        red[(2 * 2 + which) * BC + c] + red[(3 * 2 + which) * BC + c];
+            float tot = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) tot += red[(wv * 2 + which) * BC + c];
             if (c0 + c < a.Cout)
                 atomicAdd(&a.stats[(((size_t)(m0 / a.rows_per_group) * NREP + (blockIdx.x & (NREP - 1))) * 2 + which) * a.Cout + c0 + c], tot);
         }
@@ -320,19 +322,25 @@ extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int
     // CU, so the long-K head convolutions want the largest tile that still gives every CU a workgroup
     // (128 x 256: 85 FLOP per byte); everything else runs fastest on 128 x 64 tiles, two workgroups per CU.
     int bc = (Cout <= 64) ? 64 : 128;
-    int bp = 64;
+    int bp = 64, waves = 4;
     const long long ktot = (long long)kh * kw * Cin;
-    if (bc == 128 && ktot >= 4096 && (long long)cdiv(M, 256) * cdiv(Cout, bc) >= 240) bp = 256;
+    if (bc == 128 && ktot >= 4096 && (long long)cdiv(M, 256) * cdiv(Cout, bc) >= 240) { bp = 256; waves = 8; }
+    else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= 512) { bp = 128; waves = 8; }
     if (stats && stat_groups > 1) {     // a tile may not straddle two statistics groups
         while (bp > 64 && (a.rows_per_group % bp)) bp >>= 1;
         if (a.rows_per_group % bp) return RGDA_ERR_UNSUPPORTED;
     }
+    // 4-wave workgroups: 3-stage ring; 8-wave 128x128: 2 stages = 64 KiB so that two workgroups (16 waves) share a CU
     int stages = (bc == 64) ? 2 : 3;
+    if (waves == 8) stages = (bp == 256) ? 83 : 82;
     if (const char* e = getenv("RGDA_TILE")) sscanf(e, "%d,%d,%d", &bc, &bp, &stages);   // tuning experiments only
     a.tiles_c = cdiv(Cout, bc);
     a.tiles_p = cdiv(M, bp);
     int grid = a.tiles_c * a.tiles_p;
-    if (bc == 128 && bp == 256) conv_igemm_kernel<128, 256, 3><<<grid, 256, 0, st>>>(a);
+    if (bc == 128 && bp == 128 && stages == 83) conv_igemm_kernel<128, 128, 3, 2, 4><<<grid, 512, 0, st>>>(a);
+    else if (bc == 128 && bp == 128 && stages == 82) conv_igemm_kernel<128, 128, 2, 2, 4><<<grid, 512, 0, st>>>(a);
+    else if (bc == 128 && bp == 256 && stages == 83) conv_igemm_kernel<128, 256, 3, 2, 4><<<grid, 512, 0, st>>>(a);
+    else if (bc == 128 && bp == 256) conv_igemm_kernel<128, 256, 3><<<grid, 256, 0, st>>>(a);
     else if (bc == 256 && bp == 128) conv_igemm_kernel<256, 128, 3><<<grid, 256, 0, st>>>(a);
     else if (bc == 128 && bp == 128 && stages == 2) conv_igemm_kernel<128, 128, 2><<<grid, 256, 0, st>>>(a);
     else if (bc == 128 && bp == 128 && stages == 4) conv_igemm_kernel<128, 128, 4><<<grid, 256, 0, st>>>(a);

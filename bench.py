@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--serial', action='store_true', help='one stream only (clean per-kernel profiles)')
+    ap.add_argument('--no-comm-overlap', action='store_true', help='all-reduce the whole gradient after backward instead of bucket by bucket during it')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 34.5 vs 31.6 ms)')
     ap.add_argument('--cpu-batch', type=int, default=2)
     return ap.parse_args()
@@ -130,8 +131,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if world > 1 or os.environ.get('RGDA_FORCE_DDP'):       # RGDA_FORCE_DDP=1: exercise the RCCL path on one GPU
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local), rank=rank, world_size=world,
+                                init_method=None if 'MASTER_ADDR' in os.environ else 'tcp://127.0.0.1:29533')
     from regda_amd.models.Encoder import Deeplabv2
     from regda_amd.ssl import SSLStep
     from regda_amd.synthetic import make_batch
@@ -142,13 +144,20 @@ def main():
                            multi_layer=True, cascade=False, use_ppm=True,
                            ppm=dict(num_classes=6, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=6,
                            is_ins_norm=True))
+    # random-init classifiers emit near-uniform probabilities, so no pseudo label would pass the 0.6 threshold and
+    # the target loss / its gradient would be identically zero (zero operands also let the chip clock higher):
+    # scale the two 6-class classifiers so the teacher is confident on part of the pixels.
+    with torch.no_grad():
+        for head in ('layer5', 'layer6'):
+            model.convs[f'{head}.conv_last.4'].w.mul_(40.0)
+    model.sync_weights()
     if world > 1:       # identical initial weights on every rank
         dist.broadcast(model.flat_p, 0)
         dist.broadcast(model.flat_buf, 0)
         model.sync_weights()
     protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
     teacher = not args.no_teacher
-    step = SSLStep(model, protos, ema_decay=0.999 if teacher else None, overlap_wgrad=not args.serial)
+    step = SSLStep(model, protos, ema_decay=0.999 if teacher else None, overlap_wgrad=not args.serial, overlap_comm=not args.no_comm_overlap)
     batch = make_batch(b=args.batch, size=args.size, seed=2333 + rank, with_soft=not teacher)
     soft = batch.get('soft_t')
     it = [0]
@@ -215,7 +224,7 @@ def main():
         res['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -25,10 +25,12 @@ def make_buckets(boundaries, total, bucket_elems):
 
 
 class FlatGradReducer:
-    def __init__(self, flat_g, boundaries, bucket_elems=8 << 20, group=None):
+    def __init__(self, flat_g, boundaries, bucket_elems=24 << 20, group=None):
         self.flat_g = flat_g
         self.group = group
+        import os
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = dist.is_initialized() and bool(os.environ.get('RGDA_FORCE_DDP'))   # single-GPU exercise of the path
         self.buckets = make_buckets(boundaries, flat_g.numel(), bucket_elems)
         self._next = 0
         self._works = []
@@ -40,7 +42,7 @@ class FlatGradReducer:
     def ready_down_to(self, offset):
         """Backward has finished every gradient at element offset >= `offset`: launch the buckets that
         lie entirely above it."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= offset:
             a, b = self.buckets[self._next]

@@ -18,8 +18,8 @@ from .ddp import FlatGradReducer
 class SSLStep:
     def __init__(self, model, prototypes, class_num=6, ignore_label=-1, momentum=0.9, weight_decay=5e-4,
                  max_norm=32.0, cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996, refine_temp=2.0,
-                 sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=8 << 20,
-                 process_group=None, overlap_wgrad=True):
+                 sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=24 << 20,
+                 process_group=None, overlap_wgrad=True, overlap_comm=True):
         self.model = model
         self.C, self.ig = class_num, ignore_label
         self.momentum, self.wd, self.max_norm = momentum, weight_decay, max_norm
@@ -43,6 +43,7 @@ class SSLStep:
         self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
         self._graph = None
+        self.overlap_comm = overlap_comm
         self.world = self.reducer.world
         self.group = process_group
 
@@ -132,10 +133,16 @@ class SSLStep:
         T['main_stream'] = main
 
         def progress(offset):
-            if self.world > 1:
-                if self.wgrad_stream is not None:       # a bucket needs the weight gradients of its layers too
-                    main.wait_stream(self.wgrad_stream)
-                self.reducer.ready_down_to(offset)
+            if (self.world > 1 or self.reducer.force) and self.overlap_comm:
+                if self.wgrad_stream is not None:
+                    # a bucket needs the weight gradients (second stream) AND the BN gradients (main stream) of its
+                    # layers: issue it from the second stream once that has caught up with this point of the main
+                    # stream, so the critical path never waits for communication
+                    self.wgrad_stream.wait_event(main.record_event())
+                    with ops.use_stream(self.wgrad_stream):
+                        self.reducer.ready_down_to(offset)
+                else:
+                    self.reducer.ready_down_to(offset)
         m._backward_plan(T, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]), on_progress=progress)
         self.reducer.finish()
         # ---- clip + SGD (+ EMA) in one pass over the flat buffers

@@ -44,54 +44,57 @@ def parse():
 
 
 def conv_flops_probe(step_fn):
-    """Run one step with HIP events around every conv launch; returns (total GFLOP, total ms, per-kind dict)."""
+    """Run one step with HIP events (torch.cuda.Event on the launch stream) around every conv launch.
+    Returns {kernel instantiation: dict(gflop, ms, launches, tflops, avg_us)}; names match rocprofv3's."""
     import torch
     from regda_amd import ops
+    from regda_amd._lib import lib
+    L = lib()
     rec = []
     o_conv, o_wgrad = ops.conv2d, ops.conv2d_wgrad
 
     def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1):
+        co, taps, ci = w.shape
+        M = N * Ho * Wo
+        code = L.raw('rgda_conv2d_tile')(M, co, kh, kw, ci, (M // stat_groups) if (stats is not None and stat_groups > 1) else 0)
+        bc, bp, stg = code & 1023, (code >> 10) & 1023, code >> 20
+        name = 'conv_igemm_kernel<%d, %d, %d, %s>' % (bc, bp, stg % 80 if stg >= 80 else stg, '2, 4' if stg >= 80 else '2, 2')
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups)
         e1.record()
-        co, taps, ci = w.shape
-        rec.append(('dgrad' if mode else 'fwd', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1,
-                    (N * Ho * Wo, co, ci, taps, stride, dil)))
+        rec.append((name, 2.0 * M * co * taps * ci, e0, e1, ('dgrad' if mode else 'fwd', M, co, ci, taps, stride, dil)))
 
     def wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
+        co, taps, ci = dw.shape
+        fused = (kh == 3 and kw == 3 and stride == 1 and pad == dil and Ho == H and Wo == W and
+                 -(-co // 64) * -(-ci // 64) >= 8 and min(W, 64) in (16, 32, 64))
+        name = ('conv_wgrad3x3_kernel<%d, %d>' % (min(W, 64), dil)) if fused else \
+            ('conv_wgrad_kernel<%d, %d>' % (64 if co <= 64 else 128, 64 if ci <= 64 else 128))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         o_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil)
         e1.record()
-        co, taps, ci = dw.shape
-        rec.append(('wgrad', 2.0 * N * Ho * Wo * co * taps * ci, e0, e1, (N * Ho * Wo, co, ci, taps, stride, dil)))
+        rec.append((name, 2.0 * N * Ho * Wo * co * taps * ci, e0, e1, ('wgrad', N * Ho * Wo, co, ci, taps, stride, dil)))
     ops.conv2d, ops.conv2d_wgrad = conv, wgrad
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
         ops.conv2d, ops.conv2d_wgrad = o_conv, o_wgrad
-    kinds = {}
-    shapes = {}
-    for kind, fl, e0, e1, shp in rec:
-        q = shapes.setdefault((kind,) + shp, [0.0, 0.0, 0])
-        q[0] += fl
-        q[1] += e0.elapsed_time(e1)
-        q[2] += 1
+    kern, shapes = {}, {}
+    for name, fl, e0, e1, shp in rec:
+        dt = e0.elapsed_time(e1)
+        k = kern.setdefault(name, [0.0, 0.0, 0])
+        k[0] += fl; k[1] += dt; k[2] += 1
+        q = shapes.setdefault(shp, [0.0, 0.0, 0])
+        q[0] += fl; q[1] += dt; q[2] += 1
     if os.environ.get('RGDA_CONV_REPORT'):
         with open(os.environ['RGDA_CONV_REPORT'], 'w') as f:
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 f.write('%-6s M=%-7d Co=%-5d Ci=%-5d taps=%d s=%d d=%d  n=%-3d ms=%8.3f  TF/s=%7.1f\n' % (k + (v[2], v[1], v[0] / 1e9 / max(v[1], 1e-9))))
-    for kind, fl, e0, e1, shp in rec:
-        k = kinds.setdefault(kind, [0.0, 0.0, 0])
-        k[0] += fl
-        k[1] += e0.elapsed_time(e1)
-        k[2] += 1
-    tot_f = sum(k[0] for k in kinds.values())
-    tot_ms = sum(k[1] for k in kinds.values())
-    return tot_f / 1e9, tot_ms, {k: dict(gflop=v[0] / 1e9, ms=v[1], launches=v[2],
-                                         tflops=v[0] / 1e9 / max(v[1], 1e-9)) for k, v in kinds.items()}
+    return {k: dict(gflop=v[0] / 1e9, ms=v[1], launches=v[2], tflops=v[0] / 1e9 / max(v[1], 1e-9),
+                    avg_us=v[1] / v[2] * 1e3) for k, v in kern.items()}
 
 
 def cpu_baseline(args):
@@ -214,12 +217,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_roofline:
         step._graph = None          # the per-launch HIP-event probe needs the eager path ...
         side, step.wgrad_stream = step.wgrad_stream, None     # ... and one stream, so a launch's events bracket only itself
-        gf, ms, kinds = conv_flops_probe(one)
+        kern = conv_flops_probe(one)
         step.wgrad_stream = side
-        res['roofline'] = {'bound': 'mfma', 'achieved': gf / ms, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': gf / ms / MFMA_PEAK_TFLOPS, 'traffic': None,
-                           'kernel': 'conv_igemm_kernel + conv_wgrad_kernel (all conv launches of one step, HIP events)',
-                           'gflop_per_step': gf, 'conv_ms_per_step': ms, 'by_kind': kinds}
+        # the dominant kernel = the conv instantiation with the most GPU time in the step
+        dom = max(kern, key=lambda k: kern[k]['ms'])
+        d = kern[dom]
+        gf = sum(v['gflop'] for v in kern.values())
+        ms = sum(v['ms'] for v in kern.values())
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')      # written from the rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
+        res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': MFMA_PEAK_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': d['tflops'] / MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                           'launches_per_step': d['launches'], 'avg_launch_us': d['avg_us'],
+                           'gflop_per_launch': d['gflop'] / d['launches'],
+                           'all_conv_kernels': {'achieved': gf / ms, 'frac': gf / ms / MFMA_PEAK_TFLOPS,
+                                                'gflop_per_step': gf, 'ms_per_step': ms},
+                           'by_kernel': kern}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:

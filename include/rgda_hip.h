@@ -134,6 +134,12 @@ int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const
                 int ldres, float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo,
                 int Cout, int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream);
 
+/* Which conv_igemm_kernel<BC, BP, STAGES, ...> instantiation rgda_conv2d picks for a problem: returns
+ * BC | BP << 10 | STAGES << 20 (STAGES 82 / 83 = 8-wave workgroups with a 2 / 3 stage ring), or a negative
+ * status.  rows_per_group = rows of one BatchNorm group when fused statistics with groups > 1 are requested, else 0.
+ * (bench.py labels its per-launch timings with it so they can be matched against rocprof kernel names.) */
+int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, int rows_per_group);
+
 /* Weight gradient: dw[co][tap][ci] (f32, row stride taps*Cin) +=
  *   sum_p dy[p][co] * x[src(p,tap)][ci]   (same geometry as mode 0 above). */
 int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int N, int H,

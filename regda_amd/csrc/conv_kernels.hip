@@ -294,6 +294,32 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #endif
 }
 
+// tile choice (measured on MI355X, tests/dev_conv_bench.py): the L2 -> LDS path sustains <= ~80 GB/s per CU, so the
+// long-K head convolutions want the largest tile that still gives every CU a workgroup (128 x 256, 85 FLOP per
+// byte, 8 waves); large-M layers run 128 x 128 tiles with 8 waves and a 2-stage ring (64 KiB: two workgroups =
+// 16 waves per CU); everything else 128 x 64 tiles with 4 waves, two workgroups per CU.  `stages` 82 / 83 mean
+// 8-wave workgroups with 2 / 3 stages.  rows_per_group != 0: a tile may not straddle two statistics groups.
+static int pick_tile(long long M, int Cout, long long ktot, int rows_per_group, int& bc, int& bp, int& stages) {
+    bc = (Cout <= 64) ? 64 : 128;
+    bp = 64;
+    int waves = 4;
+    if (bc == 128 && ktot >= 4096 && (long long)cdiv(M, 256) * cdiv(Cout, bc) >= 240) { bp = 256; waves = 8; }
+    else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= 512) { bp = 128; waves = 8; }
+    if (rows_per_group) {
+        while (bp > 64 && (rows_per_group % bp)) bp >>= 1;
+        if (rows_per_group % bp) return 1;
+    }
+    stages = (bc == 64) ? 2 : 3;
+    if (waves == 8 && bp >= 128) stages = (bp == 256) ? 83 : 82;
+    return 0;
+}
+
+extern "C" int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, int rows_per_group) {
+    int bc, bp, stages;
+    if (pick_tile(M, Cout, (long long)kh * kw * Cin, rows_per_group, bc, bp, stages)) return RGDA_ERR_UNSUPPORTED;
+    return bc | (bp << 10) | (stages << 20);
+}
+
 extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
                            float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                            int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream) {
@@ -318,21 +344,9 @@ extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int
     a.rows_per_group = (int)(M / stat_groups);
     a.dbg = nullptr;
     if (const char* e = getenv("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
-    // tile choice (measured on MI355X, tests/dev_conv_bench.py): the L2 -> LDS path sustains <= ~80 GB/s per
-    // CU, so the long-K head convolutions want the largest tile that still gives every CU a workgroup
-    // (128 x 256: 85 FLOP per byte); everything else runs fastest on 128 x 64 tiles, two workgroups per CU.
-    int bc = (Cout <= 64) ? 64 : 128;
-    int bp = 64, waves = 4;
-    const long long ktot = (long long)kh * kw * Cin;
-    if (bc == 128 && ktot >= 4096 && (long long)cdiv(M, 256) * cdiv(Cout, bc) >= 240) { bp = 256; waves = 8; }
-    else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= 512) { bp = 128; waves = 8; }
-    if (stats && stat_groups > 1) {     // a tile may not straddle two statistics groups
-        while (bp > 64 && (a.rows_per_group % bp)) bp >>= 1;
-        if (a.rows_per_group % bp) return RGDA_ERR_UNSUPPORTED;
-    }
-    // 4-wave workgroups: 3-stage ring; 8-wave 128x128: 2 stages = 64 KiB so that two workgroups (16 waves) share a CU
-    int stages = (bc == 64) ? 2 : 3;
-    if (waves == 8) stages = (bp == 256) ? 83 : 82;
+    int bc, bp, stages;
+    if (pick_tile(M, Cout, (long long)kh * kw * Cin, (stats && stat_groups > 1) ? a.rows_per_group : 0, bc, bp, stages))
+        return RGDA_ERR_UNSUPPORTED;
     if (const char* e = getenv("RGDA_TILE")) sscanf(e, "%d,%d,%d", &bc, &bp, &stages);   // tuning experiments only
     a.tiles_c = cdiv(Cout, bc);
     a.tiles_p = cdiv(M, bp);

@@ -134,6 +134,17 @@ int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const
                 int ldres, float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo,
                 int Cout, int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream);
 
+/* rgda_conv2d (normally the data-gradient, mode 1) with the BatchNorm-backward REDUCTION of the layer that consumes
+ * its output fused into the epilogue: with g = the stored result (after the residual add),
+ *   g' = g * [bn_y > 0 if relu] * nscale[n][c],  xhat = (bn_x - mean) * invstd  (mean/invstd from bn_mi[group]),
+ * sums[group][REPLICAS][2][Cout] += (sum g', sum g' * xhat) -- exactly what rgda_bn_bwd_reduce would compute
+ * from the stored tensor, without re-reading it. */
+int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
+                      float* sums, int groups, const void* bn_y, int bn_ldy, const void* bn_x, int bn_ldx,
+                      const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N, int H,
+                      int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
+                      int mode, rgda_stream_t stream);
+
 /* Which conv_igemm_kernel<BC, BP, STAGES, ...> instantiation rgda_conv2d picks for a problem: returns
  * BC | BP << 10 | STAGES << 20 (STAGES 82 / 83 = 8-wave workgroups with a 2 / 3 stage ring), or a negative
  * status.  rows_per_group = rows of one BatchNorm group when fused statistics with groups > 1 are requested, else 0.

@@ -31,6 +31,13 @@ struct ConvArgs {
     int tiles_c, tiles_p;
     int rows_per_group;   // BatchNorm statistics are kept per group of rows (src / tgt batch)
     unsigned long long* dbg;   // optional per-workgroup phase timestamps (tuning builds only)
+    // optional fused BatchNorm-backward reduction of the CONSUMER of this (data-gradient) output: with g = the stored
+    // result, g' = g * [bn_y > 0] * nscale, xhat = (bn_x - mean) * invstd, `stats` receives sum(g'), sum(g' * xhat)
+    const bf16_t* bn_y;
+    const bf16_t* bn_x;
+    const float* bn_mi;
+    const float* bn_nscale;
+    int bn_ldy, bn_ldx, bn_rpi, bn_relu;
 };
 
 static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -232,9 +239,14 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
     const int cv = t % VPR, rr = t / VPR;
     const int co = c0 + cv * 8;
     const bool cok = co < a.Cout;
-    float s[8], q[8];
+    float s[8], q[8], bmean[8], bistd[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; bmean[e] = 0.f; bistd[e] = 0.f; }
+    if (a.bn_x && cok) {
+        const float* mi = a.bn_mi + (size_t)(m0 / a.rows_per_group) * 2 * a.Cout;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bmean[e] = mi[co + e]; bistd[e] = mi[a.Cout + co + e]; }
+    }
 #pragma unroll 2
     for (int p = 0; p < BP / RPP; ++p) {
         int row = rr + p * RPP;
@@ -250,7 +262,24 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
                     val[e + 1] = (bf16_t)(pk >> 16);
                 }
             }
-            if (a.stats) {
+            if (a.bn_x) {
+                u16x8 xv = *(const u16x8*)(a.bn_x + (size_t)m * a.bn_ldx + co);
+                float gf[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gf[e] = bf2f(val[e]);
+                if (a.bn_relu) {
+                    u16x8 yv = *(const u16x8*)(a.bn_y + (size_t)m * a.bn_ldy + co);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gf[e] = (bf2f(yv[e]) > 0.f) ? gf[e] : 0.f;
+                }
+                if (a.bn_nscale) {
+                    const float* ns = a.bn_nscale + (size_t)(m / a.bn_rpi) * a.Cout + co;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += gf[e]; q[e] += gf[e] * ((bf2f(xv[e]) - bmean[e]) * bistd[e]); }
+            } else if (a.stats) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float f = bf2f(val[e]); s[e] += f; q[e] += f * f; }
             }
@@ -320,9 +349,12 @@ extern "C" int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, in
     return bc | (bp << 10) | (stages << 20);
 }
 
-extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                           float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                           int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream) {
+struct BnBwdFuse { const void* y; int ldy; const void* x; int ldx; const float* mi; const float* nscale; int rpi; int relu; };
+
+static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
+                         float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                         int kh, int kw, int stride, int pad, int dil, int mode, const BnBwdFuse* bnb,
+                         rgda_stream_t stream) {
     if (!x || !wgt || !y) return RGDA_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || dil <= 0 || pad < 0 || (mode != 0 && mode != 1))
@@ -342,6 +374,14 @@ extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int
     if (stat_groups < 1) stat_groups = 1;
     if (M % stat_groups) return RGDA_ERR_ARG;
     a.rows_per_group = (int)(M / stat_groups);
+    a.bn_y = a.bn_x = nullptr; a.bn_mi = a.bn_nscale = nullptr; a.bn_ldy = a.bn_ldx = a.bn_rpi = a.bn_relu = 0;
+    if (bnb) {
+        if (!stats || !bnb->x || !bnb->mi || (bnb->relu && !bnb->y) || (bnb->ldx & 7) || (bnb->relu && (bnb->ldy & 7)) ||
+            (bnb->nscale && bnb->rpi <= 0))
+            return RGDA_ERR_ARG;
+        a.bn_y = (const bf16_t*)bnb->y; a.bn_x = (const bf16_t*)bnb->x; a.bn_mi = bnb->mi; a.bn_nscale = bnb->nscale;
+        a.bn_ldy = bnb->ldy; a.bn_ldx = bnb->ldx; a.bn_rpi = bnb->rpi; a.bn_relu = bnb->relu;
+    }
     a.dbg = nullptr;
     if (const char* e = getenv("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
     int bc, bp, stages;
@@ -368,6 +408,23 @@ extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int
     else conv_igemm_kernel<64, 64><<<grid, 256, 0, st>>>(a);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
+}
+
+extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
+                           float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                           int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream) {
+    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, stats, stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
+                         pad, dil, mode, nullptr, stream);
+}
+
+extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
+                                 float* sums, int groups, const void* bn_y, int bn_ldy, const void* bn_x, int bn_ldx,
+                                 const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N,
+                                 int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                 int dil, int mode, rgda_stream_t stream) {
+    BnBwdFuse b = {bn_y, bn_ldy, bn_x, bn_ldx, bn_mi, bn_nscale, rows_per_image, relu};
+    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, sums, groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad,
+                         dil, mode, &b, stream);
 }
 
 // ======================================================================================

@@ -149,6 +149,7 @@ class Deeplabv2(nn.Module):
         self._init_weights()
         self._anchor = torch.zeros(1, device=self.device, requires_grad=True)   # routes autograd into backward()
         self._drop_override = None
+        self.fuse_bn_bwd = True      # fold BN-backward reductions into the producing data-gradient conv
         self._mat_cache = {}
         self._synced_version = -1
         self.sync_weights()
@@ -410,11 +411,18 @@ class Deeplabv2(nn.Module):
             T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale)
         return y, Ho, Wo
 
-    def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False):
+    def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False,
+                 consumer=None):
+        """Backward of one conv+BN(+ReLU) unit.  `consumer` = (tape key, relu) of the unit that will consume this
+        unit's data gradient: its BN-backward reduction is then folded into our data-gradient conv's epilogue."""
         x, c, y, mi, (N, H, W, Ho, Wo), nscale = T[key]
         M, C, G = N * Ho * Wo, conv.co, T['groups']
-        sums = T['sums_pool'].take(G * NREP * 2 * C)
-        ops.bn_bwd_reduce(g, y if relu else None, c, mi, sums, M, C, relu, nscale, Ho * Wo, groups=G)
+        sums = T.pop('sums:' + key, None)
+        if sums is None:
+            sums = T.pop('presums:' + key, None)        # arena slice reserved by a producer that could not fuse
+            if sums is None:
+                sums = T['sums_pool'].take(G * NREP * 2 * C)
+            ops.bn_bwd_reduce(g, y if relu else None, c, mi, sums, M, C, relu, nscale, Ho * Wo, groups=G)
         dc = torch.empty(M, C, dtype=BF, device=self.device)
         gm = torch.empty(M, C, dtype=BF, device=self.device) if want_gmask else None
         ops.bn_bwd_apply(g, y if relu else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm, bn.dgamma, bn.dbeta,
@@ -438,8 +446,22 @@ class Deeplabv2(nn.Module):
         dx = None
         if need_dx:
             dx = torch.empty(N * H * W, conv.ci, dtype=BF, device=self.device)
-            ops.conv2d(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil, 1, dx_res,
-                       None)
+            fused = False
+            if consumer is not None and self.fuse_bn_bwd:
+                ckey, crelu = consumer
+                cx, cc, cy, cmi, (cN, cH, cW, cHo, cWo), cns = T[ckey]
+                assert cN * cHo * cWo == N * H * W and cc.shape[1] == conv.ci
+                csums = T['sums_pool'].take(G * NREP * 2 * conv.ci)
+                try:
+                    ops.conv2d_bnbwd(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil,
+                                     1, dx_res, csums, G, cy if crelu else None, cc, cmi, crelu, cns, cHo * cWo)
+                    T['sums:' + ckey] = csums
+                    fused = True
+                except ValueError:          # row groups do not tile (tiny maps): plain conv, standalone reduction
+                    T['presums:' + ckey] = csums
+            if not fused:
+                ops.conv2d(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil, 1,
+                           dx_res, None)
         return dx, gm
 
     # ------------------------------------------------------------------ forward plan
@@ -565,17 +587,22 @@ class Deeplabv2(nn.Module):
         if on_progress is not None:
             on_progress(self._offset_of('layer5.ppm.0.1'))
         hh, ww = h, w
-        for p, inpl, planes, stride, dil, ds in reversed(self.blocks):
+        order = [b[0] for b in self.blocks]
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            p, inpl, planes, stride, dil, ds = self.blocks[bi]
             if dbg is not None:
                 dbg[p] = nchw(g, hh, ww)
                 hh, ww = hh * stride, ww * stride
-            da2, gm = self._cbr_bwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], g, True, want_gmask=True)
-            da1, _ = self._cbr_bwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], da2, True)
+            # the gradient that leaves this block is consumed by bn3 of the block above it in the net
+            below = (order[bi - 1] + '.3', True) if bi > 0 else None
+            da2, gm = self._cbr_bwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], g, True, want_gmask=True,
+                                    consumer=(p + '.2', True))
+            da1, _ = self._cbr_bwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], da2, True, consumer=(p + '.1', True))
             if ds:
                 dxd, _ = self._cbr_bwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], gm, False)
-                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=dxd)
+                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=dxd, consumer=below)
             else:
-                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm)
+                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm, consumer=below)
             if on_progress is not None:
                 on_progress(self._offset_of(p + '.conv1'))
         idx, (N, H1, W1, H2, W2) = T['pool']

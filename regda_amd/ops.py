@@ -196,6 +196,17 @@ def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None,
                pad, dil, mode, _stream())
 
 
+def conv2d_bnbwd(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, bn_mi, relu,
+                 nscale=None, rows_per_image=0):
+    """conv2d whose epilogue also accumulates the BN-backward sums of the consumer of `y` (see rgda_conv2d_bnbwd)."""
+    Cout, taps, Cin = w.shape
+    assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
+    lib().call('rgda_conv2d_bnbwd', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
+               _ld(res) if res is not None else 0, sums.data_ptr(), groups, _p(bn_y), _ld(bn_y) if bn_y is not None else 0,
+               bn_x.data_ptr(), _ld(bn_x), bn_mi.data_ptr(), _p(nscale), rows_per_image, int(relu), N, H, W, Cin, Ho, Wo,
+               Cout, kh, kw, stride, pad, dil, mode, _stream())
+
+
 def conv2d_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
     """dw f32 [Cout, kh*kw, Cin] contiguous, accumulated."""
     Cout, taps, Cin = dw.shape

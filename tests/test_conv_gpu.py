@@ -335,3 +335,28 @@ def test_batchnorm_bwd_with_dropout_scale(ops, C, N, HW):
     ops.bn_bwd_apply(gg, y, xg, mi, gamma.cuda(), sums, dx, M, C, True, None, dgam, dbet, ns.cuda(), HW)
     assert relerr(dx.float().cpu(), xr.grad) < 2e-2
     assert relerr(dgam.cpu(), gr.grad) < 1e-2 and relerr(dbet.cpu(), br.grad) < 1e-2
+
+
+@pytest.mark.parametrize('groups', [1, 2])
+def test_conv_dgrad_with_fused_bn_backward_reduction(ops, groups):
+    """rgda_conv2d_bnbwd: the data-gradient conv also accumulates the consumer BatchNorm's backward sums; they
+    must equal rgda_bn_bwd_reduce run on the stored gradient."""
+    g = torch.Generator().manual_seed(21)
+    N, H, W, Cf, Cb, k = 4, 16, 16, 128, 256, 3            # forward conv Cf -> Cb; its data gradient Cb -> Cf
+    M = N * H * W
+    dy = torch.randn(M, Cb, generator=g).to(BF).cuda()
+    wt = (torch.randn(Cf, k * k, Cb, generator=g) * 0.05).to(BF).cuda()
+    res = torch.randn(M, Cf, generator=g).to(BF).cuda()
+    cy = torch.randn(M, Cf, generator=g).to(BF).cuda()      # consumer's activation (ReLU mask) and raw conv output
+    cx = torch.randn(M, Cf, generator=g).to(BF).cuda()
+    mi = torch.stack([torch.randn(groups, Cf, generator=g) * 0.1, torch.rand(groups, Cf, generator=g) + 0.5], 1).cuda().contiguous()
+    ns = ((torch.rand(N, Cf, generator=g) > 0.2).float() / 0.8).cuda()
+    dx = torch.empty(M, Cf, dtype=BF, device='cuda')
+    sums = torch.zeros(groups, 8, 2, Cf, device='cuda')
+    ops.conv2d_bnbwd(dy, wt, dx, N, H, W, H, W, k, k, 1, 1, 1, 1, res, sums, groups, cy, cx, mi, True, ns, H * W)
+    dx2 = torch.empty_like(dx)
+    ops.conv2d(dy, wt, dx2, N, H, W, H, W, k, k, 1, 1, 1, 1, res, None)
+    assert torch.equal(dx, dx2)
+    ref = torch.zeros(groups, 8, 2, Cf, device='cuda')
+    ops.bn_bwd_reduce(dx, cy, cx, mi, ref, M, Cf, True, ns, H * W, groups=groups)
+    torch.testing.assert_close(sums.sum(1).cpu(), ref.sum(1).cpu(), rtol=2e-4, atol=2e-2)

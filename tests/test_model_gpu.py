@@ -154,11 +154,11 @@ def test_layerwise_backward_consistency():
     rec = []
     orig = E.Deeplabv2._cbr_bwd
 
-    def spy(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False):
+    def spy(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False, consumer=None):
         x, c, y, mi, dims, nscale = T[key]
         g0 = conv.g.clone()
         dg0, db0 = bn.dgamma.clone(), bn.dbeta.clone()
-        out = orig(self, T, key, conv, bn, g, relu, need_dx, want_gmask, dx_res, stem)
+        out = orig(self, T, key, conv, bn, g, relu, need_dx, want_gmask, dx_res, stem, consumer)
         if not stem and nscale is None:
             rec.append((key, conv, bn, x.clone(), c.clone(), y.clone(), g.clone(), dims, relu,
                         None if dx_res is None else dx_res.clone(), None if out[0] is None else out[0].clone(),

@@ -134,6 +134,14 @@ int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const
                 int ldres, float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo,
                 int Cout, int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream);
 
+/* Forward conv with an INFERENCE-mode BatchNorm (+ residual + ReLU) folded into the epilogue -- the EMA teacher's
+ * conv + BN + ReLU units (regda/models/Encoder.py:152-155 runs the model in eval()):
+ *   y = act((conv(x) - running_mean) / sqrt(running_var + eps) * gamma + beta + res). */
+int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
+                       const float* running_mean, const float* running_var, const float* gamma,
+                       const float* beta, float eps, int relu, int N, int H, int W, int Cin, int Ho, int Wo,
+                       int Cout, int kh, int kw, int stride, int pad, int dil, rgda_stream_t stream);
+
 /* rgda_conv2d (normally the data-gradient, mode 1) with the BatchNorm-backward REDUCTION of the layer that consumes
  * its output fused into the epilogue: with g = the stored result (after the residual add),
  *   g' = g * [bn_y > 0 if relu] * nscale[n][c],  xhat = (bn_x - mean) * invstd  (mean/invstd from bn_mi[group]),

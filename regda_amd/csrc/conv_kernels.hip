@@ -38,6 +38,13 @@ struct ConvArgs {
     const float* bn_mi;
     const float* bn_nscale;
     int bn_ldy, bn_ldx, bn_rpi, bn_relu;
+    // optional fused inference-mode BatchNorm (+ residual + ReLU): y = act((conv - rm) / sqrt(rv + eps) * gamma + beta + res)
+    const float* ev_rm;
+    const float* ev_rv;
+    const float* ev_gamma;
+    const float* ev_beta;
+    float ev_eps;
+    int ev_relu;
 };
 
 static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -247,13 +254,40 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bmean[e] = mi[co + e]; bistd[e] = mi[a.Cout + co + e]; }
     }
+    if (a.ev_rm && cok) {       // reuse the two register arrays: bistd = scale, bmean = shift
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float sc = a.ev_gamma[co + e] / sqrtf(a.ev_rv[co + e] + a.ev_eps);
+            bistd[e] = sc;
+            bmean[e] = a.ev_beta[co + e] - a.ev_rm[co + e] * sc;
+        }
+    }
 #pragma unroll 2
     for (int p = 0; p < BP / RPP; ++p) {
         int row = rr + p * RPP;
         int m = m0 + row;
         if (m < a.M && cok) {
             u16x8 val = *(const u16x8*)(smem + row * CSTR + cv * 16);
-            if (a.res) {
+            if (a.ev_rm) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bf2f(val[e]) * bistd[e] + bmean[e];
+                if (a.res) {
+                    u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += bf2f(rv[e]);
+                }
+                if (a.ev_relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    unsigned pk = pack2bf(f[e], f[e + 1]);
+                    val[e] = (bf16_t)(pk & 0xffffu);
+                    val[e + 1] = (bf16_t)(pk >> 16);
+                }
+            } else if (a.res) {
                 u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
@@ -350,11 +384,12 @@ extern "C" int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, in
 }
 
 struct BnBwdFuse { const void* y; int ldy; const void* x; int ldx; const float* mi; const float* nscale; int rpi; int relu; };
+struct BnEvalFuse { const float* rm; const float* rv; const float* gamma; const float* beta; float eps; int relu; };
 
 static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
                          float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int kh, int kw, int stride, int pad, int dil, int mode, const BnBwdFuse* bnb,
-                         rgda_stream_t stream) {
+                         rgda_stream_t stream, const BnEvalFuse* bne = nullptr) {
     if (!x || !wgt || !y) return RGDA_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || dil <= 0 || pad < 0 || (mode != 0 && mode != 1))
@@ -381,6 +416,12 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
             return RGDA_ERR_ARG;
         a.bn_y = (const bf16_t*)bnb->y; a.bn_x = (const bf16_t*)bnb->x; a.bn_mi = bnb->mi; a.bn_nscale = bnb->nscale;
         a.bn_ldy = bnb->ldy; a.bn_ldx = bnb->ldx; a.bn_rpi = bnb->rpi; a.bn_relu = bnb->relu;
+    }
+    a.ev_rm = a.ev_rv = a.ev_gamma = a.ev_beta = nullptr; a.ev_eps = 0.f; a.ev_relu = 0;
+    if (bne) {
+        if (!bne->rm || !bne->rv || !bne->gamma || !bne->beta || stats) return RGDA_ERR_ARG;
+        a.ev_rm = bne->rm; a.ev_rv = bne->rv; a.ev_gamma = bne->gamma; a.ev_beta = bne->beta; a.ev_eps = bne->eps;
+        a.ev_relu = bne->relu;
     }
     a.dbg = nullptr;
     if (const char* e = getenv("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
@@ -415,6 +456,15 @@ extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int
                            int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream) {
     return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, stats, stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
                          pad, dil, mode, nullptr, stream);
+}
+
+extern "C" int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
+                                  const float* running_mean, const float* running_var, const float* gamma,
+                                  const float* beta, float eps, int relu, int N, int H, int W, int Cin, int Ho, int Wo,
+                                  int Cout, int kh, int kw, int stride, int pad, int dil, rgda_stream_t stream) {
+    BnEvalFuse e = {running_mean, running_var, gamma, beta, eps, relu};
+    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, nullptr, 1, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil,
+                         0, nullptr, stream, &e);
 }
 
 extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,

@@ -390,6 +390,14 @@ class Deeplabv2(nn.Module):
         M = N * Ho * Wo
         train = T is not None
         G = T['groups'] if train else 1
+        if not train:       # inference: conv + BN + residual + ReLU in one kernel
+            y = torch.empty(M, conv.co, dtype=BF, device=self.device)
+            if geom is None:
+                ops.conv2d_bneval(x, conv.wb if wb is None else wb, y, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride,
+                                  conv.pad, conv.dil, bn.rm, bn.rv, bn.gamma, bn.beta, relu, res)
+            else:
+                ops.conv2d_bneval(x, wb, y, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1, bn.rm, bn.rv, bn.gamma, bn.beta, relu, res)
+            return y, Ho, Wo
         c = torch.empty(M, conv.co, dtype=BF, device=self.device)
         stats = T['stats_pool'].take(G * NREP * 2 * conv.co) if train else None
         if geom is None:

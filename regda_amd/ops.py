@@ -196,6 +196,15 @@ def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None,
                pad, dil, mode, _stream())
 
 
+def conv2d_bneval(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, gamma, beta, relu, res=None, eps=1e-5):
+    """conv + inference-mode BN (+ residual + ReLU) in one kernel (the EMA teacher's units)."""
+    Cout, taps, Cin = w.shape
+    assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
+    lib().call('rgda_conv2d_bneval', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
+               _ld(res) if res is not None else 0, rm.data_ptr(), rv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
+               int(relu), N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, _stream())
+
+
 def conv2d_bnbwd(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, bn_mi, relu,
                  nscale=None, rows_per_image=0):
     """conv2d whose epilogue also accumulates the BN-backward sums of the consumer of `y` (see rgda_conv2d_bnbwd)."""

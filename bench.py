@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--no-comm-overlap', action='store_true', help='all-reduce the whole gradient after backward instead of bucket by bucket during it')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 34.5 vs 31.6 ms)')
     ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--phases', action='store_true', help='HIP-event phase marks of one extra step, to stderr')
     return ap.parse_args()
 
 
@@ -51,48 +52,84 @@ def conv_flops_probe(step_fn):
     from regda_amd._lib import lib
     L = lib()
     rec = []
-    o_conv, o_wgrad = ops.conv2d, ops.conv2d_wgrad
+    o_conv, o_wgrad, o_bne, o_bnb = ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd
+    o_wgrad_g = ops.conv2d_wgrad_grouped
 
-    def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1):
+    def timed(kind, w, N, Ho, Wo, kh, kw, stride, dil, rows_per_group, launch):
         co, taps, ci = w.shape
         M = N * Ho * Wo
-        code = L.raw('rgda_conv2d_tile')(M, co, kh, kw, ci, (M // stat_groups) if (stats is not None and stat_groups > 1) else 0)
+        code = L.raw('rgda_conv2d_tile')(M, co, kh, kw, ci, rows_per_group)
         bc, bp, stg = code & 1023, (code >> 10) & 1023, code >> 20
         name = 'conv_igemm_kernel<%d, %d, %d, %s>' % (bc, bp, stg % 80 if stg >= 80 else stg, '2, 4' if stg >= 80 else '2, 2')
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups)
+        launch()
         e1.record()
-        rec.append((name, 2.0 * M * co * taps * ci, e0, e1, ('dgrad' if mode else 'fwd', M, co, ci, taps, stride, dil)))
+        rec.append((name, 2.0 * M * co * taps * ci, e0, e1, (kind, M, co, ci, taps, stride, dil)))
 
-    def wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
+    def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1):
+        rpg = (N * Ho * Wo // stat_groups) if (stats is not None and stat_groups > 1) else 0
+        timed('dgrad' if mode else 'fwd', w, N, Ho, Wo, kh, kw, stride, dil, rpg,
+              lambda: o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups))
+
+    def conv_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, *a, **k):
+        timed('fwd-ev', w, N, Ho, Wo, kh, kw, stride, dil, 0,
+              lambda: o_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, *a, **k))
+
+    def conv_bnb(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, *a, **k):
+        timed('dgrad+bn' if mode else 'fwd+bn', w, N, Ho, Wo, kh, kw, stride, dil, (N * Ho * Wo // groups) if groups > 1 else 0,
+              lambda: o_bnb(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, *a, **k))
+
+    def wgrad_kernel_name(item):
+        x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil = item
         co, taps, ci = dw.shape
         fused = (kh == 3 and kw == 3 and stride == 1 and pad == dil and Ho == H and Wo == W and
-                 -(-co // 64) * -(-ci // 64) >= 8 and min(W, 64) in (16, 32, 64))
-        name = ('conv_wgrad3x3_kernel<%d, %d>' % (min(W, 64), dil)) if fused else \
-            ('conv_wgrad_kernel<%d, %d>' % (64 if co <= 64 else 128, 64 if ci <= 64 else 128))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        o_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil)
-        e1.record()
-        rec.append((name, 2.0 * N * Ho * Wo * co * taps * ci, e0, e1, ('wgrad', N * Ho * Wo, co, ci, taps, stride, dil)))
-    ops.conv2d, ops.conv2d_wgrad = conv, wgrad
+                 -(-co // 64) * -(-ci // 64) >= 8 and min(W, 64) in (16, 32, 64) and W % min(W, 64) == 0 and
+                 H % (64 // min(W, 64)) == 0 and dil in (1, 2))
+        if fused:
+            return 'conv_wgrad3x3_kernel<%d, %d>' % (min(W, 64), dil)
+        bco, bci = (64 if co <= 64 else 128), (64 if ci <= 64 else 128)
+        wi, wj = {(128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 2)}[(bco, bci)]
+        return 'conv_wgrad_kernel<%d, %d, %d, %d, 3>' % (bco, bci, wi, wj)
+
+    def wgrad_grouped(items):
+        # the library buckets a list by kernel instantiation (order kept, 16 layers per launch); hand it one
+        # bucket at a time so the events bracket the launches of one instantiation
+        buckets = {}
+        for it in items:
+            buckets.setdefault(wgrad_kernel_name(it), []).append(it)
+        for name, its in buckets.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_wgrad_g(its)
+            e1.record()
+            fl = sum(2.0 * it[3] * it[6] * it[7] * it[2].numel() for it in its)
+            rec.append((name, fl, e0, e1, ('wgrad x%d' % len(its),) + (its[0][3] * its[0][6] * its[0][7],) + tuple(its[0][2].shape[i] for i in (0, 2, 1)) + (its[0][10], its[0][12]),
+                        -(-len(its) // 16)))
+
+    def wgrad(*item):
+        wgrad_grouped([item])
+    ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd = conv, wgrad, conv_bne, conv_bnb
+    ops.conv2d_wgrad_grouped = wgrad_grouped
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
-        ops.conv2d, ops.conv2d_wgrad = o_conv, o_wgrad
+        ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd = o_conv, o_wgrad, o_bne, o_bnb
+        ops.conv2d_wgrad_grouped = o_wgrad_g
     kern, shapes = {}, {}
-    for name, fl, e0, e1, shp in rec:
+    for r in rec:
+        name, fl, e0, e1, shp = r[:5]
+        nl = r[5] if len(r) > 5 else 1          # kernel launches inside the bracket
         dt = e0.elapsed_time(e1)
         k = kern.setdefault(name, [0.0, 0.0, 0])
-        k[0] += fl; k[1] += dt; k[2] += 1
+        k[0] += fl; k[1] += dt; k[2] += nl
         q = shapes.setdefault(shp, [0.0, 0.0, 0])
-        q[0] += fl; q[1] += dt; q[2] += 1
+        q[0] += fl; q[1] += dt; q[2] += nl
     if os.environ.get('RGDA_CONV_REPORT'):
         with open(os.environ['RGDA_CONV_REPORT'], 'w') as f:
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                f.write('%-6s M=%-7d Co=%-5d Ci=%-5d taps=%d s=%d d=%d  n=%-3d ms=%8.3f  TF/s=%7.1f\n' % (k + (v[2], v[1], v[0] / 1e9 / max(v[1], 1e-9))))
+                f.write('%-8s M=%-7d Co=%-5d Ci=%-5d taps=%d s=%d d=%d  n=%-3d ms=%8.3f  TF/s=%7.1f\n' % (k + (v[2], v[1], v[0] / 1e9 / max(v[1], 1e-9))))
     return {k: dict(gflop=v[0] / 1e9, ms=v[1], launches=v[2], tflops=v[0] / 1e9 / max(v[1], 1e-9),
                     avg_us=v[1] / v[2] * 1e3) for k, v in kern.items()}
 
@@ -190,6 +227,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one()
+    t_host = time.perf_counter() - t0           # host launch work only (the GPU may still be running)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -200,6 +238,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = [float(x.item()) for x in out]
+    if args.phases and rank == 0:
+        one()                       # keep the GPU queue primed like in the timed loop
+        step.marks = []
+        one()
+        marks, step.marks = step.marks, None
+        one()
+        torch.cuda.synchronize()
+        base = marks[0][1]
+        for name, ev in marks:
+            print('  %+9.3f ms  %s' % (base.elapsed_time(ev), name), file=sys.stderr)
     pairs = args.batch * world * args.steps
     value = pairs / dt
     gflop_pair = GFLOP_PER_PAIR_STUDENT + (GFLOP_PER_PAIR_TEACHER if teacher else 0.0)
@@ -213,6 +261,7 @@ def main():
         'pairs_per_sec_per_gpu': value / world,
         'step_mfma_frac': value / world * gflop_pair / (MFMA_PEAK_TFLOPS * 1e3),
         'loss_source': losses[0], 'loss_target': losses[1], 'hip_graph': graphed,
+        'host_enqueue_ms_per_step': t_host / args.steps * 1e3,
     }
     if rank == 0 and world == 1 and not args.no_roofline:
         step._graph = None          # the per-launch HIP-event probe needs the eager path ...

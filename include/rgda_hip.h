@@ -165,6 +165,21 @@ int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* d
                       int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride,
                       int pad, int dil, rgda_stream_t stream);
 
+/* The weight gradients of several layers in as few launches as possible (same arithmetic as n calls of
+ * rgda_conv2d_wgrad, accumulated into each dw).  Layers that map to the same kernel instantiation share a
+ * launch (up to 16 per launch): autograd hands the reference one conv-backward at a time
+ * (tools/train_ssl_reg.py:236 loss.backward()), but the gradients are only needed by clip + SGD
+ * (tools/train_ssl_reg.py:237-238), so the host may collect them while the data-gradient chain runs on.
+ * `descs` is a host array; it is consumed before the call returns. */
+typedef struct rgda_wgrad_desc {
+    const void* x;      /* bf16 [N*H*W][ldx] */
+    const void* dy;     /* bf16 [N*Ho*Wo][lddy] */
+    float* dw;          /* f32 [Cout][kh*kw][Cin] */
+    int ldx, lddy;
+    int N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil;
+} rgda_wgrad_desc;
+int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, rgda_stream_t stream);
+
 /* Stem im2col: NCHW f32 image (N,3,H,W) -> [N*Ho*Wo][Kp] bf16 patches of the
  * 7x7/2 pad-3 conv (regda/_resnets.py:150-151), k index = (kh*7+kw)*3+c, zero padded to Kp. */
 int rgda_stem_im2col(const float* img, void* col, int N, int H, int W, int Ho, int Wo, int Kp,

@@ -489,24 +489,75 @@ struct WgradArgs {
     int M;
     int tiles_co, tiles_ci, splits, kt_per_split;
     int howo_shift, wo_shift;   // log2 when powers of two, else -1
+    int tap_fused;              // host side: which kernel family the layer maps to
+    unsigned long long* dbg;    // tuning builds only: per-workgroup phase timestamps
 };
 
-template <int BCO, int BCI>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
+// WI x WJ waves tile the [BCO][BCI] result; 8 waves (two per SIMD) keep the 8-byte transposing LDS reads and the
+// MFMA pipe busy while the other wave of the SIMD waits (one wave per SIMD reaches a fraction of the LDS rate).
+// One launch covers the weight gradients of up to RGDA_WGRAD_MAXG layers that map to the same kernel
+// instantiation: workgroup ids [first[l], first[l+1]) belong to layer l.  A layer-3 bottleneck of ResNet-101 has
+// only 16 result tiles, so a launch per layer must split K 16 ways to fill 256 CUs -- 16x the fp32 atomics, and a
+// launch ramp, a first-tile miss and an atomic drain per 9 GFLOP.  Grouped, the tiles of many layers fill the
+// chip with 1-2 K splits and those fixed costs are paid once per group.
+#define RGDA_WGRAD_MAXG 16
+struct WgradGroup {
+    int n;
+    int first[RGDA_WGRAD_MAXG + 1];
+    WgradArgs a[RGDA_WGRAD_MAXG];
+};
+
+// LDS-DMA issued from inline assembly (weight-gradient kernels).  Through the builtin the compiler knows the
+// instruction writes LDS and -- it cannot prove which bytes -- puts `s_waitcnt vmcnt(0)` in front of the
+// transposing LDS reads of the K loop, which drains the tiles prefetched for the NEXT iterations as well and
+// serialises memory latency with the MFMAs.  The kernels order DMA against LDS reads themselves (explicit
+// vmcnt + one barrier per K tile), so the DMA is kept opaque.  M0 carries the wave-uniform LDS destination.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+static __device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r = {(int)(unsigned)b, (int)((unsigned)(b >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    return r;
+}
+static __device__ __forceinline__ void dma16_to_lds(i32x4 rsrc, const unsigned char* lds_dst, int voffset, int soffset) {
+    const unsigned m0 = (unsigned)(__UINTPTR_TYPE__)LDS_PTR(lds_dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(m0), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+
+// wait until at most `tiles` of the most recently issued K tiles (LD DMA instructions each) are still in flight
+template <int LD>
+static __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+    switch (tiles) {
+        case 0: WAIT_VMCNT(0); break;
+        case 1: WAIT_VMCNT(LD); break;
+        case 2: WAIT_VMCNT(2 * LD); break;
+        case 3: WAIT_VMCNT(3 * LD); break;
+        default: WAIT_VMCNT(4 * LD); break;
+    }
+}
+
+template <int BCO, int BCI, int WI = 2, int WJ = 2, int STAGES = 3>
+__global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int FI = BCO / 64, FJ = BCI / 64;
+    constexpr int NW = WI * WJ;
+    constexpr int FI = BCO / (32 * WI), FJ = BCI / (32 * WJ);
+    static_assert(FI >= 1 && FJ >= 1, "wave grid too fine for the tile");
     constexpr int RA = BCO * 2, RB = BCI * 2;             // LDS row bytes (64 pixel rows per K tile)
     constexpr int TA = 64 * RA, TB = 64 * RB, TILE = TA + TB;
-    constexpr int LA = TA / 4096, LB = TB / 4096;         // LDS-DMA instructions per wave per tile
+    constexpr int LA = TA / (1024 * NW), LB = TB / (1024 * NW);   // LDS-DMA instructions per wave per tile
+    static_assert(LA >= 1 && LB >= 1, "too many waves for the tile");
     constexpr int LD = LA + LB;
-    constexpr int STAGES = 3;
+    static_assert(STAGES >= 3 && STAGES <= 6 && LD * (STAGES - 2) < 64, "vmcnt is 6 bits");
     __shared__ __attribute__((aligned(256))) unsigned char smem[STAGES * TILE];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wi = wave & 1, wj = wave >> 1;
+    const int wi = wave % WI, wj = wave / WI;
+    int bid = blockIdx.x, layer = 0;
+    while (layer + 1 < g.n && bid >= g.first[layer + 1]) ++layer;
+    bid -= g.first[layer];
+    const WgradArgs& a = g.a[layer];
     const int taps = a.KH * a.KW;
-    int bid = blockIdx.x;
     const int split = bid % a.splits; bid /= a.splits;
     const int tco = bid % a.tiles_co; bid /= a.tiles_co;
     const int tci = bid % a.tiles_ci;
@@ -527,10 +578,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     const int rb = lane / (RB / 16), pb = lane % (RB / 16);
     constexpr int OOB = (int)0x80000000;
     // buffer descriptors sized to the last valid byte: pixel rows >= M fall out of range -> zeros
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.dy, 0, (int)((((size_t)a.M - 1) * a.lddy + a.Cout) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.x, 0, (int)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2), 0x00020000);
+    const i32x4 rs_a = dma_rsrc(a.dy, (unsigned)((((size_t)a.M - 1) * a.lddy + a.Cout) * 2));
+    const i32x4 rs_b = dma_rsrc(a.x, (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2));
     auto swz = [](int row, int slot, int rowbytes) {
         int f = (rowbytes == 256) ? (row & 3) : ((row >> 1) & 1);
         return (((slot >> 2) ^ f) << 2) | (slot & 3);
@@ -538,13 +587,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     int avo[LA], brow[LB], bcolb[LB], bvo[LB];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        int row = (i * 4 + wave) * RPA + ra;
+        int row = (i * NW + wave) * RPA + ra;
         int col = co0 + swz(row, pa, RA) * 8;
         avo[i] = (col < a.Cout) ? ((row * a.lddy + col) * 2) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        brow[i] = (i * 4 + wave) * RPB + rb;
+        brow[i] = (i * NW + wave) * RPB + rb;
         int col = ci0 + swz(brow[i], pb, RB) * 8;
         bcolb[i] = (col < a.Cin) ? col * 2 : OOB;
         bvo[i] = (col < a.Cin) ? ((brow[i] * a.ldx + col) * 2) : OOB;
@@ -555,13 +604,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
         const int so_a = mb * a.lddy * 2;
 #pragma unroll
         for (int i = 0; i < LA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(ab + i * 4096), 16, avo[i], so_a, 0, 0);
+            dma16_to_lds(rs_a, ab + i * 1024 * NW, avo[i], so_a);
         unsigned char* bb = ab + TA;
         if (pointwise) {
             const int so_b = mb * a.ldx * 2;
 #pragma unroll
             for (int i = 0; i < LB; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bb + i * 4096), 16, bvo[i], so_b, 0, 0);
+                dma16_to_lds(rs_b, bb + i * 1024 * NW, bvo[i], so_b);
         } else {
 #pragma unroll
             for (int i = 0; i < LB; ++i) {
@@ -574,7 +623,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
                 int hi = ho * a.stride - a.pad + kh * a.dil, wi2 = wo * a.stride - a.pad + kw * a.dil;
                 bool ok = (m < a.M) && (bcolb[i] != OOB) && hi >= 0 && hi < a.H && wi2 >= 0 && wi2 < a.W;
                 int vo = ok ? (((n * a.H + hi) * a.W + wi2) * a.ldx * 2 + bcolb[i]) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bb + i * 4096), 16, vo, 0, 0, 0);
+                dma16_to_lds(rs_b, bb + i * 1024 * NW, vo, 0);
             }
         }
     };
@@ -587,18 +636,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
+    if (a.dbg) tq0 = __builtin_readcyclecounter();
     if (kt_beg < kt_end) {
-        issue(kt_beg, 0);
-        if (kt_beg + 1 < kt_end) issue(kt_beg + 1, 1);
+        // the operands stream from HBM / the Infinity Cache (~2300 cycles away): STAGES - 1 tiles stay in flight
+#pragma unroll
+        for (int s0 = 0; s0 < STAGES - 1; ++s0)
+            if (kt_beg + s0 < kt_end) issue(kt_beg + s0, s0);
         // transposing-read lane geometry: 16-lane group g reads a [4 k][16 col] block
         const int g = lane >> 4, la = lane & 15;
         const int krow = (g >> 1) * 8 + (la >> 2);          // + kk*16 (+4 for the second half)
         const int kcol2 = ((g & 1) * 16 + (la & 3) * 4) * 2;  // byte offset inside a 64-byte granule pair
         int stage = 0;
         for (int kt = kt_beg; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end) WAIT_VMCNT(LD); else WAIT_VMCNT(0);
+            wait_tiles_in_flight<LD>(min(STAGES - 2, kt_end - 1 - kt));
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < kt_end) issue(kt + 2, stage >= 1 ? stage - 1 : STAGES - 1);
+            if (a.dbg && kt == kt_beg) tq1 = __builtin_readcyclecounter();
+            if (kt + STAGES - 1 < kt_end) issue(kt + STAGES - 1, stage >= 1 ? stage - 1 : STAGES - 1);
             const unsigned char* ab = smem + stage * TILE;
             const unsigned char* bb = ab + TA;
 #pragma unroll
@@ -607,7 +661,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
                 const int r0 = kk * 16 + krow, r1 = r0 + 4;
 #pragma unroll
                 for (int i = 0; i < FI; ++i) {
-                    int byte = (wi * (BCO / 2) + i * 32) * 2 + kcol2;           // column byte offset in the row
+                    int byte = (wi * (BCO / WI) + i * 32) * 2 + kcol2;          // column byte offset in the row
                     int f0 = (RA == 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (RA == 256) ? (r1 & 3) : ((r1 >> 1) & 1);
                     const unsigned char* p0 = ab + r0 * RA + ((((byte >> 6) ^ f0) << 6) | (byte & 63));
                     const unsigned char* p1 = ab + r1 * RA + ((((byte >> 6) ^ f1) << 6) | (byte & 63));
@@ -619,7 +673,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
-                    int byte = (wj * (BCI / 2) + j * 32) * 2 + kcol2;
+                    int byte = (wj * (BCI / WJ) + j * 32) * 2 + kcol2;
                     int f0 = (RB == 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (RB == 256) ? (r1 & 3) : ((r1 >> 1) & 1);
                     const unsigned char* p0 = bb + r0 * RB + ((((byte >> 6) ^ f0) << 6) | (byte & 63));
                     const unsigned char* p1 = bb + r1 * RB + ((((byte >> 6) ^ f1) << 6) | (byte & 63));
@@ -638,20 +692,38 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
             stage = (stage == STAGES - 1) ? 0 : stage + 1;
         }
     }
-    // ---- split-K reduction: fp32 atomics straight into the gradient buffer (128 B per half-wave)
+    // ---- split-K reduction: fp32 atomics straight into the gradient buffer (128 B per half-wave).
+    // 32-bit element offsets off one base (a layer's dW is far below 2^31 elements): no 64-bit multiplies here.
+    if (a.dbg) tq2 = __builtin_readcyclecounter();
     const int lcol = lane & 31, lk = lane >> 5;
+    const unsigned rs = (unsigned)(taps * a.Cin);
+    const bool full = (co0 + BCO <= a.Cout) && (ci0 + BCI <= a.Cin);
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
-            int ci = ci0 + wj * (BCI / 2) + j * 32 + lcol;
-            if (ci >= a.Cin) continue;
+            const int cob = co0 + wi * (BCO / WI) + i * 32 + 4 * lk;
+            const int ci = ci0 + wj * (BCI / WJ) + j * 32 + lcol;
+            unsigned o = (unsigned)cob * rs + (unsigned)(tap * a.Cin + ci);
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int co = co0 + wi * (BCO / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * taps + tap) * a.Cin + ci, acc[i][j][r]);
+                for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) atomicAdd(a.dw + (o + q * rs), acc[i][j][g4 * 4 + q]);
+                    o += 8 * rs;
+                }
+            } else if (ci < a.Cin) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co = cob + (r & 3) + 8 * (r >> 2);
+                    if (co < a.Cout) atomicAdd(a.dw + (o + (unsigned)((r & 3) + 8 * (r >> 2)) * rs), acc[i][j][r]);
+                }
             }
         }
+    if (a.dbg && t == 0) {
+        a.dbg[blockIdx.x * 4 + 0] = tq0; a.dbg[blockIdx.x * 4 + 1] = tq1;
+        a.dbg[blockIdx.x * 4 + 2] = tq2; a.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+    }
 #endif
 }
 
@@ -663,7 +735,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 //   from L2 (the generic kernel: 64), and the dY tile is read once instead of nine times.
 // ======================================================================================
 template <int WT, int D>
-__global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradGroup g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int R = 64 / WT;                       // image rows per K tile
     constexpr int HR = R + 2 * D, HC = WT + 2 * D;   // halo tile (pixels)
@@ -677,7 +749,10 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wi = wave & 1, wj = wave >> 1;
-    int bid = blockIdx.x;
+    int bid = blockIdx.x, layer = 0;
+    while (layer + 1 < g.n && bid >= g.first[layer + 1]) ++layer;
+    bid -= g.first[layer];
+    const WgradArgs& a = g.a[layer];
     const int split = bid % a.splits; bid /= a.splits;
     const int tco = bid % a.tiles_co;
     const int tci = bid / a.tiles_co;
@@ -686,10 +761,8 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradArgs a) {
     const int KT = a.N * tpi;
     const int kt_beg = split * a.kt_per_split, kt_end = min(kt_beg + a.kt_per_split, KT);
     constexpr int OOB = (int)0x80000000;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.dy, 0, (int)((((size_t)a.M - 1) * a.lddy + a.Cout) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.x, 0, (int)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2), 0x00020000);
+    const i32x4 rs_a = dma_rsrc(a.dy, (unsigned)((((size_t)a.M - 1) * a.lddy + a.Cout) * 2));
+    const i32x4 rs_b = dma_rsrc(a.x, (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2));
 
     // lane geometry of a DMA instruction: 8 rows x 8 slots of 16 B; 128-byte rows, granule swizzle (row>>1)&1
     const int lr = lane >> 3, ls = lane & 7;
@@ -718,14 +791,14 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradArgs a) {
         const int so_a = ((n * a.H + y0) * a.W + x0) * a.lddy * 2;
 #pragma unroll
         for (int i = 0; i < LA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(ab + i * 4096), 16, avo[i], so_a, 0, 0);
+            dma16_to_lds(rs_a, ab + i * 4096, avo[i], so_a);
         unsigned char* bb = ab + TA;
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             int y = y0 + bhr[i], x = x0 + bhc[i];
             bool ok = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
             int vo = ok ? (((n * a.H + y) * a.W + x) * a.ldx * 2 + bcol[i]) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bb + i * 4096), 16, vo, 0, 0, 0);
+            dma16_to_lds(rs_b, bb + i * 4096, vo, 0);
         }
     };
 
@@ -791,23 +864,6 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradArgs a) {
 #endif
 }
 
-template <int WT, int D>
-static void launch_wgrad3x3(WgradArgs& a, hipStream_t st) {
-    constexpr int R = 64 / WT;
-    a.tiles_co = cdiv(a.Cout, 64);
-    a.tiles_ci = cdiv(a.Cin, 64);
-    int tiles = a.tiles_co * a.tiles_ci;
-    int KT = a.N * (a.H / R) * (a.W / WT);
-    // every split adds 147 KB of fp32 atomics (9 x 64 x 64 results): ~256 workgroups, >= 16 K tiles each
-    int splits = cdiv(256, tiles);
-    if (splits > KT / 16) splits = KT / 16;
-    if (splits < 1) splits = 1;
-    if (const char* e = getenv("RGDA_WGRAD_SPLITS")) splits = atoi(e);
-    a.kt_per_split = cdiv(KT, splits);
-    a.splits = cdiv(KT, a.kt_per_split);
-    conv_wgrad3x3_kernel<WT, D><<<tiles * a.splits, 256, 0, st>>>(a);
-}
-
 static int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;
@@ -815,58 +871,127 @@ static int ilog2_exact(int v) {
     return s;
 }
 
+// kernel families: 0..3 generic <128,128> <128,64> <64,128> <64,64>; 4..9 tap-fused 3x3 <WT,D>
+enum { WK_G128_128 = 0, WK_G128_64, WK_G64_128, WK_G64_64, WK_F64_1, WK_F64_2, WK_F32_1, WK_F32_2, WK_F16_1, WK_F16_2, WK_COUNT };
+
+static int wgrad_prepare(const rgda_wgrad_desc& d, WgradArgs& a) {
+    if (!d.x || !d.dy || !d.dw) return RGDA_ERR_ARG;
+    if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Ho <= 0 || d.Wo <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.kh <= 0 || d.kw <= 0 ||
+        d.stride <= 0 || d.dil <= 0 || d.pad < 0)
+        return RGDA_ERR_ARG;
+    if ((d.Cin & 7) || (d.Cout & 7) || (d.ldx & 7) || (d.lddy & 7) || d.ldx < d.Cin || d.lddy < d.Cout) return RGDA_ERR_ARG;
+    a.x = (const bf16_t*)d.x; a.dy = (const bf16_t*)d.dy; a.dw = d.dw; a.ldx = d.ldx; a.lddy = d.lddy;
+    a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout; a.KH = d.kh; a.KW = d.kw;
+    a.stride = d.stride; a.pad = d.pad; a.dil = d.dil;
+    long long M = (long long)d.N * d.Ho * d.Wo;
+    if (M > 0x7fffffffLL - 64) return RGDA_ERR_ARG;
+    a.M = (int)M;
+    a.howo_shift = ilog2_exact(d.Ho * d.Wo);
+    a.wo_shift = ilog2_exact(d.Wo);
+    a.dbg = nullptr;
+    if (const char* e = getenv("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
+    a.splits = 1; a.kt_per_split = 0;
+    // tap-fused path: 3x3, stride 1, "same" padding, the map tiles into 64-pixel row blocks
+    a.tap_fused = 0;
+    if (d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == d.dil && d.Ho == d.H && d.Wo == d.W &&
+        cdiv(d.Cout, 64) * cdiv(d.Cin, 64) >= 8 && !getenv("RGDA_WGRAD_GENERIC")) {
+        int wt = (d.W >= 64) ? 64 : d.W;
+        if ((wt == 64 || wt == 32 || wt == 16) && (d.W % wt) == 0 && (d.H % (64 / wt)) == 0 && (d.dil == 1 || d.dil == 2)) {
+            a.tap_fused = 1;
+            a.tiles_co = cdiv(d.Cout, 64);
+            a.tiles_ci = cdiv(d.Cin, 64);
+            return (wt == 64 ? WK_F64_1 : wt == 32 ? WK_F32_1 : WK_F16_1) + (d.dil == 2 ? 1 : 0);
+        }
+    }
+    int bco = (d.Cout <= 64) ? 64 : 128, bci = (d.Cin <= 64) ? 64 : 128;
+    a.tiles_co = cdiv(d.Cout, bco);
+    a.tiles_ci = cdiv(d.Cin, bci);
+    return (bco == 128) ? (bci == 128 ? WK_G128_128 : WK_G128_64) : (bci == 128 ? WK_G64_128 : WK_G64_64);
+}
+
+static inline int wgrad_tiles(const WgradArgs& a) {
+    return a.tiles_co * a.tiles_ci * (a.tap_fused ? 1 : a.KH * a.KW);
+}
+static inline int wgrad_ktiles(const WgradArgs& a) {
+    if (!a.tap_fused) return cdiv(a.M, 64);
+    int wt = (a.W >= 64) ? 64 : a.W;
+    return a.N * (a.H / (64 / wt)) * (a.W / wt);
+}
+
+// one launch for the layers g.a[0..n): split K just enough that the launch has >= ~2 workgroups per CU (generic)
+// or ~1 (tap-fused: 147 KB of atomics per split), never fewer than 16 K tiles per split
+static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
+    int total = 0;
+    for (int l = 0; l < g.n; ++l) total += wgrad_tiles(g.a[l]);
+    const int target = (kind >= WK_F64_1) ? 256 : 512;
+    int minkt = 16;
+    if (const char* e = getenv("RGDA_WGRAD_MINKT")) minkt = atoi(e);                     // tuning experiments only
+    int items = 0;
+    for (int l = 0; l < g.n; ++l) {
+        WgradArgs& a = g.a[l];
+        const int KT = wgrad_ktiles(a);
+        int splits = cdiv(target, total);
+        if (splits > KT / minkt) splits = KT / minkt;
+        if (splits < 1) splits = 1;
+        if (const char* e = getenv("RGDA_WGRAD_SPLITS")) splits = atoi(e);               // tuning experiments only
+        a.kt_per_split = cdiv(KT, splits);
+        a.splits = cdiv(KT, a.kt_per_split);
+        g.first[l] = items;
+        items += wgrad_tiles(a) * a.splits;
+    }
+    for (int l = g.n; l <= RGDA_WGRAD_MAXG; ++l) g.first[l] = items;
+    switch (kind) {
+        case WK_G128_128: conv_wgrad_kernel<128, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
+        case WK_G128_64: conv_wgrad_kernel<128, 64, 4, 2><<<items, 512, 0, st>>>(g); break;
+        case WK_G64_128: conv_wgrad_kernel<64, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
+        case WK_G64_64: conv_wgrad_kernel<64, 64><<<items, 256, 0, st>>>(g); break;
+        case WK_F64_1: conv_wgrad3x3_kernel<64, 1><<<items, 256, 0, st>>>(g); break;
+        case WK_F64_2: conv_wgrad3x3_kernel<64, 2><<<items, 256, 0, st>>>(g); break;
+        case WK_F32_1: conv_wgrad3x3_kernel<32, 1><<<items, 256, 0, st>>>(g); break;
+        case WK_F32_2: conv_wgrad3x3_kernel<32, 2><<<items, 256, 0, st>>>(g); break;
+        case WK_F16_1: conv_wgrad3x3_kernel<16, 1><<<items, 256, 0, st>>>(g); break;
+        default: conv_wgrad3x3_kernel<16, 2><<<items, 256, 0, st>>>(g); break;
+    }
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+extern "C" int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, rgda_stream_t stream) {
+    if (n < 0 || (n > 0 && !descs)) return RGDA_ERR_ARG;
+    hipStream_t st = to_stream(stream);
+    static thread_local WgradGroup groups[WK_COUNT];
+    for (int k = 0; k < WK_COUNT; ++k) groups[k].n = 0;
+    // validate everything first: nothing is launched for a list with a bad entry
+    for (int i = 0; i < n; ++i) {
+        WgradArgs a;
+        int kind = wgrad_prepare(descs[i], a);
+        if (kind < 0) return kind;
+    }
+    for (int i = 0; i < n; ++i) {
+        WgradArgs a;
+        int kind = wgrad_prepare(descs[i], a);
+        WgradGroup& g = groups[kind];
+        g.a[g.n++] = a;
+        if (g.n == RGDA_WGRAD_MAXG) {
+            int rc = wgrad_launch(kind, g, st);
+            if (rc != RGDA_OK) return rc;
+            g.n = 0;
+        }
+    }
+    for (int k = 0; k < WK_COUNT; ++k)
+        if (groups[k].n) {
+            int rc = wgrad_launch(k, groups[k], st);
+            if (rc != RGDA_OK) return rc;
+        }
+    return RGDA_OK;
+}
+
 extern "C" int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int N, int H, int W,
                                  int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
                                  rgda_stream_t stream) {
-    if (!x || !dy || !dw) return RGDA_ERR_ARG;
-    if (N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 ||
-        stride <= 0 || dil <= 0 || pad < 0)
-        return RGDA_ERR_ARG;
-    if ((Cin & 7) || (Cout & 7) || (ldx & 7) || (lddy & 7) || ldx < Cin || lddy < Cout) return RGDA_ERR_ARG;
-    WgradArgs a;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw; a.ldx = ldx; a.lddy = lddy;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = kh; a.KW = kw;
-    a.stride = stride; a.pad = pad; a.dil = dil;
-    long long M = (long long)N * Ho * Wo;
-    if (M > 0x7fffffffLL - 64) return RGDA_ERR_ARG;
-    a.M = (int)M;
-    a.howo_shift = ilog2_exact(Ho * Wo);
-    a.wo_shift = ilog2_exact(Wo);
-    hipStream_t st0 = to_stream(stream);
-    // tap-fused path: 3x3, stride 1, "same" padding, the map tiles into 64-pixel row blocks
-    if (kh == 3 && kw == 3 && stride == 1 && pad == dil && Ho == H && Wo == W && cdiv(Cout, 64) * cdiv(Cin, 64) >= 8 &&
-        !getenv("RGDA_WGRAD_GENERIC")) {
-        int wt = (W >= 64) ? 64 : W;
-        if ((wt == 64 || wt == 32 || wt == 16) && (W % wt) == 0 && (H % (64 / wt)) == 0 && (dil == 1 || dil == 2)) {
-            if (wt == 64 && dil == 1) launch_wgrad3x3<64, 1>(a, st0);
-            else if (wt == 64) launch_wgrad3x3<64, 2>(a, st0);
-            else if (wt == 32 && dil == 1) launch_wgrad3x3<32, 1>(a, st0);
-            else if (wt == 32) launch_wgrad3x3<32, 2>(a, st0);
-            else if (dil == 1) launch_wgrad3x3<16, 1>(a, st0);
-            else launch_wgrad3x3<16, 2>(a, st0);
-            RGDA_CHECK_LAUNCH();
-            return RGDA_OK;
-        }
-    }
-    int bco = (Cout <= 64) ? 64 : 128, bci = (Cin <= 64) ? 64 : 128;
-    a.tiles_co = cdiv(Cout, bco);
-    a.tiles_ci = cdiv(Cin, bci);
-    int tiles = a.tiles_co * a.tiles_ci * kh * kw;
-    // split-K over the pixel dimension: ~512 workgroups, but never fewer than 16 K tiles per split (the
-    // 3-stage pipeline fill/drain and the fp32 atomics of the 64 KiB result tile must be amortised)
-    int KT = cdiv(M, 64);
-    int splits = cdiv(512, tiles);
-    if (splits > KT / 16) splits = KT / 16;
-    if (splits < 1) splits = 1;
-    if (const char* e = getenv("RGDA_WGRAD_SPLITS")) splits = atoi(e);                   // tuning experiments only
-    a.kt_per_split = cdiv(KT, splits);
-    a.splits = cdiv(KT, a.kt_per_split);
-    int grid = tiles * a.splits;
-    hipStream_t st = to_stream(stream);
-    if (bco == 128 && bci == 128) conv_wgrad_kernel<128, 128><<<grid, 256, 0, st>>>(a);
-    else if (bco == 128 && bci == 64) conv_wgrad_kernel<128, 64><<<grid, 256, 0, st>>>(a);
-    else if (bco == 64 && bci == 128) conv_wgrad_kernel<64, 128><<<grid, 256, 0, st>>>(a);
-    else conv_wgrad_kernel<64, 64><<<grid, 256, 0, st>>>(a);
-    RGDA_CHECK_LAUNCH();
-    return RGDA_OK;
+    rgda_wgrad_desc d;
+    d.x = x; d.dy = dy; d.dw = dw; d.ldx = ldx; d.lddy = lddy;
+    d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Ho = Ho; d.Wo = Wo; d.Cout = Cout; d.kh = kh; d.kw = kw;
+    d.stride = stride; d.pad = pad; d.dil = dil;
+    return rgda_conv2d_wgrad_grouped(&d, 1, stream);
 }

@@ -3,6 +3,7 @@
 // and the 6-class classifier.  Every thread owns one 16-byte channel vector (8 bf16) and walks
 // rows, so global accesses are 16 B per lane and row-contiguous; per-channel parameters live in
 // registers; reductions are wave shuffle -> LDS -> one atomic per channel per workgroup.
+#include <stdlib.h>
 #include "common.h"
 
 // thread layout shared by the per-channel passes: VPB channel-vectors per block (<= 256),
@@ -39,6 +40,13 @@ static __device__ __forceinline__ void load8(const bf16_t* p, float (&f)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] = bf2f(v[e]);
 }
+static __device__ __forceinline__ void cvt8(const u16x8& v, float (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = bf2f(v[e]);
+}
+// rows handled per thread per batch in the streaming kernels: all loads of a batch are issued before the first
+// use, so every wave keeps 4 (x up to 3 operands) 16-byte loads in flight
+#define ROW_BATCH 4
 static __device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
     uint4 v;
     v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
@@ -236,27 +244,41 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
     }
     long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
-    for (long long r = r0 + rl; r < r1; r += rpb) {
-        float f[8];
-        load8(x + r * ldx + cg, f);
+    for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
+        u16x8 xv[ROW_BATCH], rv[ROW_BATCH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean[e]) * sc[e] + sh[e];
-        if (res) {
-            float g[8];
-            load8(res + r * ldres + cg, g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += g[e];
+        for (int u = 0; u < ROW_BATCH; ++u) {
+            const long long r = rb + (long long)u * rpb;
+            if (r < r1) {
+                xv[u] = *(const u16x8*)(x + r * ldx + cg);
+                if (res) rv[u] = *(const u16x8*)(res + r * ldres + cg);
+            }
         }
-        if (relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-        }
-        if (nscale) {
-            const float* ns = nscale + (r / rpi) * C + cg;
+        for (int u = 0; u < ROW_BATCH; ++u) {
+            const long long r = rb + (long long)u * rpb;
+            if (r >= r1) break;
+            float f[8];
+            cvt8(xv[u], f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] *= ns[e];
+            for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean[e]) * sc[e] + sh[e];
+            if (res) {
+                float g[8];
+                cvt8(rv[u], g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += g[e];
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+            }
+            if (nscale) {
+                const float* ns = nscale + (r / rpi) * C + cg;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] *= ns[e];
+            }
+            store8(y + r * ldy + cg, f);
         }
-        store8(y + r * ldy + cg, f);
     }
 }
 
@@ -264,6 +286,14 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
 static void elementwise_grid(long long M, int C, int groups, RowLayout& L, int& rows_per_block, int& bpg, dim3& grid,
                              int rows_mult = 8) {
     L = row_layout(C);
+    // small maps (<= 16M elements per launch): at most 128 channels per workgroup -- every workgroup first rebuilds
+    // (or loads) the statistics of its channels, 16 floats each, which must stay small next to the rows it streams
+    if ((long long)M * groups * C <= (1ll << 24) && L.vpb > 16) { L.vpb = 16; L.rpb = 16; }
+    if (const char* e = getenv("RGDA_BN_VPB")) {                  // tuning experiments only
+        int v = atoi(e);
+        if (v < L.vpb) { L.vpb = v; L.rpb = 256 / v; }
+    }
+    if (const char* e = getenv("RGDA_BN_ROWS")) rows_mult = atoi(e);   // tuning experiments only
     rows_per_block = L.rpb * rows_mult;
     while ((long long)cdiv(M, rows_per_block) * groups * cdiv(L.vpr, L.vpb) > 8192) rows_per_block *= 2;
     bpg = cdiv(M, rows_per_block);
@@ -330,23 +360,38 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
         for (int e = 0; e < 8; ++e) { mean[e] = mi[cg + e]; istd[e] = mi[C + cg + e]; }
         long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
         long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
-        for (long long r = r0 + rl; r < r1; r += rpb) {
-            float gf[8], xf[8];
-            load8(g + r * ldg + cg, gf);
-            load8(x + r * ldx + cg, xf);
-            if (relu) {
-                float yf[8];
-                load8(y + r * ldy + cg, yf);
+        for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
+            u16x8 gv[ROW_BATCH], xv[ROW_BATCH], yv[ROW_BATCH];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
-            }
-            if (nscale) {
-                const float* ns = nscale + (r / rpi) * C + cg;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
+            for (int u = 0; u < ROW_BATCH; ++u) {
+                const long long r = rb + (long long)u * rpb;
+                if (r < r1) {
+                    gv[u] = *(const u16x8*)(g + r * ldg + cg);
+                    xv[u] = *(const u16x8*)(x + r * ldx + cg);
+                    if (relu) yv[u] = *(const u16x8*)(y + r * ldy + cg);
+                }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += gf[e]; q[e] += gf[e] * ((xf[e] - mean[e]) * istd[e]); }
+            for (int u = 0; u < ROW_BATCH; ++u) {
+                const long long r = rb + (long long)u * rpb;
+                if (r >= r1) break;
+                float gf[8], xf[8];
+                cvt8(gv[u], gf);
+                cvt8(xv[u], xf);
+                if (relu) {
+                    float yf[8];
+                    cvt8(yv[u], yf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+                }
+                if (nscale) {
+                    const float* ns = nscale + (r / rpi) * C + cg;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += gf[e]; q[e] += gf[e] * ((xf[e] - mean[e]) * istd[e]); }
+            }
         }
     }
     float* rep = sums + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NREP - 1)) * 2 * C;
@@ -411,26 +456,41 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     for (int e = 0; e < 8; ++e) { k1[e] *= invM; k2[e] *= invM; }
     long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
-    for (long long r = r0 + rl; r < r1; r += rpb) {
-        float gf[8], xf[8];
-        load8(g + r * ldg + cg, gf);
-        load8(x + r * ldx + cg, xf);
-        if (relu) {
-            float yf[8];
-            load8(y + r * ldy + cg, yf);
+    for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
+        u16x8 gv[ROW_BATCH], xv[ROW_BATCH], yv[ROW_BATCH];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+        for (int u = 0; u < ROW_BATCH; ++u) {
+            const long long r = rb + (long long)u * rpb;
+            if (r < r1) {
+                gv[u] = *(const u16x8*)(g + r * ldg + cg);
+                xv[u] = *(const u16x8*)(x + r * ldx + cg);
+                if (relu) yv[u] = *(const u16x8*)(y + r * ldy + cg);
+            }
         }
-        if (nscale) {
-            const float* ns = nscale + (r / rpi) * C + cg;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
+        for (int u = 0; u < ROW_BATCH; ++u) {
+            const long long r = rb + (long long)u * rpb;
+            if (r >= r1) break;
+            float gf[8], xf[8];
+            cvt8(gv[u], gf);
+            cvt8(xv[u], xf);
+            if (relu) {
+                float yf[8];
+                cvt8(yv[u], yf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+            }
+            if (nscale) {
+                const float* ns = nscale + (r / rpi) * C + cg;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
+            }
+            if (gmask) store8(gmask + r * ldgm + cg, gf);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = k0[e] * (gf[e] - k1[e] - (xf[e] - mean[e]) * istd[e] * k2[e]);
+            store8(dx + r * lddx + cg, o);
         }
-        if (gmask) store8(gmask + r * ldgm + cg, gf);
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = k0[e] * (gf[e] - k1[e] - (xf[e] - mean[e]) * istd[e] * k2[e]);
-        store8(dx + r * lddx + cg, o);
     }
 }
 

@@ -150,6 +150,9 @@ class Deeplabv2(nn.Module):
         self._anchor = torch.zeros(1, device=self.device, requires_grad=True)   # routes autograd into backward()
         self._drop_override = None
         self.fuse_bn_bwd = True      # fold BN-backward reductions into the producing data-gradient conv
+        # weight gradients are collected and launched in groups (rgda_conv2d_wgrad_grouped) once this much work
+        # is pending; 0 = one launch per layer
+        self.wgrad_group_gflop = 250.0
         self._mat_cache = {}
         self._synced_version = -1
         self.sync_weights()
@@ -419,6 +422,37 @@ class Deeplabv2(nn.Module):
             T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale)
         return y, Ho, Wo
 
+    def _flush_wgrads(self, T):
+        """Launch the queued weight gradients (grouped by kernel) -- on the second HIP stream when there is one,
+        next to the BN-backward / data-gradient chain of the layers below, which is the critical path -- and
+        release the all-reduce progress mark that was waiting for them."""
+        pend = T['wgrad_pending']
+        if pend:
+            side = T.get('wgrad_stream')
+            if side is None:
+                ops.conv2d_wgrad_grouped(pend)
+            else:
+                side.wait_event(T['main_stream'].record_event())
+                with ops.use_stream(side):
+                    ops.conv2d_wgrad_grouped(pend)
+                # keep the operands alive until the streams join (no record_stream: the step must stay
+                # capturable into a hipGraph)
+                T['keep'].extend((it[0], it[1]) for it in pend)
+            T['wgrad_pending'] = []
+            T['wgrad_pending_flop'] = 0.0
+        off = T.pop('progress_deferred', None)
+        if off is not None:
+            T['on_progress'](off)
+
+    def _progress(self, T, offset):
+        """All gradients of the parameters at flat offsets >= `offset` have been produced or queued."""
+        if T.get('on_progress') is None:
+            return
+        if T['wgrad_pending']:
+            T['progress_deferred'] = offset       # released by the flush that launches the queued layers
+        else:
+            T['on_progress'](offset)
+
     def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False,
                  consumer=None):
         """Backward of one conv+BN(+ReLU) unit.  `consumer` = (tape key, relu) of the unit that will consume this
@@ -440,17 +474,11 @@ class Deeplabv2(nn.Module):
             ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
             ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
             return None, gm
-        side = T.get('wgrad_stream')
-        if side is None:
-            ops.conv2d_wgrad(x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil)
-        else:
-            # weight gradients are only needed by the optimizer: they run on a second HIP stream, next to the
-            # BN-backward / data-gradient chain of the layers below (which is what the critical path is)
-            side.wait_event(T['main_stream'].record_event())
-            with ops.use_stream(side):
-                ops.conv2d_wgrad(x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil)
-            T['keep'].append((dc, x))        # keep the operands alive until the streams join (no record_stream:
-                                             # the step must stay capturable into a hipGraph)
+        # weight gradients are only needed by the optimizer: they are queued, and launched in groups
+        T['wgrad_pending'].append((x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil))
+        T['wgrad_pending_flop'] += 2.0 * M * conv.co * conv.ci * conv.k * conv.k
+        if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
+            self._flush_wgrads(T)
         dx = None
         if need_dx:
             dx = torch.empty(N * H * W, conv.ci, dtype=BF, device=self.device)
@@ -558,6 +586,8 @@ class Deeplabv2(nn.Module):
     # ------------------------------------------------------------------ backward plan
     def _backward_plan(self, T, g1, g2, on_progress=None):
         dev = self.device
+        T['on_progress'] = on_progress
+        T['wgrad_pending'], T['wgrad_pending_flop'] = [], 0.0
         T['sums_pool'] = _StatsPool(sum(T['groups'] * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)
         C, B = self.convs, self.bns
         y4, imi, (N, h, w) = T['inorm']
@@ -592,8 +622,7 @@ class Deeplabv2(nn.Module):
         g = torch.empty(M, 2048, dtype=BF, device=dev)
         ops.instnorm_bwd(dcats[0][:, :2048], dcats[1][:, :2048], gpool, y4, imi, g, N, HW, 2048)
         del dcats, gpool
-        if on_progress is not None:
-            on_progress(self._offset_of('layer5.ppm.0.1'))
+        self._progress(T, self._offset_of('layer5.ppm.0.1'))
         hh, ww = h, w
         order = [b[0] for b in self.blocks]
         for bi in range(len(self.blocks) - 1, -1, -1):
@@ -611,12 +640,14 @@ class Deeplabv2(nn.Module):
                 g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=dxd, consumer=below)
             else:
                 g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm, consumer=below)
-            if on_progress is not None:
-                on_progress(self._offset_of(p + '.conv1'))
+            self._progress(T, self._offset_of(p + '.conv1'))
         idx, (N, H1, W1, H2, W2) = T['pool']
         ga0 = torch.empty(N * H1 * W1, 64, dtype=BF, device=dev)
         ops.maxpool_bwd(g, idx, ga0, N, H1, W1, 64, H2, W2)
         self._cbr_bwd(T, 'stem', C['encoder.resnet.conv1'], B['encoder.resnet.bn1'], ga0, True, stem=True)
+        self._flush_wgrads(T)
+        if T.get('mark') is not None:
+            T['mark']('backward main chain done')
         if T.get('wgrad_stream') is not None:
             T['main_stream'].wait_stream(T['wgrad_stream'])
 

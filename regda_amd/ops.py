@@ -4,6 +4,8 @@ Everything here takes/returns CUDA(ROCm) torch tensors, enqueues on
 `torch.cuda.current_stream()` and never synchronises.  PyTorch is plumbing
 (device memory + streams); the arithmetic is in librgda_hip.so.
 """
+import ctypes
+
 import torch
 
 from ._lib import lib
@@ -222,6 +224,27 @@ def conv2d_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
     assert dw.is_contiguous() and dw.dtype == torch.float32
     lib().call('rgda_conv2d_wgrad', x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dw.data_ptr(), N, H, W, Cin, Ho, Wo,
                Cout, kh, kw, stride, pad, dil, _stream())
+
+
+class _WgradDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('ldx', ctypes.c_int),
+                ('lddy', ctypes.c_int)] + [(k, ctypes.c_int) for k in
+                                           ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'kh', 'kw', 'stride', 'pad', 'dil')]
+
+
+def conv2d_wgrad_grouped(items):
+    """items: list of (x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil) -- the arguments of conv2d_wgrad.
+    Layers that map to the same kernel share a launch (rgda_conv2d_wgrad_grouped)."""
+    if not items:
+        return
+    arr = (_WgradDesc * len(items))()
+    for d, (x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil) in zip(arr, items):
+        Cout, taps, Cin = dw.shape
+        assert dw.is_contiguous() and dw.dtype == torch.float32 and taps == kh * kw
+        d.x, d.dy, d.dw, d.ldx, d.lddy = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ld(x), _ld(dy)
+        d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
+        d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
+    lib().call('rgda_conv2d_wgrad_grouped', ctypes.cast(arr, ctypes.c_void_p), len(items), _stream())
 
 
 def stem_im2col(img, col, N, H, W, Ho, Wo):

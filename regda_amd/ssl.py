@@ -43,6 +43,7 @@ class SSLStep:
         self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
         self._graph = None
+        self.marks = None           # set to [] to collect (name, event) phase marks of the next step (bench --phases)
         self.overlap_comm = overlap_comm
         self.world = self.reducer.world
         self.group = process_group
@@ -81,10 +82,17 @@ class SSLStep:
         self._graph.replay()
         return self._out
 
+    def _mark(self, name, stream=None):
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self.marks.append((name, ev))
+
     def _step(self, images_s, label_s, images_t, soft_t, regs_t):
         m = self.model
         if not m.training:
             m.train()
+        self._mark('step start')
         m._maybe_sync()
         m.flat_g.zero_()
         # source and target batch go through the network TOGETHER (twice the GEMM rows per launch), as two
@@ -99,13 +107,16 @@ class SSLStep:
             self.wgrad_stream.wait_stream(main)
             with ops.use_stream(self.wgrad_stream):
                 soft_t = self.teacher_probs(images_t)
+                self._mark('teacher forward done (side)', self.wgrad_stream)
         x1, x2, feat = m._forward_plan([images_s.contiguous().float(), images_t.contiguous().float()], T)
+        self._mark('student forward done')
         s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
         feat_s, feat_t = feat[:nb], feat[nb:]
         if teacher_on_side:
             main.wait_stream(self.wgrad_stream)
         elif soft_t is None:
             soft_t = self.teacher_probs(images_t)
+        self._mark('joined teacher')
         # ---- label path (a5-a8)
         if self.refine_label:
             soft, cm = ops.label_refine(feat_t, self.prototypes, t1, t2, soft_t, self.temp, return_ws=True)
@@ -127,10 +138,12 @@ class SSLStep:
         # ---- losses + d(loss)/d(logits)
         loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
         loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
+        self._mark('label path + losses done')
         # ---- backward (both domains in one pass); all-reduce buckets are released as it moves down the net
         self.reducer.reset()
         T['wgrad_stream'] = self.wgrad_stream
         T['main_stream'] = main
+        T['mark'] = self._mark if self.marks is not None else None
 
         def progress(offset):
             if (self.world > 1 or self.reducer.force) and self.overlap_comm:
@@ -144,6 +157,7 @@ class SSLStep:
                 else:
                     self.reducer.ready_down_to(offset)
         m._backward_plan(T, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]), on_progress=progress)
+        self._mark('backward done (streams joined)')
         self.reducer.finish()
         # ---- clip + SGD (+ EMA) in one pass over the flat buffers
         ops.sumsq(m.flat_g, self.gn, self.gn_ws)
@@ -153,6 +167,7 @@ class SSLStep:
         self.first = False
         m.sync_derived_weights()
         m._synced_version = m.flat_p._version
+        self._mark('optimizer + weight mirrors done')
         self.last_hard = hard
         return loss_s, loss_t, self.gn
 

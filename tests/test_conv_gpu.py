@@ -92,6 +92,44 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     assert relerr(dw.cpu(), dwr) < 2e-3, 'wgrad'
 
 
+def test_wgrad_grouped_matches_reference_and_single_launches(ops):
+    """rgda_conv2d_wgrad_grouped over a mixed list (every kernel family, 20 layers of one family so a group
+    overflows into a second launch, one layer listed twice = accumulated twice) against F.conv2d's weight
+    gradient, and against one rgda_conv2d_wgrad call per layer."""
+    g = torch.Generator().manual_seed(21)
+    layers = list(CASES) + [(2, 16, 16, 128, 256, 1, 1, 0, 1)] * 19
+    items, refs, singles = [], [], []
+    for (N, H, W, Cin, Cout, k, s, p, d) in layers:
+        Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
+        Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
+        x = rbf(torch.randn(N, Cin, H, W, generator=g))
+        dy = rbf(torch.randn(N, Cout, Ho, Wo, generator=g))
+        wr = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+        F.conv2d(x, wr, None, s, p, d).backward(dy)
+        refs.append(wr.grad.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin))
+        xg, dyg = to_pxc(x), to_pxc(dy)
+        dw = torch.zeros(Cout, k * k, Cin, device='cuda')
+        items.append((xg, dyg, dw, N, H, W, Ho, Wo, k, k, s, p, d))
+        one = torch.zeros(Cout, k * k, Cin, device='cuda')
+        ops.conv2d_wgrad(xg, dyg, one, N, H, W, Ho, Wo, k, k, s, p, d)
+        singles.append(one)
+    ops.conv2d_wgrad_grouped(items + [items[0]])
+    refs[0] = refs[0] * 2
+    singles[0] = singles[0] * 2
+    for i, (it, ref, one) in enumerate(zip(items, refs, singles)):
+        assert relerr(it[2].cpu(), ref) < 2e-3, (i, layers[i])
+        # same products, another split of the pixel sum: fp32 re-association only
+        assert relerr(it[2].cpu(), one.cpu()) < 1e-5, (i, layers[i])
+    ops.conv2d_wgrad_grouped([])
+    with pytest.raises(ValueError):     # a bad entry anywhere: nothing is launched
+        bad = list(items[1])
+        bad[3] = 0
+        before = items[2][2].clone()
+        ops.conv2d_wgrad_grouped([items[2], tuple(bad)])
+    torch.cuda.synchronize()
+    assert torch.equal(before, items[2][2])
+
+
 def test_conv_strided_views_and_row_tail(ops):
     """ld > C on both sides (channel-slice views of a concat buffer) and M not a tile multiple."""
     g = torch.Generator().manual_seed(4)

@@ -151,6 +151,7 @@ def test_layerwise_backward_consistency():
     m = build(rt)
     m.load_state_dict(omodel.init_state_dict(rt, 6, seed=2), strict=True)
     m.train()
+    m.wgrad_group_gflop = 0.0       # one weight-gradient launch per layer, so the spy sees each layer's dW at once
     rec = []
     orig = E.Deeplabv2._cbr_bwd
 

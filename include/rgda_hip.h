@@ -145,10 +145,12 @@ int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void* y, int ldy
 /* rgda_conv2d (normally the data-gradient, mode 1) with the BatchNorm-backward REDUCTION of the layer that consumes
  * its output fused into the epilogue: with g = the stored result (after the residual add),
  *   g' = g * [bn_y > 0 if relu] * nscale[n][c],  xhat = (bn_x - mean) * invstd  (mean/invstd from bn_mi[group]),
+ * ([bn_y > 0] is read from bn_relu_mask instead when that is given, see rgda_bn_train_apply)
  * sums[group][REPLICAS][2][Cout] += (sum g', sum g' * xhat) -- exactly what rgda_bn_bwd_reduce would compute
  * from the stored tensor, without re-reading it. */
 int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                      float* sums, int groups, const void* bn_y, int bn_ldy, const void* bn_x, int bn_ldx,
+                      float* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
+                      const void* bn_x, int bn_ldx,
                       const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N, int H,
                       int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
                       int mode, rgda_stream_t stream);
@@ -203,21 +205,24 @@ int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, c
                   const void* res, int ldres, const float* nscale, int rows_per_image, void* y,
                   int ldy, int64_t M, int C, int relu, int groups, rgda_stream_t stream);
 /* bn_finalize + bn_apply in one launch (the training forward): statistics -> (mean, invstd) -> y, `mi` and the
- * running statistics are written by one designated workgroup per channel block. */
+ * running statistics are written by one designated workgroup per channel block.
+ * relu_mask (optional, needs relu): uint8 [M][C/8], bit e of byte k = [y[row][8k+e] > 0] -- the only thing the
+ * backward pass needs from y; reading it instead of y saves 15/16 of that operand's HBM traffic there. */
 int rgda_bn_train_apply(const void* x, int ldx, const float* stats, float* mi, float* running_mean,
                         float* running_var, int64_t* num_batches_tracked, const float* gamma,
                         const float* beta, const void* res, int ldres, const float* nscale,
-                        int rows_per_image, void* y, int ldy, int64_t M, int C, int relu, int groups,
-                        float eps, float momentum, rgda_stream_t stream);
+                        int rows_per_image, void* y, int ldy, uint8_t* relu_mask, int64_t M, int C, int relu,
+                        int groups, float eps, float momentum, rgda_stream_t stream);
 /* sums f32[REPLICAS][2][C] must be ZERO on entry (the caller clears one arena per backward pass):
- * sums[0] += sum(g'), sums[1] += sum(g' * xhat), g' = g*[y>0]*nscale */
-int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
-                       const float* mi, const float* nscale, int rows_per_image, float* sums,
+ * sums[0] += sum(g'), sums[1] += sum(g' * xhat), g' = g*[y>0]*nscale.  With relu, [y>0] comes from relu_mask
+ * when given, else from y. */
+int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask, const void* x,
+                       int ldx, const float* mi, const float* nscale, int rows_per_image, float* sums,
                        int64_t M, int C, int relu, int groups, rgda_stream_t stream);
 /* dx = gamma*invstd*(g' - sum(g')/M - xhat*sum(g' xhat)/M); gmask (optional) = g';
  * dgamma += sum(g' xhat), dbeta += sum(g') (f32, accumulated) */
-int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
-                      const float* mi, const float* gamma, const float* nscale,
+int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask, const void* x,
+                      int ldx, const float* mi, const float* gamma, const float* nscale,
                       int rows_per_image, const float* sums, void* dx, int lddx, void* gmask,
                       int ldgm, float* dgamma, float* dbeta, int64_t M, int C, int relu, int groups,
                       rgda_stream_t stream);

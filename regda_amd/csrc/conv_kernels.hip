@@ -34,6 +34,7 @@ struct ConvArgs {
     // optional fused BatchNorm-backward reduction of the CONSUMER of this (data-gradient) output: with g = the stored
     // result, g' = g * [bn_y > 0] * nscale, xhat = (bn_x - mean) * invstd, `stats` receives sum(g'), sum(g' * xhat)
     const bf16_t* bn_y;
+    const unsigned char* bn_mask;   // [M][Cout/8] ReLU sign bits of bn_y (read instead of bn_y when given)
     const bf16_t* bn_x;
     const float* bn_mi;
     const float* bn_nscale;
@@ -302,9 +303,15 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gf[e] = bf2f(val[e]);
                 if (a.bn_relu) {
-                    u16x8 yv = *(const u16x8*)(a.bn_y + (size_t)m * a.bn_ldy + co);
+                    if (a.bn_mask) {
+                        const unsigned mb = a.bn_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gf[e] = (bf2f(yv[e]) > 0.f) ? gf[e] : 0.f;
+                        for (int e = 0; e < 8; ++e) gf[e] = ((mb >> e) & 1u) ? gf[e] : 0.f;
+                    } else {
+                        u16x8 yv = *(const u16x8*)(a.bn_y + (size_t)m * a.bn_ldy + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gf[e] = (bf2f(yv[e]) > 0.f) ? gf[e] : 0.f;
+                    }
                 }
                 if (a.bn_nscale) {
                     const float* ns = a.bn_nscale + (size_t)(m / a.bn_rpi) * a.Cout + co;
@@ -383,7 +390,7 @@ extern "C" int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, in
     return bc | (bp << 10) | (stages << 20);
 }
 
-struct BnBwdFuse { const void* y; int ldy; const void* x; int ldx; const float* mi; const float* nscale; int rpi; int relu; };
+struct BnBwdFuse { const void* y; int ldy; const unsigned char* mask; const void* x; int ldx; const float* mi; const float* nscale; int rpi; int relu; };
 struct BnEvalFuse { const float* rm; const float* rv; const float* gamma; const float* beta; float eps; int relu; };
 
 static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
@@ -409,11 +416,12 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
     if (stat_groups < 1) stat_groups = 1;
     if (M % stat_groups) return RGDA_ERR_ARG;
     a.rows_per_group = (int)(M / stat_groups);
-    a.bn_y = a.bn_x = nullptr; a.bn_mi = a.bn_nscale = nullptr; a.bn_ldy = a.bn_ldx = a.bn_rpi = a.bn_relu = 0;
+    a.bn_y = a.bn_x = nullptr; a.bn_mask = nullptr; a.bn_mi = a.bn_nscale = nullptr; a.bn_ldy = a.bn_ldx = a.bn_rpi = a.bn_relu = 0;
     if (bnb) {
-        if (!stats || !bnb->x || !bnb->mi || (bnb->relu && !bnb->y) || (bnb->ldx & 7) || (bnb->relu && (bnb->ldy & 7)) ||
-            (bnb->nscale && bnb->rpi <= 0))
+        if (!stats || !bnb->x || !bnb->mi || (bnb->relu && !bnb->y && !bnb->mask) || (bnb->ldx & 7) ||
+            (bnb->relu && bnb->y && (bnb->ldy & 7)) || (bnb->nscale && bnb->rpi <= 0))
             return RGDA_ERR_ARG;
+        a.bn_mask = bnb->relu ? bnb->mask : nullptr;
         a.bn_y = (const bf16_t*)bnb->y; a.bn_x = (const bf16_t*)bnb->x; a.bn_mi = bnb->mi; a.bn_nscale = bnb->nscale;
         a.bn_ldy = bnb->ldy; a.bn_ldx = bnb->ldx; a.bn_rpi = bnb->rpi; a.bn_relu = bnb->relu;
     }
@@ -468,11 +476,12 @@ extern "C" int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void*
 }
 
 extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                                 float* sums, int groups, const void* bn_y, int bn_ldy, const void* bn_x, int bn_ldx,
+                                 float* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
+                                 const void* bn_x, int bn_ldx,
                                  const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N,
                                  int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                                  int dil, int mode, rgda_stream_t stream) {
-    BnBwdFuse b = {bn_y, bn_ldy, bn_x, bn_ldx, bn_mi, bn_nscale, rows_per_image, relu};
+    BnBwdFuse b = {bn_y, bn_ldy, bn_relu_mask, bn_x, bn_ldx, bn_mi, bn_nscale, rows_per_image, relu};
     return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, sums, groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad,
                          dil, mode, &b, stream);
 }

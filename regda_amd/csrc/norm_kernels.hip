@@ -47,6 +47,12 @@ static __device__ __forceinline__ void cvt8(const u16x8& v, float (&f)[8]) {
 // rows handled per thread per batch in the streaming kernels: all loads of a batch are issued before the first
 // use, so every wave keeps 4 (x up to 3 operands) 16-byte loads in flight
 #define ROW_BATCH 4
+// sign mask of 8 packed bf16 values: bit e = [value e > 0]
+static __device__ __forceinline__ unsigned char relu_bits(const uint4& v) {
+    auto pos = [](unsigned h) { return (unsigned)((h & 0x7fffu) != 0 && (h & 0x8000u) == 0); };
+    return (unsigned char)(pos(v.x & 0xffffu) | pos(v.x >> 16) << 1 | pos(v.y & 0xffffu) << 2 | pos(v.y >> 16) << 3 |
+                           pos(v.z & 0xffffu) << 4 | pos(v.z >> 16) << 5 | pos(v.w & 0xffffu) << 6 | pos(v.w >> 16) << 7);
+}
 static __device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
     uint4 v;
     v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
@@ -176,7 +182,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ y, int ldy, long long M, int C, int relu,
                                                        int vpb, int rpb, int rows_per_block, int bpg,
                                                        const float* __restrict__ stats, float* mi_out, float* rm,
-                                                       float* rv, long long* nbt, int groups, float eps, float mom) {
+                                                       float* rv, long long* nbt, int groups, float eps, float mom,
+                                                       uint8_t* __restrict__ mask_out) {
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
     const int grp = blockIdx.x / bpg, chunk = blockIdx.x % bpg;     // M = rows of ONE group
@@ -277,7 +284,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] *= ns[e];
             }
-            store8(y + r * ldy + cg, f);
+            uint4 pk;
+            pk.x = pack2bf(f[0], f[1]); pk.y = pack2bf(f[2], f[3]); pk.z = pack2bf(f[4], f[5]); pk.w = pack2bf(f[6], f[7]);
+            *(uint4*)(y + r * ldy + cg) = pk;
+            if (mask_out) mask_out[r * (C >> 3) + (cg >> 3)] = relu_bits(pk);
         }
     }
 }
@@ -312,7 +322,7 @@ extern "C" int rgda_bn_apply(const void* x, int ldx, const float* mi, const floa
     bn_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, mi, gamma, beta, (const bf16_t*)res,
                                                           ldres, nscale, rows_per_image, (bf16_t*)y, ldy, M / groups, C,
                                                           relu, L.vpb, L.rpb, rpbk, bpg, nullptr, nullptr, nullptr,
-                                                          nullptr, nullptr, groups, 0.f, 0.f);
+                                                          nullptr, nullptr, groups, 0.f, 0.f, nullptr);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
@@ -320,9 +330,10 @@ extern "C" int rgda_bn_apply(const void* x, int ldx, const float* mi, const floa
 extern "C" int rgda_bn_train_apply(const void* x, int ldx, const float* stats, float* mi, float* running_mean,
                                    float* running_var, int64_t* num_batches_tracked, const float* gamma,
                                    const float* beta, const void* res, int ldres, const float* nscale,
-                                   int rows_per_image, void* y, int ldy, int64_t M, int C, int relu, int groups,
-                                   float eps, float momentum, rgda_stream_t stream) {
+                                   int rows_per_image, void* y, int ldy, uint8_t* relu_mask, int64_t M, int C,
+                                   int relu, int groups, float eps, float momentum, rgda_stream_t stream) {
     if (!x || !stats || !mi || !gamma || !beta || !y || M <= 0 || C <= 0 || (C & 7) || (ldx & 7) || (ldy & 7)) return RGDA_ERR_ARG;
+    if (relu_mask && !relu) return RGDA_ERR_ARG;
     if (res && (ldres & 7)) return RGDA_ERR_ARG;
     if (nscale && rows_per_image <= 0) return RGDA_ERR_ARG;
     if (groups < 1 || (M % groups) || M / groups < 2) return RGDA_ERR_ARG;
@@ -334,7 +345,7 @@ extern "C" int rgda_bn_train_apply(const void* x, int ldx, const float* stats, f
                                                           ldres, nscale, rows_per_image, (bf16_t*)y, ldy, M / groups, C,
                                                           relu, L.vpb, L.rpb, rpbk, bpg, stats, mi, running_mean,
                                                           running_var, (long long*)num_batches_tracked, groups, eps,
-                                                          momentum);
+                                                          momentum, relu_mask);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
@@ -342,6 +353,7 @@ extern "C" int rgda_bn_train_apply(const void* x, int ldx, const float* stats, f
 // ------------------------------------------------------------------ BN backward
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __restrict__ g, int ldg,
                                                             const bf16_t* __restrict__ y, int ldy,
+                                                            const uint8_t* __restrict__ rmask,
                                                             const bf16_t* __restrict__ x, int ldx,
                                                             const float* __restrict__ mi, const float* __restrict__ nscale,
                                                             int rpi, float* sums, long long M, int C, int relu, int vpb,
@@ -362,13 +374,17 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
         long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
         for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
             u16x8 gv[ROW_BATCH], xv[ROW_BATCH], yv[ROW_BATCH];
+            unsigned mb[ROW_BATCH];
 #pragma unroll
             for (int u = 0; u < ROW_BATCH; ++u) {
                 const long long r = rb + (long long)u * rpb;
                 if (r < r1) {
                     gv[u] = *(const u16x8*)(g + r * ldg + cg);
                     xv[u] = *(const u16x8*)(x + r * ldx + cg);
-                    if (relu) yv[u] = *(const u16x8*)(y + r * ldy + cg);
+                    if (relu) {
+                        if (rmask) mb[u] = rmask[r * (C >> 3) + (cg >> 3)];
+                        else yv[u] = *(const u16x8*)(y + r * ldy + cg);
+                    }
                 }
             }
 #pragma unroll
@@ -379,10 +395,15 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                 cvt8(gv[u], gf);
                 cvt8(xv[u], xf);
                 if (relu) {
-                    float yf[8];
-                    cvt8(yv[u], yf);
+                    if (rmask) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+                        for (int e = 0; e < 8; ++e) gf[e] = ((mb[u] >> e) & 1u) ? gf[e] : 0.f;
+                    } else {
+                        float yf[8];
+                        cvt8(yv[u], yf);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+                    }
                 }
                 if (nscale) {
                     const float* ns = nscale + (r / rpi) * C + cg;
@@ -398,10 +419,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
     block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, rep, rep + C, lds);
 }
 
-extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
-                                  const float* mi, const float* nscale, int rows_per_image, float* sums, int64_t M,
-                                  int C, int relu, int groups, rgda_stream_t stream) {
-    if (!g || !x || !mi || !sums || (relu && !y) || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || (ldx & 7)) return RGDA_ERR_ARG;
+extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask,
+                                  const void* x, int ldx, const float* mi, const float* nscale, int rows_per_image,
+                                  float* sums, int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
+    if (!g || !x || !mi || !sums || (relu && !y && !relu_mask) || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || (ldx & 7)) return RGDA_ERR_ARG;
     if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     hipStream_t st = to_stream(stream);
     RowLayout L = row_layout(C);
@@ -410,7 +431,7 @@ extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy
     if (rows_per_block > Mg) rows_per_block = (int)((Mg + L.rpb - 1) / L.rpb * L.rpb);
     int bpg = cdiv(Mg, rows_per_block);
     dim3 grid(bpg * groups, cdiv(L.vpr, L.vpb));
-    bn_bwd_reduce_kernel<<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, (const bf16_t*)x, ldx, mi,
+    bn_bwd_reduce_kernel<<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask, (const bf16_t*)x, ldx, mi,
                                                nscale, rows_per_image, sums, Mg, C, relu, L.vpb, L.rpb, rows_per_block,
                                                bpg);
     RGDA_CHECK_LAUNCH();
@@ -419,6 +440,7 @@ extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restrict__ g, int ldg,
                                                            const bf16_t* __restrict__ y, int ldy,
+                                                           const uint8_t* __restrict__ rmask,
                                                            const bf16_t* __restrict__ x, int ldx,
                                                            const float* __restrict__ mi, const float* __restrict__ gamma,
                                                            const float* __restrict__ nscale, int rpi,
@@ -458,13 +480,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
     for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
         u16x8 gv[ROW_BATCH], xv[ROW_BATCH], yv[ROW_BATCH];
+        unsigned mb[ROW_BATCH];
 #pragma unroll
         for (int u = 0; u < ROW_BATCH; ++u) {
             const long long r = rb + (long long)u * rpb;
             if (r < r1) {
                 gv[u] = *(const u16x8*)(g + r * ldg + cg);
                 xv[u] = *(const u16x8*)(x + r * ldx + cg);
-                if (relu) yv[u] = *(const u16x8*)(y + r * ldy + cg);
+                if (relu) {
+                    if (rmask) mb[u] = rmask[r * (C >> 3) + (cg >> 3)];
+                    else yv[u] = *(const u16x8*)(y + r * ldy + cg);
+                }
             }
         }
 #pragma unroll
@@ -475,10 +501,15 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             cvt8(gv[u], gf);
             cvt8(xv[u], xf);
             if (relu) {
-                float yf[8];
-                cvt8(yv[u], yf);
+                if (rmask) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+                    for (int e = 0; e < 8; ++e) gf[e] = ((mb[u] >> e) & 1u) ? gf[e] : 0.f;
+                } else {
+                    float yf[8];
+                    cvt8(yv[u], yf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+                }
             }
             if (nscale) {
                 const float* ns = nscale + (r / rpi) * C + cg;
@@ -494,17 +525,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     }
 }
 
-extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const void* x, int ldx,
+extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask,
+                                 const void* x, int ldx,
                                  const float* mi, const float* gamma, const float* nscale, int rows_per_image,
                                  const float* sums, void* dx, int lddx, void* gmask, int ldgm, float* dgamma,
                                  float* dbeta, int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
-    if (!g || !x || !mi || !gamma || !sums || !dx || (relu && !y) || M <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
+    if (!g || !x || !mi || !gamma || !sums || !dx || (relu && !y && !relu_mask) || M <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
     if ((ldg & 7) || (ldx & 7) || (lddx & 7) || (gmask && (ldgm & 7)) || ((dgamma == nullptr) != (dbeta == nullptr)))
         return RGDA_ERR_ARG;
     if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     RowLayout L; int rpbk, bpg; dim3 grid;
     elementwise_grid(M / groups, C, groups, L, rpbk, bpg, grid);
-    bn_bwd_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy,
+    bn_bwd_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask,
                                                               (const bf16_t*)x, ldx, mi, gamma, nscale, rows_per_image,
                                                               sums, (bf16_t*)dx, lddx, (bf16_t*)gmask, ldgm, dgamma,
                                                               dbeta, M / groups, C, relu, L.vpb, L.rpb, rpbk, bpg);

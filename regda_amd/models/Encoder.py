@@ -153,6 +153,7 @@ class Deeplabv2(nn.Module):
         # weight gradients are collected and launched in groups (rgda_conv2d_wgrad_grouped) once this much work
         # is pending; 0 = one launch per layer
         self.wgrad_group_gflop = 250.0
+        self.relu_sign_mask = False  # keep ReLU sign bits for the backward pass instead of re-reading y
         self._mat_cache = {}
         self._synced_version = -1
         self.sync_weights()
@@ -413,13 +414,18 @@ class Deeplabv2(nn.Module):
         if train:
             if M // G < 2:
                 raise ValueError('Expected more than 1 value per channel when training')
+            # optional: the backward pass needs only the SIGN of y (ReLU), one bit per element written next to y.
+            # Measured on MI355X it does not pay (the BN-backward kernels are not read-bandwidth bound and the
+            # byte stores cost the forward ~2 us per launch), so it is off by default.
+            rmask = (torch.empty(M, conv.co // 8, dtype=torch.uint8, device=self.device)
+                     if (relu and self.relu_sign_mask) else None)
             ops.bn_train_apply(c, stats, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale,
-                               Ho * Wo, groups=G)
+                               Ho * Wo, groups=G, relu_mask=rmask)
         else:
             ops.bn_finalize(None, mi, bn.rm, bn.rv, None, M, conv.co)
             ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale, Ho * Wo, groups=G)
         if train:
-            T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale)
+            T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale, rmask)
         return y, Ho, Wo
 
     def _flush_wgrads(self, T):
@@ -457,18 +463,19 @@ class Deeplabv2(nn.Module):
                  consumer=None):
         """Backward of one conv+BN(+ReLU) unit.  `consumer` = (tape key, relu) of the unit that will consume this
         unit's data gradient: its BN-backward reduction is then folded into our data-gradient conv's epilogue."""
-        x, c, y, mi, (N, H, W, Ho, Wo), nscale = T[key]
+        x, c, y, mi, (N, H, W, Ho, Wo), nscale, rmask = T[key]
         M, C, G = N * Ho * Wo, conv.co, T['groups']
         sums = T.pop('sums:' + key, None)
         if sums is None:
             sums = T.pop('presums:' + key, None)        # arena slice reserved by a producer that could not fuse
             if sums is None:
                 sums = T['sums_pool'].take(G * NREP * 2 * C)
-            ops.bn_bwd_reduce(g, y if relu else None, c, mi, sums, M, C, relu, nscale, Ho * Wo, groups=G)
+            ops.bn_bwd_reduce(g, y if (relu and rmask is None) else None, c, mi, sums, M, C, relu, nscale, Ho * Wo,
+                              groups=G, relu_mask=rmask)
         dc = torch.empty(M, C, dtype=BF, device=self.device)
         gm = torch.empty(M, C, dtype=BF, device=self.device) if want_gmask else None
-        ops.bn_bwd_apply(g, y if relu else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm, bn.dgamma, bn.dbeta,
-                         nscale, Ho * Wo, groups=G)
+        ops.bn_bwd_apply(g, y if (relu and rmask is None) else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm,
+                         bn.dgamma, bn.dbeta, nscale, Ho * Wo, groups=G, relu_mask=rmask)
         if stem:
             self.stem_gtmp.zero_()
             ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
@@ -485,12 +492,13 @@ class Deeplabv2(nn.Module):
             fused = False
             if consumer is not None and self.fuse_bn_bwd:
                 ckey, crelu = consumer
-                cx, cc, cy, cmi, (cN, cH, cW, cHo, cWo), cns = T[ckey]
+                cx, cc, cy, cmi, (cN, cH, cW, cHo, cWo), cns, cmask = T[ckey]
                 assert cN * cHo * cWo == N * H * W and cc.shape[1] == conv.ci
                 csums = T['sums_pool'].take(G * NREP * 2 * conv.ci)
                 try:
                     ops.conv2d_bnbwd(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil,
-                                     1, dx_res, csums, G, cy if crelu else None, cc, cmi, crelu, cns, cHo * cWo)
+                                     1, dx_res, csums, G, cy if (crelu and cmask is None) else None, cc, cmi, crelu,
+                                     cns, cHo * cWo, relu_mask=cmask)
                     T['sums:' + ckey] = csums
                     fused = True
                 except ValueError:          # row groups do not tile (tiny maps): plain conv, standalone reduction

@@ -208,13 +208,13 @@ def conv2d_bneval(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, ga
 
 
 def conv2d_bnbwd(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, bn_mi, relu,
-                 nscale=None, rows_per_image=0):
+                 nscale=None, rows_per_image=0, relu_mask=None):
     """conv2d whose epilogue also accumulates the BN-backward sums of the consumer of `y` (see rgda_conv2d_bnbwd)."""
     Cout, taps, Cin = w.shape
     assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
     lib().call('rgda_conv2d_bnbwd', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
                _ld(res) if res is not None else 0, sums.data_ptr(), groups, _p(bn_y), _ld(bn_y) if bn_y is not None else 0,
-               bn_x.data_ptr(), _ld(bn_x), bn_mi.data_ptr(), _p(nscale), rows_per_image, int(relu), N, H, W, Cin, Ho, Wo,
+               _p(relu_mask), bn_x.data_ptr(), _ld(bn_x), bn_mi.data_ptr(), _p(nscale), rows_per_image, int(relu), N, H, W, Cin, Ho, Wo,
                Cout, kh, kw, stride, pad, dil, mode, _stream())
 
 
@@ -267,20 +267,22 @@ def bn_apply(x, mi, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_
 
 
 def bn_train_apply(x, stats, mi, rm, rv, nbt, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_image=0,
-                   groups=1, eps=1e-5, momentum=0.1):
+                   groups=1, eps=1e-5, momentum=0.1, relu_mask=None):
     lib().call('rgda_bn_train_apply', x.data_ptr(), _ld(x), stats.data_ptr(), mi.data_ptr(), _p(rm), _p(rv), _p(nbt),
                gamma.data_ptr(), beta.data_ptr(), _p(res), _ld(res) if res is not None else 0, _p(nscale),
-               rows_per_image, y.data_ptr(), _ld(y), M, C, int(relu), groups, eps, momentum, _stream())
+               rows_per_image, y.data_ptr(), _ld(y), _p(relu_mask), M, C, int(relu), groups, eps, momentum, _stream())
 
 
-def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0, groups=1):
-    lib().call('rgda_bn_bwd_reduce', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, x.data_ptr(), _ld(x),
+def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0, groups=1, relu_mask=None):
+    lib().call('rgda_bn_bwd_reduce', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, _p(relu_mask),
+               x.data_ptr(), _ld(x),
                mi.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), M, C, int(relu), groups, _stream())
 
 
 def bn_bwd_apply(g, y, x, mi, gamma, sums, dx, M, C, relu, gmask=None, dgamma=None, dbeta=None, nscale=None,
-                 rows_per_image=0, groups=1):
-    lib().call('rgda_bn_bwd_apply', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, x.data_ptr(), _ld(x),
+                 rows_per_image=0, groups=1, relu_mask=None):
+    lib().call('rgda_bn_bwd_apply', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, _p(relu_mask),
+               x.data_ptr(), _ld(x),
                mi.data_ptr(), gamma.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), dx.data_ptr(), _ld(dx),
                _p(gmask), _ld(gmask) if gmask is not None else 0, _p(dgamma), _p(dbeta), M, C, int(relu), groups,
                _stream())

@@ -13,7 +13,7 @@ def bench(fn, n=48):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 R = 12
-CFG = [dict(), dict(RGDA_BN_VPB='8', RGDA_BN_ROWS='8'), dict(RGDA_BN_VPB='8', RGDA_BN_ROWS='4'), dict(RGDA_BN_VPB='16', RGDA_BN_ROWS='8'), dict(RGDA_BN_VPB='16', RGDA_BN_ROWS='16'), dict(RGDA_BN_VPB='32', RGDA_BN_ROWS='16')]
+CFG = [dict()]
 for (M, C, res) in [(16384, 256, 0), (16384, 1024, 1), (65536, 128, 0), (65536, 512, 1), (262144, 64, 0), (262144, 256, 1), (16384, 512, 0), (16384, 2048, 1)]:
     G = 2
     x = [torch.randn(M, C, device='cuda').to(BF) for _ in range(R)]
@@ -22,6 +22,7 @@ for (M, C, res) in [(16384, 256, 0), (16384, 1024, 1), (65536, 128, 0), (65536, 
     g = [torch.randn(M, C, device='cuda').to(BF) for _ in range(R)]
     dx = [torch.empty(M, C, dtype=BF, device='cuda') for _ in range(R)]
     gm = [torch.empty(M, C, dtype=BF, device='cuda') for _ in range(R)]
+    mk = [torch.zeros(M, C // 8, dtype=torch.uint8, device='cuda') for _ in range(R)]
     stats = torch.rand(G, 8, 2, C, device='cuda')
     stats[:, :, 1] += 4.0 * M / G / 8
     mi = torch.zeros(G, 2, C, device='cuda')
@@ -31,7 +32,7 @@ for (M, C, res) in [(16384, 256, 0), (16384, 1024, 1), (65536, 128, 0), (65536, 
     sums = torch.zeros(G, 8, 2, C, device='cuda')
     for cfg in CFG:
         os.environ.update(cfg)
-        t1 = bench(lambda i: ops.bn_train_apply(x[i % R], stats, mi, rm, rv, nbt, gamma, beta, y[i % R], M, C, True, r[i % R] if res else None, None, 0, groups=G))
-        t2 = bench(lambda i: ops.bn_bwd_apply(g[i % R], y[i % R], x[i % R], mi, gamma, sums, dx[i % R], M, C, True, gm[i % R] if res else None, dgam, dbet, None, 0, groups=G))
+        t1 = bench(lambda i: ops.bn_train_apply(x[i % R], stats, mi, rm, rv, nbt, gamma, beta, y[i % R], M, C, True, r[i % R] if res else None, None, 0, groups=G, relu_mask=mk[i % R]))
+        t2 = bench(lambda i: ops.bn_bwd_apply(g[i % R], None, x[i % R], mi, gamma, sums, dx[i % R], M, C, True, gm[i % R] if res else None, dgam, dbet, None, 0, groups=G, relu_mask=mk[i % R]))
         for k in cfg: os.environ.pop(k)
         print('M=%-7d C=%-5d res=%d %-14s| train_apply %6.1fus | bwd_apply %6.1fus' % (M, C, res, ','.join(cfg.values()) or 'default', t1, t2))

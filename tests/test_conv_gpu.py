@@ -203,6 +203,65 @@ def test_batchnorm_fwd_bwd(ops):
     torch.testing.assert_close(mi2[1].cpu(), 1 / torch.sqrt(rvg.cpu() + 1e-5), rtol=1e-5, atol=1e-6)
 
 
+def unpack_mask(mask, C):
+    """uint8 [M][C/8] sign bits -> bool [M][C]"""
+    bits = (mask.cpu().unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1
+    return bits.reshape(mask.shape[0], C).bool()
+
+
+@pytest.mark.parametrize('C', [64, 256])
+def test_relu_sign_mask_replaces_y_in_the_backward_kernels(ops, C):
+    """bn_train_apply's relu_mask must be exactly [y > 0] bit for bit, and the three backward consumers
+    (bn_bwd_reduce, bn_bwd_apply, conv2d_bnbwd's epilogue) must give IDENTICAL results from the mask as from y."""
+    g = torch.Generator().manual_seed(31)
+    N, H, W, G = 4, 8, 8, 2
+    M = N * H * W
+    x = torch.randn(M, C, generator=g).to(BF).cuda()
+    res = torch.randn(M, C, generator=g).to(BF).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    ns = ((torch.rand(N, C, generator=g) > 0.2).float() / 0.8).cuda()
+    stats = torch.zeros(G, 8, 2, C, device='cuda')
+    for gi in range(G):
+        ops.bn_stats(x[gi * M // G:(gi + 1) * M // G], stats[gi], M // G, C)
+    mi = torch.empty(G, 2, C, device='cuda')
+    rm, rv, nbt = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+    y = torch.empty(M, C, dtype=BF, device='cuda')
+    mask = torch.zeros(M, C // 8, dtype=torch.uint8, device='cuda')
+    ops.bn_train_apply(x, stats, mi, rm, rv, nbt, gamma, beta, y, M, C, True, res, ns, H * W, groups=G, relu_mask=mask)
+    assert torch.equal(unpack_mask(mask, C), (y.float() > 0).cpu())
+    assert 0.2 < unpack_mask(mask, C).float().mean() < 0.8
+    with pytest.raises(ValueError):      # a mask without ReLU is a caller bug
+        ops.bn_train_apply(x, stats, mi, rm, rv, nbt, gamma, beta, y, M, C, False, res, ns, H * W, groups=G, relu_mask=mask)
+    go = torch.randn(M, C, generator=g).to(BF).cuda()
+    out = {}
+    for tag, kw in (('y', dict()), ('mask', dict(relu_mask=mask))):
+        yy = y if tag == 'y' else None
+        sums = torch.zeros(G, 8, 2, C, device='cuda')
+        ops.bn_bwd_reduce(go, yy, x, mi, sums, M, C, True, ns, H * W, groups=G, **kw)
+        dx = torch.empty(M, C, dtype=BF, device='cuda')
+        gm = torch.empty(M, C, dtype=BF, device='cuda')
+        dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+        ops.bn_bwd_apply(go, yy, x, mi, gamma, sums, dx, M, C, True, gm, dgam, dbet, ns, H * W, groups=G, **kw)
+        out[tag] = (sums.sum(1), dx, gm, dgam, dbet)
+    for a, b in zip(out['y'][1:3], out['mask'][1:3]):
+        assert torch.equal(a, b)
+    for a, b in zip((out['y'][0],) + out['y'][3:], (out['mask'][0],) + out['mask'][3:]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)         # atomics: summation order only
+    if C % 64 == 0:
+        k, Cb = 3, 128
+        dy = torch.randn(M, Cb, generator=g).to(BF).cuda()
+        wt = (torch.randn(C, k * k, Cb, generator=g) * 0.05).to(BF).cuda()
+        got = []
+        for tag in ('y', 'mask'):
+            dx = torch.empty(M, C, dtype=BF, device='cuda')
+            sums = torch.zeros(G, 8, 2, C, device='cuda')
+            ops.conv2d_bnbwd(dy, wt, dx, N, H, W, H, W, k, k, 1, 1, 1, 1, res, sums, G, y if tag == 'y' else None, x, mi,
+                             True, ns, H * W, relu_mask=mask if tag == 'mask' else None)
+            got.append((dx, sums.sum(1)))
+        assert torch.equal(got[0][0], got[1][0])
+        torch.testing.assert_close(got[0][1], got[1][1], rtol=1e-5, atol=1e-3)
+
+
 def test_bn_dropout_scale(ops):
     g = torch.Generator().manual_seed(9)
     N, C, HW = 2, 64, 16

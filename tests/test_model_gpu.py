@@ -156,7 +156,7 @@ def test_layerwise_backward_consistency():
     orig = E.Deeplabv2._cbr_bwd
 
     def spy(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False, consumer=None):
-        x, c, y, mi, dims, nscale = T[key]
+        x, c, y, mi, dims, nscale, rmask = T[key]
         g0 = conv.g.clone()
         dg0, db0 = bn.dgamma.clone(), bn.dbeta.clone()
         out = orig(self, T, key, conv, bn, g, relu, need_dx, want_gmask, dx_res, stem, consumer)
@@ -236,3 +236,30 @@ def test_grouped_forward_backward_equals_two_separate_passes():
     assert int(m.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == 2
     cos = (m.flat_g @ ga / (m.flat_g.norm() * ga.norm())).item()
     assert cos > 0.99 and abs(m.flat_g.norm().item() / ga.norm().item() - 1) < 0.03
+
+
+def test_relu_sign_mask_mode_gives_identical_gradients():
+    """relu_sign_mask=True keeps one bit per activation for the backward pass instead of re-reading y:
+    identical activations, identical data gradients, weight gradients equal up to atomic summation order."""
+    rt = 'resnet17t'
+    m = build(rt)
+    sd = omodel.init_state_dict(rt, 6, seed=6)
+    gen = torch.Generator().manual_seed(13)
+    x = [torch.randn(2, 3, 64, 64, generator=gen).cuda(), torch.randn(2, 3, 64, 64, generator=gen).cuda()]
+    g1, g2 = torch.randn(4, 6, 4, 4, generator=gen).cuda(), torch.randn(4, 6, 4, 4, generator=gen).cuda()
+    ones = torch.ones(2, 512)
+    out = []
+    for flag in (False, True):
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        m.relu_sign_mask = flag
+        m.set_drop_masks(ones, ones)
+        m.flat_g.zero_()
+        T = m.new_tape(groups=2)
+        with torch.no_grad():
+            c1, c2, f = m._forward_plan(x, T)
+            m._backward_plan(T, g1, g2)
+        out.append((c1.clone(), c2.clone(), m.flat_g.clone()))
+    m.relu_sign_mask = False
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert l2(out[1][2], out[0][2]) < 1e-4

@@ -31,6 +31,7 @@ struct ConvArgs {
     int tiles_c, tiles_p;
     int rows_per_group;   // BatchNorm statistics are kept per group of rows (src / tgt batch)
     unsigned long long* dbg;   // optional per-workgroup phase timestamps (tuning builds only)
+    int skip;                  // tuning only: 1 = no DMA inside the K loop, 2 = no LDS reads / MFMA
     // optional fused BatchNorm-backward reduction of the CONSUMER of this (data-gradient) output: with g = the stored
     // result, g' = g * [bn_y > 0] * nscale, xhat = (bn_x - mean) * invstd, `stats` receives sum(g'), sum(g' * xhat)
     const bf16_t* bn_y;
@@ -192,10 +193,12 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         if (a.dbg) tbar += __builtin_readcyclecounter() - tw0;
         if (a.dbg && kt == 0) tq1 = __builtin_readcyclecounter();
-        if (kt + STAGES - 1 < KT) {
+        const bool more = kt + STAGES - 1 < KT && !(a.skip & 1);
+        if (more && !(a.skip & 4)) {
             advance();
             issue(stage >= 1 ? stage - 1 : STAGES - 1);      // (kt + STAGES - 1) % STAGES
         }
+        if (a.skip & 2) { stage = (stage == STAGES - 1) ? 0 : stage + 1; continue; }
         const unsigned char* wb = smem + stage * TILE;
         const unsigned char* xb = wb + BC * 128;
         // all fragments of the K tile are fetched up front (4 k-steps x (FI+FJ) x 16 B per lane), then the MFMAs
@@ -221,6 +224,10 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < FJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+        if (more && (a.skip & 4)) {          // tuning: DMA issued behind the MFMAs instead of in front of the LDS reads
+            advance();
+            issue(stage >= 1 ? stage - 1 : STAGES - 1);
+        }
         stage = (stage == STAGES - 1) ? 0 : stage + 1;
     }
     __syncthreads();
@@ -373,8 +380,10 @@ static int pick_tile(long long M, int Cout, long long ktot, int rows_per_group, 
     bc = (Cout <= 64) ? 64 : 128;
     bp = 64;
     int waves = 4;
+    int t82 = 512;
+    if (const char* e = getenv("RGDA_T82")) t82 = atoi(e);     // tuning experiments only
     if (bc == 128 && ktot >= 4096 && (long long)cdiv(M, 256) * cdiv(Cout, bc) >= 240) { bp = 256; waves = 8; }
-    else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= 512) { bp = 128; waves = 8; }
+    else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= t82) { bp = 128; waves = 8; }
     if (rows_per_group) {
         while (bp > 64 && (rows_per_group % bp)) bp >>= 1;
         if (rows_per_group % bp) return 1;
@@ -431,8 +440,9 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         a.ev_rm = bne->rm; a.ev_rv = bne->rv; a.ev_gamma = bne->gamma; a.ev_beta = bne->beta; a.ev_eps = bne->eps;
         a.ev_relu = bne->relu;
     }
-    a.dbg = nullptr;
+    a.dbg = nullptr; a.skip = 0;
     if (const char* e = getenv("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
+    if (const char* e = getenv("RGDA_CONV_SKIP")) a.skip = atoi(e);                                      // tuning only
     int bc, bp, stages;
     if (pick_tile(M, Cout, (long long)kh * kw * Cin, (stats && stat_groups > 1) ? a.rows_per_group : 0, bc, bp, stages))
         return RGDA_ERR_UNSUPPORTED;

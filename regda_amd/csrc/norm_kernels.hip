@@ -791,62 +791,90 @@ extern "C" int rgda_instnorm_bwd(const void* ga, const void* gb, int ldg, const 
 }
 
 // ------------------------------------------------------------------ spatial linear map
-// out[n][i][c] (+)= sum_j Mx[i][j] * in[n][j][c]; block = (i, n), threads over channel vectors
+// out[n][i][c] (+)= sum_j Mx[i][j] * in[n][j][c]; block = (output row i, image n, CVB channel vectors);
+// 256 / CVB thread slices split the J range.  Long rows (adaptive-pool matrices: J = H*W, a bin touches a
+// few dozen of them) use 8 vectors x 32 slices and walk only the row's nonzero span; short rows (bilinear
+// upsampling from an s x s grid) use 32 vectors x 8 slices.
+template <int CVB>
 __global__ void __launch_bounds__(256) spatial_mix_kernel(const bf16_t* __restrict__ in, int ldin,
                                                           const float* __restrict__ Mx, void* out, int ldout, int I,
                                                           int J, int C, int accumulate, int out_f32) {
-    // block = (output row i, image n, 32 channel vectors) ; 8 thread slices split the J range
-    __shared__ float red[8][32][8];
+    constexpr int SL = 256 / CVB;
+    __shared__ float red[SL][CVB][8];
+    __shared__ int span[2];
     const int i = blockIdx.x, n = blockIdx.y;
-    const int cvl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int cv = blockIdx.z * 32 + cvl;
+    const int cvl = threadIdx.x % CVB, sl = threadIdx.x / CVB;
+    const int cv = blockIdx.z * CVB + cvl;
     const bool cok = cv < C / 8;
     const float* mrow = Mx + (size_t)i * J;
-    {
-        float acc[8] = {0};
-        if (cok)
-            for (int j = sl; j < J; j += 8) {
-                float m = mrow[j];
-                if (m == 0.f) continue;
-                float f[8];
-                load8(in + ((size_t)n * J + j) * ldin + cv * 8, f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += m * f[e];
-            }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[sl][cvl][e] = acc[e];
+    int lo = 0, hi = J - 1;
+    if (J >= 256) {
+        if (threadIdx.x == 0) { span[0] = J; span[1] = -1; }
         __syncthreads();
-        if (sl != 0 || !cok) return;
+        int l = J, h = -1;
+        for (int j = threadIdx.x; j < J; j += 256)
+            if (mrow[j] != 0.f) { l = min(l, j); h = max(h, j); }
+        if (h >= 0) { atomicMin(&span[0], l); atomicMax(&span[1], h); }
+        __syncthreads();
+        lo = span[0]; hi = span[1];
+    }
+    float acc[8] = {0};
+    if (cok)
+        for (int jb = lo + sl; jb <= hi; jb += SL * ROW_BATCH) {
+            float m[ROW_BATCH];
+            u16x8 v[ROW_BATCH];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) a += red[q][cvl][e];
-            acc[e] = a;
-        }
-        size_t o = ((size_t)n * I + i) * ldout + cv * 8;
-        if (out_f32) {
-            float* op = (float*)out + o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) op[e] = accumulate ? op[e] + acc[e] : acc[e];
-        } else {
-            bf16_t* op = (bf16_t*)out + o;
-            if (accumulate) {
-                float f[8];
-                load8(op, f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += f[e];
+            for (int u = 0; u < ROW_BATCH; ++u) {
+                const int j = jb + u * SL;
+                m[u] = (j <= hi) ? mrow[j] : 0.f;
+                if (m[u] != 0.f) v[u] = *(const u16x8*)(in + ((size_t)n * J + j) * ldin + cv * 8);
             }
-            store8(op, acc);
+#pragma unroll
+            for (int u = 0; u < ROW_BATCH; ++u) {
+                if (m[u] == 0.f) continue;
+                float f[8];
+                cvt8(v[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += m[u] * f[e];
+            }
         }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[sl][cvl][e] = acc[e];
+    __syncthreads();
+    if (sl != 0 || !cok) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float a = 0.f;
+        for (int q = 0; q < SL; ++q) a += red[q][cvl][e];
+        acc[e] = a;
+    }
+    size_t o = ((size_t)n * I + i) * ldout + cv * 8;
+    if (out_f32) {
+        float* op = (float*)out + o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = accumulate ? op[e] + acc[e] : acc[e];
+    } else {
+        bf16_t* op = (bf16_t*)out + o;
+        if (accumulate) {
+            float f[8];
+            load8(op, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+        store8(op, acc);
     }
 }
 
 extern "C" int rgda_spatial_mix(const void* in, int ldin, const float* Mx, void* out, int ldout, int N, int I, int J,
                                 int C, int accumulate, int out_f32, rgda_stream_t stream) {
     if (!in || !Mx || !out || N <= 0 || I <= 0 || J <= 0 || C <= 0 || (C & 7) || (ldin & 7) || (ldout & 7)) return RGDA_ERR_ARG;
-    dim3 grid(I, N, cdiv(C / 8, 32));
-    spatial_mix_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)in, ldin, Mx, out, ldout, I, J, C, accumulate, out_f32);
+    if (J >= 256) {
+        dim3 grid(I, N, cdiv(C / 8, 8));
+        spatial_mix_kernel<8><<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)in, ldin, Mx, out, ldout, I, J, C, accumulate, out_f32);
+    } else {
+        dim3 grid(I, N, cdiv(C / 8, 32));
+        spatial_mix_kernel<32><<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)in, ldin, Mx, out, ldout, I, J, C, accumulate, out_f32);
+    }
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -282,50 +282,59 @@ __global__ void __launch_bounds__(256) proto_center_kernel(const float* __restri
     if (threadIdx.x == 0) pstd[c] = sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)(K - 1));
 }
 
-// sim[b][c][p] = 1 / pearson_dist(feat[b,:,p], protos[c]).  Workgroup = 64 pixels x 4 k-slices.
-template <int C>
-__global__ void __launch_bounds__(256) pearson_sim_kernel(const float* __restrict__ feat, const float* __restrict__ pc,
-                                                          const float* __restrict__ pstd, float* __restrict__ sim,
-                                                          int K, int hw) {
-    extern __shared__ float lds[];      // pc[C][K] then red[4][64][C+1]
+// sim[b][c][p] = 1 / pearson_dist(feat[b,:,p], protos[c]).  Workgroup = PX pixels x SL k-slices (PX * SL threads):
+// 32 x 16 gives 256 workgroups of 8 waves for the 8 x 32 x 32 target map, every CU streams its share of the
+// 67 MB feature map (the second pass over it is served by L2).
+template <int C, int PX, int SL>
+__global__ void __launch_bounds__(PX * SL) pearson_sim_kernel(const float* __restrict__ feat, const float* __restrict__ pc,
+                                                              const float* __restrict__ pstd, float* __restrict__ sim,
+                                                              int K, int hw) {
+    extern __shared__ float lds[];      // pc[C][K] then red[SL][PX][C+1]
     float* lpc = lds;
     float* red = lds + (size_t)C * K;
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int p = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x % PX, slice = threadIdx.x / PX;
+    const int p = blockIdx.x * PX + lane;
     const bool ok = p < hw;
-    for (int i = threadIdx.x; i < C * K; i += 256) lpc[i] = pc[i];
+    for (int i = threadIdx.x; i < C * K; i += PX * SL) lpc[i] = pc[i];
     const float* f = feat + (size_t)b * K * hw + (ok ? p : 0);
-    const int k0 = slice * (K / 4), k1 = (slice == 3) ? K : k0 + K / 4;
-    float s = 0.f;
-    for (int k = k0; k < k1; ++k) s += f[(size_t)k * hw];
-    red[(slice * 64 + lane) * (C + 1)] = s;
+    const int kper = (K + SL - 1) / SL;
+    const int k0 = min(slice * kper, K), k1 = min(k0 + kper, K);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        s0 += f[(size_t)k * hw]; s1 += f[(size_t)(k + 1) * hw]; s2 += f[(size_t)(k + 2) * hw]; s3 += f[(size_t)(k + 3) * hw];
+    }
+    for (; k < k1; ++k) s0 += f[(size_t)k * hw];
+    red[(slice * PX + lane) * (C + 1)] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    float mean = (red[lane * (C + 1)] + red[(64 + lane) * (C + 1)] + red[(128 + lane) * (C + 1)] +
-                  red[(192 + lane) * (C + 1)]) / (float)K;
+    float tot = 0.f;
+    for (int q = 0; q < SL; ++q) tot += red[(q * PX + lane) * (C + 1)];
+    const float mean = tot / (float)K;
     __syncthreads();
     float q = 0.f, cov[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) cov[c] = 0.f;
-    for (int k = k0; k < k1; ++k) {
+#pragma unroll 4
+    for (k = k0; k < k1; ++k) {
         float d = f[(size_t)k * hw] - mean;
         q += d * d;
 #pragma unroll
         for (int c = 0; c < C; ++c) cov[c] += d * lpc[c * K + k];
     }
-    float* r = red + (slice * 64 + lane) * (C + 1);
+    float* r = red + (slice * PX + lane) * (C + 1);
     r[0] = q;
 #pragma unroll
     for (int c = 0; c < C; ++c) r[1 + c] = cov[c];
     __syncthreads();
     if (slice == 0 && ok) {
         float qq = 0.f;
-        for (int s4 = 0; s4 < 4; ++s4) qq += red[(s4 * 64 + lane) * (C + 1)];
+        for (int s4 = 0; s4 < SL; ++s4) qq += red[(s4 * PX + lane) * (C + 1)];
         float fstd = sqrtf(qq / (float)(K - 1));
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float cv = 0.f;
-            for (int s4 = 0; s4 < 4; ++s4) cv += red[(s4 * 64 + lane) * (C + 1) + 1 + c];
+            for (int s4 = 0; s4 < SL; ++s4) cv += red[(s4 * PX + lane) * (C + 1) + 1 + c];
             float bcov = cv / ((float)(K - 1) + 1e-7f);
             float dist = (-1.0f * bcov / (fstd * pstd[c] + 1e-7f) + 1.0f) * 0.5f;
             sim[((size_t)b * C + c) * hw + p] = 1.0f / dist;
@@ -433,9 +442,14 @@ extern "C" int rgda_label_refine(const float* feat, const float* protos, const f
     proto_center_kernel<<<c, 256, 0, st>>>(protos, pc, pstd, k);
     RGDA_CHECK_LAUNCH();
     const int hw = h * w;
-    size_t lds = ((size_t)6 * k + 4 * 64 * 7) * 4;
-    dim3 g1(cdiv(hw, 64), b);
-    pearson_sim_kernel<6><<<g1, 256, lds, st>>>(feat, pc, pstd, sim, k, hw);
+    constexpr int PX = 32, SL = 16;
+    size_t lds = ((size_t)6 * k + SL * PX * 7) * 4;
+    dim3 g1(cdiv(hw, PX), b);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)pearson_sim_kernel<6, PX, SL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return RGDA_ERR_LAUNCH;
+    pearson_sim_kernel<6, PX, SL><<<g1, PX * SL, lds, st>>>(feat, pc, pstd, sim, k, hw);
     RGDA_CHECK_LAUNCH();
     dim3 g2(cdiv(W, 256), H, b);
     refine_apply_kernel<6><<<g2, 256, 0, st>>>(sim, p1, p2, soft, out, classmax, h, w, H, W, temp);

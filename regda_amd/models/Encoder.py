@@ -306,11 +306,20 @@ class Deeplabv2(nn.Module):
         self.sync_derived_weights()
         self._synced_version = self.flat_p._version
 
-    def sync_derived_weights(self):
-        """Transposed (data-gradient) copies + padded stem weights; the bf16 mirror is already fresh."""
-        ops.weight_transpose_batched(self._wt_table, self._wt_table.shape[0], self._wt_blocks)
+    def sync_derived_weights(self, side_stream=None):
+        """Transposed (data-gradient) copies + padded stem weights; the bf16 mirror is already fresh.
+        The transposed copies are read by the NEXT backward pass only: with `side_stream` they are rebuilt there,
+        off the critical path, and `_backward_plan` waits for the recorded event."""
         s = self.convs['encoder.resnet.conv1']
         ops.pad_cast_bf16(s.w, self.stem_wb, 64, 147, STEM_KP)
+        if side_stream is None:
+            ops.weight_transpose_batched(self._wt_table, self._wt_table.shape[0], self._wt_blocks)
+            self._wt_ready = None
+        else:
+            side_stream.wait_event(torch.cuda.current_stream().record_event())
+            with ops.use_stream(side_stream):
+                ops.weight_transpose_batched(self._wt_table, self._wt_table.shape[0], self._wt_blocks)
+            self._wt_ready = side_stream.record_event()
 
     def _maybe_sync(self):
         if self.flat_p._version != self._synced_version:
@@ -594,6 +603,9 @@ class Deeplabv2(nn.Module):
     # ------------------------------------------------------------------ backward plan
     def _backward_plan(self, T, g1, g2, on_progress=None):
         dev = self.device
+        if getattr(self, '_wt_ready', None) is not None:       # transposed weights rebuilt on another stream
+            torch.cuda.current_stream().wait_event(self._wt_ready)
+            self._wt_ready = None
         T['on_progress'] = on_progress
         T['wgrad_pending'], T['wgrad_pending_flop'] = [], 0.0
         T['sums_pool'] = _StatsPool(sum(T['groups'] * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)

@@ -165,7 +165,7 @@ class SSLStep:
         ops.sgd_step(m.flat_p, m.flat_g, self.mom, shadow, m.flat_pb, self.gn, self.lr_dev, self.momentum, self.wd,
                      self.max_norm, self.reducer.gscale, self.ema_decay if shadow is not None else 0.0, self.first)
         self.first = False
-        m.sync_derived_weights()
+        m.sync_derived_weights(self.wgrad_stream)
         m._synced_version = m.flat_p._version
         self._mark('optimizer + weight mirrors done')
         self.last_hard = hard

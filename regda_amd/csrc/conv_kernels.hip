@@ -522,6 +522,7 @@ struct WgradArgs {
 #define RGDA_WGRAD_MAXG 16
 struct WgradGroup {
     int n;
+    int remap;      // 1: XCD-contiguous work-item ranges (see the kernels); measured slower for grouped 1x1 layers
     int first[RGDA_WGRAD_MAXG + 1];
     WgradArgs a[RGDA_WGRAD_MAXG];
 };
@@ -572,7 +573,8 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wi = wave % WI, wj = wave / WI;
-    int bid = blockIdx.x, layer = 0;
+    // workgroup b runs on XCD b % 8: with `remap` each XCD gets a contiguous range of work items = whole layers
+    int bid = g.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, layer = 0;
     while (layer + 1 < g.n && bid >= g.first[layer + 1]) ++layer;
     bid -= g.first[layer];
     const WgradArgs& a = g.a[layer];
@@ -768,7 +770,8 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradGroup g) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wi = wave & 1, wj = wave >> 1;
-    int bid = blockIdx.x, layer = 0;
+    // workgroup b runs on XCD b % 8: with `remap` each XCD gets a contiguous range of work items = whole layers
+    int bid = g.remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x, layer = 0;
     while (layer + 1 < g.n && bid >= g.first[layer + 1]) ++layer;
     bid -= g.first[layer];
     const WgradArgs& a = g.a[layer];
@@ -959,6 +962,11 @@ static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
         items += wgrad_tiles(a) * a.splits;
     }
     for (int l = g.n; l <= RGDA_WGRAD_MAXG; ++l) g.first[l] = items;
+    // keeping a layer's work items on one XCD (one L2) pays where the items of a layer re-read the same rows many
+    // times (the taps of the small-channel 3x3 layers in the 64x64 kernel: 297 -> 220 us; tap-fused: 2 %); the
+    // grouped 1x1 layers of the 128x128 kernel measured 9 % SLOWER with it (207 -> 225 us), so they keep b -> item b
+    g.remap = (kind != WK_G128_128);
+    if (const char* e = getenv("RGDA_WGRAD_REMAP")) g.remap = atoi(e);                   // tuning experiments only
     switch (kind) {
         case WK_G128_128: conv_wgrad_kernel<128, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
         case WK_G128_64: conv_wgrad_kernel<128, 64, 4, 2><<<items, 512, 0, st>>>(g); break;

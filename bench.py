@@ -60,7 +60,9 @@ def conv_flops_probe(step_fn):
         M = N * Ho * Wo
         code = L.raw('rgda_conv2d_tile')(M, co, kh, kw, ci, rows_per_group)
         bc, bp, stg = code & 1023, (code >> 10) & 1023, code >> 20
-        name = 'conv_igemm_kernel<%d, %d, %d, %s>' % (bc, bp, stg % 80 if stg >= 80 else stg, '2, 4' if stg >= 80 else '2, 2')
+        st3 = stg % 80 if stg >= 80 else stg
+        piped = 'true' if (st3 == 3 and bc == 128 and bp in (64, 128, 256) and (stg >= 80 or bp == 64)) else 'false'
+        name = 'conv_igemm_kernel<%d, %d, %d, %s, %s>' % (bc, bp, st3, '2, 4' if stg >= 80 else '2, 2', piped)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()

@@ -76,7 +76,7 @@ static __device__ __forceinline__ void src_coord(int mode, int base, int t, int 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int BC, int BP, int STAGES = 3, int WC = 2, int WP = 2>
+template <int BC, int BP, int STAGES = 3, int WC = 2, int WP = 2, bool PIPE = false>
 __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only
     constexpr int NW = WC * WP, NT = 64 * NW;            // waves / threads per workgroup
@@ -177,12 +177,73 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
     const int KT = taps * (a.Cin >> 6);
     unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, twait = 0, tbar = 0;
     if (a.dbg) tq0 = __builtin_readcyclecounter();
+    const int lrow = lane & 31, lk = lane >> 5;
+    int stage = 0;
+    if constexpr (PIPE) {
+        // ---- software-pipelined K loop: the barrier of K tile kt+1 sits BETWEEN the two halves of tile kt's MFMAs.
+        // Fragments of k-steps 0-1 of the next tile are read behind the barrier and land while k-steps 2-3 of this
+        // tile run; fragments of k-steps 2-3 are read at the top and land while k-steps 0-1 run.  The MFMA stream of
+        // a wave is then continuous -- the plain loop pays the LDS latency (~250 cycles) once per K tile with the
+        // matrix pipe idle.  All three stages are in flight: tile kt+3 refills the stage of tile kt as soon as every
+        // wave is past the barrier (its k-step 2-3 reads are complete by then: explicit lgkmcnt(0)).
+        static_assert(!PIPE || STAGES == 3, "the pipelined loop is written for a 3-stage ring");
+        issue(0);
+        if (1 < KT) { advance(); issue(1); }
+        if (2 < KT) { advance(); issue(2); }
+        { const int younger = min(KT - 1, 2); if (younger == 2) WAIT_VMCNT(2 * LD); else if (younger == 1) WAIT_VMCNT(LD); else WAIT_VMCNT(0); }
+        __builtin_amdgcn_s_barrier();
+        if (a.dbg) tq1 = __builtin_readcyclecounter();
+        bf16x8 fa[4][FI], fb[4][FJ];
+        auto read_half = [&](int st, int h) {
+            const unsigned char* wb = smem + st * TILE;
+            const unsigned char* xb = wb + BC * 128;
+#pragma unroll
+            for (int kk = 2 * h; kk < 2 * h + 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < FI; ++i) {
+                    int r = wc * (BC / WC) + i * 32 + lrow;
+                    fa[kk][i] = *(const bf16x8*)(wb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    int r = wp * (BP / WP) + j * 32 + lrow;
+                    fb[kk][j] = *(const bf16x8*)(xb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
+                }
+            }
+        };
+        auto mfma_half = [&](int h) {
+#pragma unroll
+            for (int kk = 2 * h; kk < 2 * h + 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        };
+        read_half(0, 0);
+        // (the last tile is peeled: a branch around the barrier block would merge two different LDS-counter states
+        // and make the compiler wait for the NEXT tile's fragments before this tile's second half)
+        for (int kt = 0; kt + 1 < KT; ++kt) {
+            const int nxt = (stage == 2) ? 0 : stage + 1;
+            read_half(stage, 1);
+            mfma_half(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this tile's k-step 2-3 fragments are in registers
+            if (kt + 2 < KT) WAIT_VMCNT(LD); else WAIT_VMCNT(0);        // tile kt+1 landed (kt+2 may still fly)
+            __builtin_amdgcn_s_barrier();
+            if (kt + 3 < KT) { advance(); issue(stage); }               // tile kt+3 -> the stage tile kt vacated
+            read_half(nxt, 0);
+            mfma_half(1);
+            stage = nxt;
+        }
+        read_half(stage, 1);
+        mfma_half(0);
+        mfma_half(1);
+    } else {
     issue(0);
 #pragma unroll
     for (int p = 1; p < STAGES - 1; ++p)
         if (p < KT) { advance(); issue(p); }
-    const int lrow = lane & 31, lk = lane >> 5;
-    int stage = 0;
+    bf16x8 af[4][FI], bfr[4][FJ];
     for (int kt = 0; kt < KT; ++kt) {
         // tile kt has landed once only the loads of the (up to STAGES-2) younger tiles are outstanding
         const int younger = min(KT - 1 - kt, STAGES - 2);
@@ -203,7 +264,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         const unsigned char* xb = wb + BC * 128;
         // all fragments of the K tile are fetched up front (4 k-steps x (FI+FJ) x 16 B per lane), then the MFMAs
         // run back to back: the LDS latency is paid once per K tile instead of once per k-step
-        bf16x8 af[4][FI], bfr[4][FJ];
+        if (!(a.skip & 8) || kt == 0) {       // (tuning: bit 8 keeps the first tile's fragments -> MFMA without LDS reads)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -217,6 +278,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
                 bfr[kk][j] = *(const bf16x8*)(xb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
             }
         }
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -229,6 +291,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
             issue(stage >= 1 ? stage - 1 : STAGES - 1);
         }
         stage = (stage == STAGES - 1) ? 0 : stage + 1;
+    }
     }
     __syncthreads();
     if (a.dbg) tq2 = __builtin_readcyclecounter();
@@ -380,16 +443,18 @@ static int pick_tile(long long M, int Cout, long long ktot, int rows_per_group, 
     bc = (Cout <= 64) ? 64 : 128;
     bp = 64;
     int waves = 4;
-    int t82 = 512;
+    int t82 = 512, t83 = 256;
     if (const char* e = getenv("RGDA_T82")) t82 = atoi(e);     // tuning experiments only
+    if (const char* e = getenv("RGDA_T83")) t83 = atoi(e);     // tuning experiments only
     if (bc == 128 && ktot >= 4096 && (long long)cdiv(M, 256) * cdiv(Cout, bc) >= 240) { bp = 256; waves = 8; }
     else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= t82) { bp = 128; waves = 8; }
+    else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= t83) { bp = 128; waves = 9; }
     if (rows_per_group) {
         while (bp > 64 && (rows_per_group % bp)) bp >>= 1;
         if (rows_per_group % bp) return 1;
     }
     stages = (bc == 64) ? 2 : 3;
-    if (waves == 8 && bp >= 128) stages = (bp == 256) ? 83 : 82;
+    if (waves >= 8 && bp >= 128) stages = (bp == 256 || waves == 9) ? 83 : 82;
     return 0;
 }
 
@@ -450,7 +515,11 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
     a.tiles_c = cdiv(Cout, bc);
     a.tiles_p = cdiv(M, bp);
     int grid = a.tiles_c * a.tiles_p;
-    if (bc == 128 && bp == 128 && stages == 83) conv_igemm_kernel<128, 128, 3, 2, 4><<<grid, 512, 0, st>>>(a);
+    static const bool pipe = getenv("RGDA_NO_PIPE") == nullptr;                           // (off switch: tuning experiments only)
+    if (pipe && bc == 128 && bp == 128 && stages == 83) conv_igemm_kernel<128, 128, 3, 2, 4, true><<<grid, 512, 0, st>>>(a);
+    else if (pipe && bc == 128 && bp == 256 && stages == 83) conv_igemm_kernel<128, 256, 3, 2, 4, true><<<grid, 512, 0, st>>>(a);
+    else if (pipe && bc == 128 && bp == 64 && stages == 3) conv_igemm_kernel<128, 64, 3, 2, 2, true><<<grid, 256, 0, st>>>(a);
+    else if (bc == 128 && bp == 128 && stages == 83) conv_igemm_kernel<128, 128, 3, 2, 4><<<grid, 512, 0, st>>>(a);
     else if (bc == 128 && bp == 128 && stages == 82) conv_igemm_kernel<128, 128, 2, 2, 4><<<grid, 512, 0, st>>>(a);
     else if (bc == 128 && bp == 256 && stages == 83) conv_igemm_kernel<128, 256, 3, 2, 4><<<grid, 512, 0, st>>>(a);
     else if (bc == 128 && bp == 256) conv_igemm_kernel<128, 256, 3><<<grid, 256, 0, st>>>(a);

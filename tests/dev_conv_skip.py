@@ -22,10 +22,10 @@ for (N, H, W, Ci, Co, k, p, d) in [(16, 32, 32, 256, 256, 3, 1, 1), (16, 32, 32,
         os.environ['RGDA_TILE'] = tile
         line = '%-26s %-11s KT=%-4d' % ((M, Ci, Co, k), tile, KT)
         ts = []
-        for skip in ('0', '1', '2', '4'):
+        for skip in ('0', '1', '2', '8', '9'):
             os.environ['RGDA_CONV_SKIP'] = skip
             ts.append(bench(lambda: ops.conv2d(x, w, y, N, H, W, H, W, k, k, 1, p, d, 0)))
         os.environ.pop('RGDA_CONV_SKIP')
-        line += ' full %7.1f | no-DMA %7.1f | no-compute %7.1f | DMA-after-MFMA %7.1f us  -> per K tile (ns): full %5.0f compute %5.0f dma %5.0f loop %5.0f' % (
-            ts[0], ts[1], ts[2], ts[3], (ts[0] - ts[3]) / KT * 1e3 + ts[3] / KT * 0, (ts[1] - ts[3]) / KT * 1e3, (ts[2] - ts[3]) / KT * 1e3, 0)
+        line += ' full %7.1f | no-DMA %7.1f | no-compute %7.1f | DMA+MFMA(no LDS reads) %7.1f | MFMA only %7.1f us  -> per K tile (ns): full %5.0f compute %5.0f dma %5.0f loop %5.0f' % (
+            ts[0], ts[1], ts[2], ts[3], ts[4], 0, 0, 0, 0)
         print(line)

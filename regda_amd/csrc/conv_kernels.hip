@@ -729,57 +729,85 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
     unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
     if (a.dbg) tq0 = __builtin_readcyclecounter();
     if (kt_beg < kt_end) {
-        // the operands stream from HBM / the Infinity Cache (~2300 cycles away): STAGES - 1 tiles stay in flight
-#pragma unroll
-        for (int s0 = 0; s0 < STAGES - 1; ++s0)
-            if (kt_beg + s0 < kt_end) issue(kt_beg + s0, s0);
         // transposing-read lane geometry: 16-lane group g reads a [4 k][16 col] block
         const int g = lane >> 4, la = lane & 15;
         const int krow = (g >> 1) * 8 + (la >> 2);          // + kk*16 (+4 for the second half)
         const int kcol2 = ((g & 1) * 16 + (la & 3) * 4) * 2;  // byte offset inside a 64-byte granule pair
-        int stage = 0;
-        for (int kt = kt_beg; kt < kt_end; ++kt) {
-            wait_tiles_in_flight<LD>(min(STAGES - 2, kt_end - 1 - kt));
-            __builtin_amdgcn_s_barrier();
-            if (a.dbg && kt == kt_beg) tq1 = __builtin_readcyclecounter();
-            if (kt + STAGES - 1 < kt_end) issue(kt + STAGES - 1, stage >= 1 ? stage - 1 : STAGES - 1);
-            const unsigned char* ab = smem + stage * TILE;
+        bf16x8 af[4][FI], bfr[4][FJ];
+        auto tr_pair = [&](const unsigned char* base, int rowbytes, int byte, int r0) {
+            const int r1 = r0 + 4;
+            int f0 = (rowbytes == 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (rowbytes == 256) ? (r1 & 3) : ((r1 >> 1) & 1);
+            const unsigned char* p0 = base + r0 * rowbytes + ((((byte >> 6) ^ f0) << 6) | (byte & 63));
+            const unsigned char* p1 = base + r1 * rowbytes + ((((byte >> 6) ^ f1) << 6) | (byte & 63));
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+            u16x8 v8 = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                        (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+            return __builtin_bit_cast(bf16x8, v8);
+        };
+        auto read_half = [&](int st, int h) {
+            const unsigned char* ab = smem + st * TILE;
             const unsigned char* bb = ab + TA;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 af[FI], bfr[FJ];
-                const int r0 = kk * 16 + krow, r1 = r0 + 4;
+            for (int kk = 2 * h; kk < 2 * h + 2; ++kk) {
+                const int r0 = kk * 16 + krow;
 #pragma unroll
-                for (int i = 0; i < FI; ++i) {
-                    int byte = (wi * (BCO / WI) + i * 32) * 2 + kcol2;          // column byte offset in the row
-                    int f0 = (RA == 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (RA == 256) ? (r1 & 3) : ((r1 >> 1) & 1);
-                    const unsigned char* p0 = ab + r0 * RA + ((((byte >> 6) ^ f0) << 6) | (byte & 63));
-                    const unsigned char* p1 = ab + r1 * RA + ((((byte >> 6) ^ f1) << 6) | (byte & 63));
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
-                    u16x8 v8 = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
-                                (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
-                    af[i] = __builtin_bit_cast(bf16x8, v8);
-                }
+                for (int i = 0; i < FI; ++i) af[kk][i] = tr_pair(ab, RA, (wi * (BCO / WI) + i * 32) * 2 + kcol2, r0);
 #pragma unroll
-                for (int j = 0; j < FJ; ++j) {
-                    int byte = (wj * (BCI / WJ) + j * 32) * 2 + kcol2;
-                    int f0 = (RB == 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (RB == 256) ? (r1 & 3) : ((r1 >> 1) & 1);
-                    const unsigned char* p0 = bb + r0 * RB + ((((byte >> 6) ^ f0) << 6) | (byte & 63));
-                    const unsigned char* p1 = bb + r1 * RB + ((((byte >> 6) ^ f1) << 6) | (byte & 63));
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
-                    u16x8 v8 = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
-                                (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
-                    bfr[j] = __builtin_bit_cast(bf16x8, v8);
-                }
+                for (int j = 0; j < FJ; ++j) bfr[kk][j] = tr_pair(bb, RB, (wj * (BCI / WJ) + j * 32) * 2 + kcol2, r0);
+            }
+        };
+        auto mfma_half = [&](int h) {
+#pragma unroll
+            for (int kk = 2 * h; kk < 2 * h + 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < FI; ++i)
 #pragma unroll
                     for (int j = 0; j < FJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+        };
+        int stage = 0;
+        if constexpr (STAGES == 3) {
+            // software-pipelined like conv_igemm_kernel<..., PIPE>: all three stages in flight, the barrier of tile
+            // kt+1 between the two halves of tile kt's MFMAs, the last tile peeled
+#pragma unroll
+            for (int s0 = 0; s0 < 3; ++s0)
+                if (kt_beg + s0 < kt_end) issue(kt_beg + s0, s0);
+            wait_tiles_in_flight<LD>(min(2, kt_end - 1 - kt_beg));
+            __builtin_amdgcn_s_barrier();
+            if (a.dbg) tq1 = __builtin_readcyclecounter();
+            read_half(0, 0);
+            for (int kt = kt_beg; kt + 1 < kt_end; ++kt) {
+                const int nxt = (stage == 2) ? 0 : stage + 1;
+                read_half(stage, 1);
+                mfma_half(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every wave's reads of this tile are complete
+                wait_tiles_in_flight<LD>(min(1, kt_end - 2 - kt));       // tile kt+1 landed (kt+2 may still fly)
+                __builtin_amdgcn_s_barrier();
+                if (kt + 3 < kt_end) issue(kt + 3, stage);
+                read_half(nxt, 0);
+                mfma_half(1);
+                stage = nxt;
             }
-            stage = (stage == STAGES - 1) ? 0 : stage + 1;
+            read_half(stage, 1);
+            mfma_half(0);
+            mfma_half(1);
+        } else {
+            // the operands stream from HBM / the Infinity Cache (~2300 cycles away): STAGES - 1 tiles stay in flight
+#pragma unroll
+            for (int s0 = 0; s0 < STAGES - 1; ++s0)
+                if (kt_beg + s0 < kt_end) issue(kt_beg + s0, s0);
+            for (int kt = kt_beg; kt < kt_end; ++kt) {
+                wait_tiles_in_flight<LD>(min(STAGES - 2, kt_end - 1 - kt));
+                __builtin_amdgcn_s_barrier();
+                if (a.dbg && kt == kt_beg) tq1 = __builtin_readcyclecounter();
+                if (kt + STAGES - 1 < kt_end) issue(kt + STAGES - 1, stage >= 1 ? stage - 1 : STAGES - 1);
+                read_half(stage, 0);
+                read_half(stage, 1);
+                mfma_half(0);
+                mfma_half(1);
+                stage = (stage == STAGES - 1) ? 0 : stage + 1;
+            }
         }
     }
     // ---- split-K reduction: fp32 atomics straight into the gradient buffer (128 B per half-wave).
@@ -915,6 +943,8 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradGroup g) {
                         (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
             return __builtin_bit_cast(bf16x8, v8);
         };
+        // (a software-pipelined variant of this loop, like conv_igemm_kernel<..., PIPE>, measured 8-10 % SLOWER here:
+        // with 9 MFMAs per 20 transposing reads the compiler's own interleaving already hides the LDS latency)
         int stage = 0;
         for (int kt = kt_beg; kt < kt_end; ++kt) {
             if (kt + 1 < kt_end) WAIT_VMCNT(LD); else WAIT_VMCNT(0);

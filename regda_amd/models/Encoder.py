@@ -16,6 +16,8 @@ gradient buffer (what the RCCL all-reduce and the fused SGD kernel work on).
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -153,7 +155,10 @@ class Deeplabv2(nn.Module):
         # weight gradients are collected and launched in groups (rgda_conv2d_wgrad_grouped) once this much work
         # is pending; 0 = one launch per layer
         self.wgrad_group_gflop = 250.0
-        self.relu_sign_mask = False  # keep ReLU sign bits for the backward pass instead of re-reading y
+        # keep ReLU sign bits (1/16 of y) for the backward pass instead of re-reading y, for units with at least this
+        # many channels (0 / False = never, True = always).  Pays only where y is big: the 1024-channel bn3 outputs,
+        # whose BN-backward operands make the fused data-gradient epilogue HBM-bound (-0.1 ms/step)
+        self.relu_sign_mask = 1024
         self._mat_cache = {}
         self._synced_version = -1
         self.sync_weights()
@@ -423,11 +428,10 @@ class Deeplabv2(nn.Module):
         if train:
             if M // G < 2:
                 raise ValueError('Expected more than 1 value per channel when training')
-            # optional: the backward pass needs only the SIGN of y (ReLU), one bit per element written next to y.
-            # Measured on MI355X it does not pay (the BN-backward kernels are not read-bandwidth bound and the
-            # byte stores cost the forward ~2 us per launch), so it is off by default.
+            # the backward pass needs only the SIGN of y (ReLU): one bit per element written next to y.  The byte
+            # stores cost the forward ~2 us per launch, so only wide units do it (see relu_sign_mask).
             rmask = (torch.empty(M, conv.co // 8, dtype=torch.uint8, device=self.device)
-                     if (relu and self.relu_sign_mask) else None)
+                     if (relu and self.relu_sign_mask and conv.co >= self.relu_sign_mask) else None)
             ops.bn_train_apply(c, stats, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale,
                                Ho * Wo, groups=G, relu_mask=rmask)
         else:

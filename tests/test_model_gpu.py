@@ -249,6 +249,7 @@ def test_relu_sign_mask_mode_gives_identical_gradients():
     g1, g2 = torch.randn(4, 6, 4, 4, generator=gen).cuda(), torch.randn(4, 6, 4, 4, generator=gen).cuda()
     ones = torch.ones(2, 512)
     out = []
+    default = m.relu_sign_mask
     for flag in (False, True):
         m.load_state_dict(sd, strict=True)
         m.train()
@@ -260,6 +261,6 @@ def test_relu_sign_mask_mode_gives_identical_gradients():
             c1, c2, f = m._forward_plan(x, T)
             m._backward_plan(T, g1, g2)
         out.append((c1.clone(), c2.clone(), m.flat_g.clone()))
-    m.relu_sign_mask = False
+    m.relu_sign_mask = default
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert l2(out[1][2], out[0][2]) < 1e-4

@@ -1,7 +1,10 @@
 """List the PyTorch-native kernels (at::native...) of a rocprofv3 kernel-trace database with counts per step."""
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); steps = float(sys.argv[2])
-rows = db.execute('select name, grid_x, workgroup_x, (end - start) from kernels').fetchall()
+allr = db.execute('select name, grid_x, workgroup_x, (end - start), start, end from kernels order by start').fetchall()
+marks = [r[5] for r in allr if 'sgd_step_kernel' in r[0]]
+steps = min(int(steps), len(marks) - 1)
+rows = [r[:4] for r in allr if r[4] >= marks[-1 - steps] and r[5] <= marks[-1]]
 agg = {}
 for n, gx, wx, d in rows:
     if 'at::native' not in n and 'rocclr' not in n: continue

@@ -76,6 +76,22 @@ def upsample_matrix(h, w, H, W):
     return U
 
 
+def ppm_tap_matrix(h, w, s):
+    """The 3x3 / pad-1 head conv applied to a bilinearly upsampled s x s map q is linear in q, and the channel
+    mixing commutes with the spatial mixing:  conv(U q)[p] = sum_tap sum_j U[p + d_tap][j] * (W_tap q[j]).
+    Returns V [h*w, 9*s*s] with V[p][j*9 + tap] = U[p + d_tap][j] (0 where p + d_tap is padding), so that
+    conv(U q) = V @ Z with Z[j*9 + tap] = W_tap q[j] computed at LOW resolution (Encoder.py:30-51 restated)."""
+    U = upsample_matrix(s, s, h, w).view(h, w, s * s)
+    V = torch.zeros(h, w, s * s, 9)
+    for kh in range(3):
+        for kw in range(3):
+            dy, dx = kh - 1, kw - 1
+            y0, y1 = max(0, -dy), min(h, h - dy)
+            x0, x1 = max(0, -dx), min(w, w - dx)
+            V[y0:y1, x0:x1, :, kh * 3 + kw] = U[y0 + dy:y1 + dy, x0 + dx:x1 + dx, :]
+    return V.reshape(h * w, s * s * 9).contiguous()
+
+
 # ----------------------------------------------------------------------------- parameter specs
 def _block_specs(resnet_type):
     """[(prefix, inplanes, planes, stride, dilation, has_downsample)] at output stride 16
@@ -281,6 +297,21 @@ class Deeplabv2(nn.Module):
         self._wt_blocks = blk
         self.stem_wb = torch.zeros(64, 1, STEM_KP, dtype=BF, device=dev)
         self.stem_gtmp = torch.zeros(64, 1, STEM_KP, device=dev)
+        # head 3x3 conv (4096 -> 512) split into its feature half and the four PPM branches (see ppm_tap_matrix):
+        #   wfeat [512][9][2048]            the feature-map half, contiguous
+        #   wz[i] [9*512][1][512]           Z = q_i @ W_tap^T for all nine taps at once (a 1x1 conv, Cout = 4608)
+        #   wzt[i] [512][1][9*512]          its transpose, for the gradient w.r.t. q_i
+        #   gfeat / gz[i]                   fp32 landing buffers of the two kinds of weight gradient
+        self.head_w = {}
+        for head in ('layer5', 'layer6'):
+            self.head_w[head] = {
+                'wfeat': torch.zeros(512, 9, 2048, dtype=BF, device=dev),
+                'wz': [torch.zeros(9 * 512, 1, 512, dtype=BF, device=dev) for _ in POOL_SCALES],
+                'wzt': [torch.zeros(512, 1, 9 * 512, dtype=BF, device=dev) for _ in POOL_SCALES],
+                'gfeat': torch.zeros(512, 9, 2048, device=dev),
+                'gz': [torch.zeros(9 * 512, 1, 512, device=dev) for _ in POOL_SCALES],
+            }
+        self._hw_ready = None
 
     def _init_weights(self):
         """kaiming_normal_(fan_out, relu) convs, BN weight 1 / bias 0 (_resnets.py:164-169); heads keep the
@@ -319,12 +350,26 @@ class Deeplabv2(nn.Module):
         ops.pad_cast_bf16(s.w, self.stem_wb, 64, 147, STEM_KP)
         if side_stream is None:
             ops.weight_transpose_batched(self._wt_table, self._wt_table.shape[0], self._wt_blocks)
-            self._wt_ready = None
+            self._sync_head_weights(True)
+            self._wt_ready = self._hw_ready = None
         else:
             side_stream.wait_event(torch.cuda.current_stream().record_event())
             with ops.use_stream(side_stream):
+                self._sync_head_weights(True)
+                self._hw_ready = side_stream.record_event()         # needed by the next forward's heads
                 ops.weight_transpose_batched(self._wt_table, self._wt_table.shape[0], self._wt_blocks)
-            self._wt_ready = side_stream.record_event()
+            self._wt_ready = side_stream.record_event()              # needed by the next backward
+
+    def _sync_head_weights(self, with_transposes):
+        """Re-slice the head convs' bf16 mirror (layout copies only: torch strided copy_)."""
+        for head, hw in self.head_w.items():
+            w = self.convs[f'{head}.conv_last.0'].wb            # [512][9][4096]
+            hw['wfeat'].copy_(w[:, :, :2048])
+            for i in range(len(POOL_SCALES)):
+                sl = w[:, :, 2048 + 512 * i: 2048 + 512 * (i + 1)]       # [co][tap][ci]
+                hw['wz'][i].view(9, 512, 512).copy_(sl.permute(1, 0, 2))
+                if with_transposes:
+                    hw['wzt'][i].view(512, 9, 512).copy_(sl.permute(2, 1, 0))
 
     def _maybe_sync(self):
         if self.flat_p._version != self._synced_version:
@@ -370,6 +415,7 @@ class Deeplabv2(nn.Module):
         ops.cast_bf16(self.flat_p, self.flat_pb)
         s = self.convs['encoder.resnet.conv1']
         ops.pad_cast_bf16(s.w, self.stem_wb, 64, 147, STEM_KP)
+        self._sync_head_weights(False)
         self._synced_version = self.flat_p._version
 
     def set_drop_masks(self, m5, m6):
@@ -384,24 +430,27 @@ class Deeplabv2(nn.Module):
             for s in POOL_SCALES:
                 P = pool_matrix(h, w, s)
                 U = upsample_matrix(s, s, h, w)
-                d[s] = tuple(t.to(self.device).contiguous() for t in (P, P.t(), U, U.t()))
+                V = ppm_tap_matrix(h, w, s)
+                d[s] = tuple(t.to(self.device).contiguous() for t in (P, P.t(), U, U.t(), V, V.t()))
             self._mat_cache[key] = d
         return self._mat_cache[key]
 
-    def _conv_stats(self, x, w, c, stats, G, N, H, W, Ho, Wo, k, stride, pad, dil):
-        """Forward conv with BatchNorm statistics per row group; falls back to one launch per group when the
-        groups are not a multiple of the pixel tile (tiny PPM maps)."""
+    def _conv_stats(self, x, w, c, stats, G, N, H, W, Ho, Wo, k, stride, pad, dil, res=None):
+        """Forward conv (+ `res` added in the epilogue, before the statistics) with BatchNorm statistics per row
+        group; falls back to one launch per group when the groups are not a multiple of the pixel tile (tiny PPM
+        maps)."""
         if G == 1 or stats is None:
-            ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, None, stats, 1)
+            ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, res, stats, 1)
             return
         try:
-            ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, None, stats, G)
+            ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, res, stats, G)
         except ValueError:
             Ng, C = N // G, c.shape[1]
             st = stats.view(G, -1)
             for g in range(G):
-                ops.conv2d(x[g * Ng * H * W:(g + 1) * Ng * H * W], w, c[g * Ng * Ho * Wo:(g + 1) * Ng * Ho * Wo], Ng, H,
-                           W, Ho, Wo, k, k, stride, pad, dil, 0, None, st[g], 1)
+                ro = slice(g * Ng * Ho * Wo, (g + 1) * Ng * Ho * Wo)
+                ops.conv2d(x[g * Ng * H * W:(g + 1) * Ng * H * W], w, c[ro], Ng, H,
+                           W, Ho, Wo, k, k, stride, pad, dil, 0, None if res is None else res[ro], st[g], 1)
 
     def _cbr_fwd(self, T, key, conv, bn, x, N, H, W, relu, res=None, nscale=None, wb=None, geom=None):
         Ho, Wo = conv.out_hw(H, W) if geom is None else geom
@@ -441,6 +490,86 @@ class Deeplabv2(nn.Module):
             T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale, rmask)
         return y, Ho, Wo
 
+    def _head_last_fwd(self, T, head, xn, qs, N, h, w, nscale):
+        """conv_last.0 (3x3, 4096 -> 512) + BN + ReLU (+ Dropout2d scale) of a PPM head WITHOUT materialising the
+        4096-channel concat (Encoder.py:30-51): the feature half is a 3x3 conv over the 2048 instance-normalised
+        channels; the four upsampled PPM branches contribute  V_i @ (q_i W_i^T)  (ppm_tap_matrix), i.e. four tiny
+        1x1 convs at s x s resolution and one spatial mix, added in the feature conv's epilogue before the BN
+        statistics.  Exactly the reference arithmetic re-associated; half the FLOPs of the head conv."""
+        C, B = self.convs, self.bns
+        conv, bn = C[f'{head}.conv_last.0'], B[f'{head}.conv_last.1']
+        hw = self.head_w[head]
+        dev = self.device
+        HW, M = h * w, N * h * w
+        mats = self._mats(h, w)
+        zs = []
+        for i, s in enumerate(POOL_SCALES):
+            z = torch.empty(N * s * s, 9 * 512, dtype=BF, device=dev)
+            ops.conv2d(qs[i], hw['wz'][i], z, N, s, s, s, s, 1, 1, 1, 0, 1)
+            zs.append(z.view(N * s * s * 9, 512))
+        ppm = torch.empty(M, 512, dtype=BF, device=dev)
+        ops.spatial_mix_multi(zs, [mats[s][4] for s in POOL_SCALES], ppm, N, HW, 512)
+        train = T is not None
+        G = T['groups'] if train else 1
+        c = torch.empty(M, 512, dtype=BF, device=dev)
+        stats = T['stats_pool'].take(G * NREP * 2 * 512) if train else None
+        self._conv_stats(xn, hw['wfeat'], c, stats, G, N, h, w, h, w, 3, 1, 1, 1, res=ppm)
+        mi = torch.empty(G, 2, 512, device=dev)
+        y = torch.empty(M, 512, dtype=BF, device=dev)
+        if train:
+            ops.bn_train_apply(c, stats, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, y, M, 512, True, None, nscale,
+                               HW, groups=G)
+            T[f'{head}.last'] = (xn, c, y, mi, (N, h, w, h, w), nscale, None)
+            T[f'{head}.last.q'] = qs
+        else:
+            ops.bn_finalize(None, mi, bn.rm, bn.rv, None, M, 512)
+            ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, 512, True, None, nscale, HW, groups=G)
+        return y
+
+    def _head_last_bwd(self, T, head, g, dfeat_prev):
+        """Backward of _head_last_fwd: BN backward, then dW / dX of the feature half as an ordinary 3x3 conv over 2048
+        channels and, per PPM branch, dZ_i = V_i^T @ dc (a pooling with the tap-shifted bilinear weights),
+        dq_i = dZ_i W_i and dW_i = dZ_i^T q_i at s x s resolution.  Returns (dfeat [M,2048], [dq_i])."""
+        C, B = self.convs, self.bns
+        conv, bn = C[f'{head}.conv_last.0'], B[f'{head}.conv_last.1']
+        hw = self.head_w[head]
+        dev = self.device
+        key = f'{head}.last'
+        xn, c, y, mi, (N, h, w, _, _), nscale, _ = T[key]
+        qs = T[key + '.q']
+        HW, M, G = h * w, N * h * w, T['groups']
+        mats = self._mats(h, w)
+        sums = T['sums_pool'].take(G * NREP * 2 * 512)
+        ops.bn_bwd_reduce(g, y, c, mi, sums, M, 512, True, nscale, HW, groups=G)
+        dc = torch.empty(M, 512, dtype=BF, device=dev)
+        ops.bn_bwd_apply(g, y, c, mi, bn.gamma, sums, dc, M, 512, True, None, bn.dgamma, bn.dbeta, nscale, HW, groups=G)
+        gview = conv.g.view(512, 9, 4096)
+        # weight gradients land in contiguous fp32 buffers (the kernels write [Cout][taps][Cin] densely) and are
+        # added into the strided slices of the real gradient behind the grouped launch
+        hw['gfeat'].zero_()
+        T['wgrad_pending'].append((xn, dc, hw['gfeat'], N, h, w, h, w, 3, 3, 1, 1, 1))
+        T['wgrad_pending_flop'] += 2.0 * M * 512 * 2048 * 9
+        T['wgrad_post'].append(lambda gv=gview, t=hw['gfeat']: gv[:, :, :2048].add_(t))
+        dfeat = torch.empty(M, 2048, dtype=BF, device=dev)
+        ops.conv2d(dc, conv.wtb[:2048], dfeat, N, h, w, h, w, 3, 3, 1, 1, 1, 1, dfeat_prev, None)
+        dqs = []
+        for i, s in enumerate(POOL_SCALES):
+            dz = torch.empty(N * s * s * 9, 512, dtype=BF, device=dev)
+            ops.spatial_mix(dc, mats[s][5], dz, N, 9 * s * s, HW, 512)
+            dzr = dz.view(N * s * s, 9 * 512)
+            dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
+            ops.conv2d(dzr, hw['wzt'][i], dq, N, s, s, s, s, 1, 1, 1, 0, 1)
+            hw['gz'][i].zero_()
+            T['wgrad_pending'].append((qs[i], dzr, hw['gz'][i], N, s, s, s, s, 1, 1, 1, 0, 1))
+            T['wgrad_post'].append(lambda gv=gview, t=hw['gz'][i], i=i:
+                                   gv[:, :, 2048 + 512 * i: 2048 + 512 * (i + 1)].add_(t.view(9, 512, 512).permute(1, 0, 2)))
+            T['keep'].append((dz, dq))
+            dqs.append(dq)
+        T['keep'].append((dc, dfeat))
+        if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
+            self._flush_wgrads(T)
+        return dfeat, dqs
+
     def _flush_wgrads(self, T):
         """Launch the queued weight gradients (grouped by kernel) -- on the second HIP stream when there is one,
         next to the BN-backward / data-gradient chain of the layers below, which is the critical path -- and
@@ -457,6 +586,16 @@ class Deeplabv2(nn.Module):
                 # keep the operands alive until the streams join (no record_stream: the step must stay
                 # capturable into a hipGraph)
                 T['keep'].extend((it[0], it[1]) for it in pend)
+            post = T.get('wgrad_post')
+            if post:        # strided adds of densely written gradients (head convs), behind the launch that made them
+                if side is None:
+                    for fn in post:
+                        fn()
+                else:
+                    with ops.use_stream(side):
+                        for fn in post:
+                            fn()
+                T['wgrad_post'] = []
             T['wgrad_pending'] = []
             T['wgrad_pending_flop'] = 0.0
         off = T.pop('progress_deferred', None)
@@ -561,10 +700,13 @@ class Deeplabv2(nn.Module):
             if dbg is not None:
                 dbg[p] = y.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
         HW, M = h * w, N * h * w
-        cats = [torch.empty(M, 4096, dtype=BF, device=dev) for _ in range(2)]
+        xn = torch.empty(M, 2048, dtype=BF, device=dev)          # instance-normalised features, shared by both heads
         feat = torch.empty(N, 2048, h, w, device=dev)
         imi = torch.empty(N, 2, 2048, device=dev)
-        ops.instnorm_fwd(y, cats[0][:, :2048], cats[1][:, :2048], feat, imi, N, HW, 2048)
+        ops.instnorm_fwd(y, xn, None, feat, imi, N, HW, 2048)
+        if self._hw_ready is not None:                             # head weight slices rebuilt on another stream
+            torch.cuda.current_stream().wait_event(self._hw_ready)
+            self._hw_ready = None
         if T is not None:
             T['inorm'] = (y, imi, (N, h, w))
         mats = self._mats(h, w)
@@ -579,22 +721,18 @@ class Deeplabv2(nn.Module):
         pooled_all = []
         for s in POOL_SCALES:       # both heads pool the same instance-normalised map: do it once
             pooled = torch.empty(N * s * s, 2048, dtype=BF, device=dev)
-            ops.spatial_mix(cats[0][:, :2048], mats[s][0], pooled, N, s * s, HW, 2048)
+            ops.spatial_mix(xn, mats[s][0], pooled, N, s * s, HW, 2048)
             pooled_all.append(pooled)
         for hi, head in enumerate(('layer5', 'layer6')):
-            cat = cats[hi]
+            qs = []
             for i, s in enumerate(POOL_SCALES):
-                P, Pt, U, Ut = mats[s]
-                pooled = pooled_all[i]
-                q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'], pooled,
-                                        N, s, s, True)
-                ops.spatial_mix(q, U, cat[:, 2048 + 512 * i: 2048 + 512 * (i + 1)], N, HW, s * s, 512)
+                q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
+                                        pooled_all[i], N, s, s, True)
+                qs.append(q)
                 if dbg is not None:
                     dbg[f'{head}.q{i}'] = q.float().reshape(N, s, s, -1).permute(0, 3, 1, 2)
-            hid, _, _ = self._cbr_fwd(T, f'{head}.last', C[f'{head}.conv_last.0'], B[f'{head}.conv_last.1'], cat, N,
-                                      h, w, True, nscale=masks[hi])
+            hid = self._head_last_fwd(T, head, xn, qs, N, h, w, masks[hi])
             if dbg is not None:
-                dbg[head + '.cat'] = cat.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
                 dbg[head + '.hidden'] = hid.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
             cl = C[f'{head}.conv_last.4']
             lg = torch.empty(N, self.num_classes, h, w, device=dev)
@@ -611,13 +749,13 @@ class Deeplabv2(nn.Module):
             torch.cuda.current_stream().wait_event(self._wt_ready)
             self._wt_ready = None
         T['on_progress'] = on_progress
-        T['wgrad_pending'], T['wgrad_pending_flop'] = [], 0.0
+        T['wgrad_pending'], T['wgrad_pending_flop'], T['wgrad_post'] = [], 0.0, []
         T['sums_pool'] = _StatsPool(sum(T['groups'] * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)
         C, B = self.convs, self.bns
         y4, imi, (N, h, w) = T['inorm']
         HW, M = h * w, N * h * w
         mats = self._mats(h, w)
-        dcats = []
+        dfeat = None
         dpools = [None] * len(POOL_SCALES)
         dbg = getattr(self, '_debug_grads', None)
 
@@ -629,23 +767,19 @@ class Deeplabv2(nn.Module):
             dh = torch.empty(M, 512, dtype=BF, device=dev)
             ops.classifier_bwd(hid, cl.w.view(cl.co, cl.ci), gl.contiguous().float(), dh, cl.g.view(cl.co, cl.ci),
                                cl.gbias, N, HW, 512, self.num_classes)
-            dcat, _ = self._cbr_bwd(T, f'{head}.last', C[f'{head}.conv_last.0'], B[f'{head}.conv_last.1'], dh, True)
+            # the second head's feature gradient is added onto the first head's in the conv epilogue
+            dfeat, dqs = self._head_last_bwd(T, head, dh, dfeat)
             if dbg is not None:
                 dbg[head + '.hidden'] = nchw(dh, h, w)
-                dbg[head + '.cat'] = nchw(dcat, h, w)
             for i, s in enumerate(POOL_SCALES):
-                P, Pt, U, Ut = mats[s]
-                dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
-                ops.spatial_mix(dcat[:, 2048 + 512 * i: 2048 + 512 * (i + 1)], Ut, dq, N, s * s, HW, 512)
-                # the second head's data-gradient is added onto the first head's in the conv epilogue
-                dpools[i], _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'], dq,
-                                             True, dx_res=dpools[i])
-            dcats.append(dcat)
+                # ... and so are the gradients of the shared pooled maps
+                dpools[i], _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
+                                             dqs[i], True, dx_res=dpools[i])
         gpool = torch.empty(M, 2048, dtype=BF, device=dev)
         ops.spatial_mix_multi(dpools, [mats[s][1] for s in POOL_SCALES], gpool, N, HW, 2048)
         g = torch.empty(M, 2048, dtype=BF, device=dev)
-        ops.instnorm_bwd(dcats[0][:, :2048], dcats[1][:, :2048], gpool, y4, imi, g, N, HW, 2048)
-        del dcats, gpool
+        ops.instnorm_bwd(dfeat, None, gpool, y4, imi, g, N, HW, 2048)
+        del dfeat, gpool
         self._progress(T, self._offset_of('layer5.ppm.0.1'))
         hh, ww = h, w
         order = [b[0] for b in self.blocks]

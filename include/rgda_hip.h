@@ -281,8 +281,10 @@ int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf1
 
 /* w [Co][T][Ci] f32 -> wt [Ci][T][Co] bf16 (weights for the data-gradient pass). */
 int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, rgda_stream_t stream);
-/* every transpose of a model in one launch: device table[n][6] int64 = {src f32*, dst bf16*, Co, T, Ci,
- * first_block}; a conv owns ceil(Ci/32)*ceil(Co/32)*T consecutive blocks starting at first_block. */
+/* every derived bf16 weight layout of a model in one launch: device table[n][8] int64 = {src f32*, dst bf16*,
+ * Co, T, Ci, first_block, src_ld, mode}.  src element (co,tap,ci) = src[(co*T+tap)*src_ld + ci] (src_ld > Ci: a
+ * channel slice of a wider tensor); mode 0: dst[ci][tap][co] (the data-gradient operand), 1: dst[tap][co][ci],
+ * 2: dst[co][tap][ci].  A row owns ceil(Ci/32)*ceil(Co/32)*T consecutive blocks starting at first_block. */
 int rgda_weight_transpose_batched(const int64_t* table, int n, int64_t total_blocks, rgda_stream_t stream);
 int rgda_cast_bf16(const float* src, void* dst, int64_t n, rgda_stream_t stream);
 /* rows of K f32 -> rows of Kp bf16, zero padded (stem weights [64][147] -> [64][192]); and the

@@ -883,24 +883,59 @@ extern "C" int rgda_spatial_mix(const void* in, int ldin, const float* Mx, void*
 // transposed adaptive-pool maps of the four PPM scales): one pass, one bf16 store per output vector.
 struct MixSrc { const bf16_t* in; const float* Mx; int ldin; int J; };
 struct MixSrc4 { MixSrc s[4]; int n; };
+// Workgroup = (output row i, image n).  The matrix rows of all sources (<= 1024 entries together) are staged in LDS
+// once; the 256 threads are CVB channel vectors x 256/CVB slices of that entry list, zeros are skipped from LDS
+// (the tap-shifted bilinear rows of the PPM heads have <= 117 nonzeros out of 450), slices are summed in a fixed
+// order (deterministic).
+template <int CVB>
 __global__ void __launch_bounds__(256) spatial_mix_multi_kernel(MixSrc4 src, bf16_t* __restrict__ out, int ldout, int I,
                                                                 int C) {
+    constexpr int SL = 256 / CVB;
+    __shared__ float s_w[1024];
+    __shared__ float red[SL][CVB][8];
     const int i = blockIdx.x, n = blockIdx.y;
-    for (int cv = threadIdx.x; cv < C / 8; cv += 256) {
+    int total = 0;
+    for (int q = 0; q < src.n; ++q) {
+        const MixSrc& m = src.s[q];
+        for (int j = threadIdx.x; j < m.J; j += 256) s_w[total + j] = m.Mx[(size_t)i * m.J + j];
+        total += m.J;
+    }
+    __syncthreads();
+    const int cvl = threadIdx.x % CVB, sl = threadIdx.x / CVB;
+    for (int cv0 = 0; cv0 < C / 8; cv0 += CVB) {
+        const int cv = cv0 + cvl;
         float acc[8] = {0};
-        for (int q = 0; q < src.n; ++q) {
-            const MixSrc& m = src.s[q];
-            const float* mrow = m.Mx + (size_t)i * m.J;
-            for (int j = 0; j < m.J; ++j) {
-                float w = mrow[j];
-                if (w == 0.f) continue;
-                float f[8];
-                load8(m.in + ((size_t)n * m.J + j) * m.ldin + cv * 8, f);
+        if (cv < C / 8) {
+            int base = 0;
+            for (int q = 0; q < src.n; ++q) {
+                const MixSrc& m = src.s[q];
+                const bf16_t* in = m.in + (size_t)n * m.J * m.ldin + cv * 8;
+                for (int j = sl; j < m.J; j += SL) {
+                    const float w = s_w[base + j];
+                    if (w == 0.f) continue;
+                    float f[8];
+                    load8(in + (size_t)j * m.ldin, f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w * f[e];
+                    for (int e = 0; e < 8; ++e) acc[e] += w * f[e];
+                }
+                base += m.J;
             }
         }
-        store8(out + ((size_t)n * I + i) * ldout + cv * 8, acc);
+        if (SL > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[sl][cvl][e] = acc[e];
+            __syncthreads();
+            if (sl == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = 0.f;
+                    for (int r = 0; r < SL; ++r) a += red[r][cvl][e];
+                    acc[e] = a;
+                }
+            }
+        }
+        if (sl == 0 && cv < C / 8) store8(out + ((size_t)n * I + i) * ldout + cv * 8, acc);
     }
 }
 
@@ -915,8 +950,14 @@ extern "C" int rgda_spatial_mix_multi(int nsrc, const void* const* ins, const in
         if (!ins[q] || !mats[q] || Js[q] <= 0 || (ldins[q] & 7)) return RGDA_ERR_ARG;
         src.s[q].in = (const bf16_t*)ins[q]; src.s[q].Mx = mats[q]; src.s[q].ldin = ldins[q]; src.s[q].J = Js[q];
     }
+    int jt = 0;
+    for (int q = 0; q < nsrc; ++q) jt += Js[q];
+    if (jt > 1024) return RGDA_ERR_UNSUPPORTED;
     dim3 grid(I, N);
-    spatial_mix_multi_kernel<<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)out, ldout, I, C);
+    if (C / 8 >= 256) spatial_mix_multi_kernel<256><<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)out, ldout, I, C);
+    else if (C / 8 >= 128) spatial_mix_multi_kernel<128><<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)out, ldout, I, C);
+    else if (C / 8 >= 64) spatial_mix_multi_kernel<64><<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)out, ldout, I, C);
+    else spatial_mix_multi_kernel<32><<<grid, 256, 0, to_stream(stream)>>>(src, (bf16_t*)out, ldout, I, C);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -137,20 +137,26 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float* __re
     }
 }
 
-// all transposes of a model in ONE launch: table[n][6] int64 = {src, dst, Co, T, Ci, first_block}, blocks of a
-// conv = ceil(Ci/32) * ceil(Co/32) * T, first_block ascending
+// all derived bf16 weight layouts of a model in ONE launch: table[n][8] int64 =
+//   {src f32*, dst bf16*, Co, T, Ci, first_block, src_ld, mode}
+// src element (co, tap, ci) lives at src[(co*T + tap)*src_ld + ci] (src_ld = Ci for a whole tensor, larger for a
+// channel slice of a wider one); mode 0: dst[ci][tap][co] (data-gradient operand), mode 1: dst[tap][co][ci]
+// (nine 1x1 filters stacked), mode 2: dst[co][tap][ci] (plain slice).  A row owns ceil(Ci/32)*ceil(Co/32)*T
+// consecutive blocks starting at first_block (ascending).
 __global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const long long* __restrict__ table, int n) {
     __shared__ float tile[32][33];
     int lo = 0, hi = n - 1;
     const long long b = blockIdx.x;
     while (lo < hi) {                       // last entry with first_block <= b
         int mid = (lo + hi + 1) >> 1;
-        if (table[mid * 6 + 5] <= b) lo = mid; else hi = mid - 1;
+        if (table[mid * 8 + 5] <= b) lo = mid; else hi = mid - 1;
     }
-    const long long* e = table + lo * 6;
+    const long long* e = table + lo * 8;
     const float* w = (const float*)e[0];
     bf16_t* wt = (bf16_t*)e[1];
     const int Co = (int)e[2], T = (int)e[3], Ci = (int)e[4];
+    const long long sld = e[6];
+    const int mode = (int)e[7];
     int rel = (int)(b - e[5]);
     const int nci = (Ci + 31) / 32, nco = (Co + 31) / 32;
     const int bx = rel % nci; rel /= nci;
@@ -160,12 +166,20 @@ __global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const lon
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
         int co = co0 + r, ci = ci0 + tx;
-        tile[r][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + tap) * Ci + ci] : 0.f;
+        tile[r][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + tap) * sld + ci] : 0.f;
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        int ci = ci0 + r, co = co0 + tx;
-        if (ci < Ci && co < Co) wt[((size_t)ci * T + tap) * Co + co] = f2bf(tile[tx][r]);
+    if (mode == 0) {
+        for (int r = ty; r < 32; r += 8) {
+            int ci = ci0 + r, co = co0 + tx;
+            if (ci < Ci && co < Co) wt[((size_t)ci * T + tap) * Co + co] = f2bf(tile[tx][r]);
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            int co = co0 + r, ci = ci0 + tx;
+            if (ci < Ci && co < Co)
+                wt[(mode == 1 ? ((size_t)tap * Co + co) : ((size_t)co * T + tap)) * Ci + ci] = f2bf(tile[r][tx]);
+        }
     }
 }
 

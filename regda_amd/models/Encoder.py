@@ -291,7 +291,7 @@ class Deeplabv2(nn.Module):
         for c in self.convs.values():
             if c.wtb is not None:
                 T = c.k * c.k
-                rows.append([c.w.data_ptr(), c.wtb.data_ptr(), c.co, T, c.ci, blk])
+                rows.append([c.w.data_ptr(), c.wtb.data_ptr(), c.co, T, c.ci, blk, c.ci, 0])
                 blk += ((c.ci + 31) // 32) * ((c.co + 31) // 32) * T
         self._wt_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._wt_blocks = blk
@@ -312,6 +312,27 @@ class Deeplabv2(nn.Module):
                 'gz': [torch.zeros(9 * 512, 1, 512, device=dev) for _ in POOL_SCALES],
             }
         self._hw_ready = None
+        # the head slices are two more tables for the same kernel: the forward operands (feature half + stacked tap
+        # filters; also all the EMA teacher needs) and the transposes for the gradient w.r.t. the PPM branches
+
+        def table(kinds):
+            rows, blk = [], 0
+            for head, hw in self.head_w.items():
+                wsrc = self.convs[f'{head}.conv_last.0'].w          # fp32 master, [512][9][4096]
+                if 'fwd' in kinds:
+                    rows.append([wsrc.data_ptr(), hw['wfeat'].data_ptr(), 512, 9, 2048, blk, 4096, 2])
+                    blk += (2048 // 32) * (512 // 32) * 9
+                for i in range(len(POOL_SCALES)):
+                    src = wsrc.data_ptr() + 4 * (2048 + 512 * i)
+                    if 'fwd' in kinds:
+                        rows.append([src, hw['wz'][i].data_ptr(), 512, 9, 512, blk, 4096, 1])
+                        blk += 16 * 16 * 9
+                    if 'bwd' in kinds:
+                        rows.append([src, hw['wzt'][i].data_ptr(), 512, 9, 512, blk, 4096, 0])
+                        blk += 16 * 16 * 9
+            return torch.tensor(rows, dtype=torch.int64, device=dev), blk
+        self._hw_fwd_table, self._hw_fwd_blocks = table(('fwd',))
+        self._hw_bwd_table, self._hw_bwd_blocks = table(('bwd',))
 
     def _init_weights(self):
         """kaiming_normal_(fan_out, relu) convs, BN weight 1 / bias 0 (_resnets.py:164-169); heads keep the
@@ -361,15 +382,10 @@ class Deeplabv2(nn.Module):
             self._wt_ready = side_stream.record_event()              # needed by the next backward
 
     def _sync_head_weights(self, with_transposes):
-        """Re-slice the head convs' bf16 mirror (layout copies only: torch strided copy_)."""
-        for head, hw in self.head_w.items():
-            w = self.convs[f'{head}.conv_last.0'].wb            # [512][9][4096]
-            hw['wfeat'].copy_(w[:, :, :2048])
-            for i in range(len(POOL_SCALES)):
-                sl = w[:, :, 2048 + 512 * i: 2048 + 512 * (i + 1)]       # [co][tap][ci]
-                hw['wz'][i].view(9, 512, 512).copy_(sl.permute(1, 0, 2))
-                if with_transposes:
-                    hw['wzt'][i].view(512, 9, 512).copy_(sl.permute(2, 1, 0))
+        """Re-slice the head convs' weights from the fp32 master (same rounding as the bf16 mirror)."""
+        ops.weight_transpose_batched(self._hw_fwd_table, self._hw_fwd_table.shape[0], self._hw_fwd_blocks)
+        if with_transposes:
+            ops.weight_transpose_batched(self._hw_bwd_table, self._hw_bwd_table.shape[0], self._hw_bwd_blocks)
 
     def _maybe_sync(self):
         if self.flat_p._version != self._synced_version:

@@ -457,3 +457,24 @@ def test_conv_dgrad_with_fused_bn_backward_reduction(ops, groups):
     ref = torch.zeros(groups, 8, 2, Cf, device='cuda')
     ops.bn_bwd_reduce(dx, cy, cx, mi, ref, M, Cf, True, ns, H * W, groups=groups)
     torch.testing.assert_close(sums.sum(1).cpu(), ref.sum(1).cpu(), rtol=2e-4, atol=2e-2)
+
+
+def test_weight_layout_table_modes(ops):
+    """rgda_weight_transpose_batched: transposed / tap-stacked / plain bf16 copies of channel slices of a wider fp32
+    weight tensor, several rows in one launch."""
+    g = torch.Generator().manual_seed(41)
+    Co, T, Cw = 96, 9, 320
+    w = torch.randn(Co, T, Cw, generator=g).cuda()
+    rows, blk, outs = [], 0, []
+    for (off, Ci, mode) in ((0, 128, 2), (128, 64, 1), (192, 128, 0), (0, 320, 0)):
+        shape = {0: (Ci, T, Co), 1: (T, Co, Ci), 2: (Co, T, Ci)}[mode]
+        dst = torch.zeros(shape, dtype=BF, device='cuda')
+        rows.append([w.data_ptr() + 4 * off, dst.data_ptr(), Co, T, Ci, blk, Cw, mode])
+        blk += -(-Ci // 32) * -(-Co // 32) * T
+        sl = w[:, :, off:off + Ci]
+        ref = {0: sl.permute(2, 1, 0), 1: sl.permute(1, 0, 2), 2: sl}[mode]
+        outs.append((dst, ref.to(BF)))
+    table = torch.tensor(rows, dtype=torch.int64, device='cuda')
+    ops.weight_transpose_batched(table, len(rows), blk)
+    for dst, ref in outs:
+        assert torch.equal(dst, ref.contiguous())

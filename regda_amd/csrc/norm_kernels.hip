@@ -1050,21 +1050,35 @@ __global__ void __launch_bounds__(256) classifier_bwd_kernel(const bf16_t* __res
     long long M = (long long)N * HW;
     long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     if (cok)
-        for (long long m = r0 + rl; m < r1; m += rpb) {
-            int n = (int)(m / HW), p = (int)(m % HW);
-            float g[NC], h[8], o[8];
+        for (long long mb = r0 + rl; mb < r1; mb += (long long)rpb * ROW_BATCH) {
+            float gq[ROW_BATCH][NC];
+            u16x8 hv[ROW_BATCH];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) g[c] = gl[((size_t)n * NC + c) * HW + p];
-            load8(hid + m * ldh + cg, h);
+            for (int u = 0; u < ROW_BATCH; ++u) {          // all loads of the batch first
+                const long long m = mb + (long long)u * rpb;
+                if (m < r1) {
+                    int n = (int)(m / HW), p = (int)(m % HW);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                dbacc[c] += g[c];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { o[e] += g[c] * wreg[c][e]; dwacc[c][e] += g[c] * h[e]; }
+                    for (int c = 0; c < NC; ++c) gq[u][c] = gl[((size_t)n * NC + c) * HW + p];
+                    hv[u] = *(const u16x8*)(hid + m * ldh + cg);
+                }
             }
-            store8(dhid + m * lddh + cg, o);
+#pragma unroll
+            for (int u = 0; u < ROW_BATCH; ++u) {
+                const long long m = mb + (long long)u * rpb;
+                if (m >= r1) break;
+                float h[8], o[8];
+                cvt8(hv[u], h);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    dbacc[c] += gq[u][c];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { o[e] += gq[u][c] * wreg[c][e]; dwacc[c][e] += gq[u][c] * h[e]; }
+                }
+                store8(dhid + m * lddh + cg, o);
+            }
         }
     // reduce dW over the row lanes
 #pragma unroll
@@ -1108,7 +1122,10 @@ extern "C" int rgda_classifier_bwd(const void* hidden, int ldh, const float* w, 
     if (ncls != 6) return RGDA_ERR_UNSUPPORTED;
     long long M = (long long)N * HW;
     RowLayout L = row_layout(C);
-    int rows_per_block = 64;
+    // every workgroup ends with ncls*C fp32 atomics onto the SAME addresses (cross-XCD same-address atomics are slow):
+    // few, long workgroups
+    int rows_per_block = 256;
+    if (const char* e = getenv("RGDA_CLS_ROWS")) rows_per_block = atoi(e);     // tuning experiments only
     while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 1024) rows_per_block *= 2;
     dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
     classifier_bwd_kernel<6><<<grid, 256, (size_t)256 * 8 * 6 * 4, to_stream(stream)>>>(

@@ -4,6 +4,8 @@ import torch
 from regda_amd import ops
 BF = torch.bfloat16
 SHAPES = [  # N,H,W,Cin,Cout,k,s,p,d
+    (8, 32, 32, 512, 2048, 1, 1, 0, 1),
+    (8, 32, 32, 2048, 512, 1, 1, 0, 1),
     (16, 32, 32, 512, 2048, 1, 1, 0, 1),
     (16, 64, 64, 128, 512, 1, 1, 0, 1),
     (16, 128, 128, 64, 256, 1, 1, 0, 1),

@@ -69,10 +69,10 @@ def conv_flops_probe(step_fn):
         e1.record()
         rec.append((name, 2.0 * M * co * taps * ci, e0, e1, (kind, M, co, ci, taps, stride, dil)))
 
-    def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1):
+    def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1, **k):
         rpg = (N * Ho * Wo // stat_groups) if (stats is not None and stat_groups > 1) else 0
         timed('dgrad' if mode else 'fwd', w, N, Ho, Wo, kh, kw, stride, dil, rpg,
-              lambda: o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups))
+              lambda: o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups, **k))
 
     def conv_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, *a, **k):
         timed('fwd-ev', w, N, Ho, Wo, kh, kw, stride, dil, 0,

@@ -124,6 +124,9 @@ int rgda_class_count(const int64_t* label, int32_t* cnt, int64_t n, int c, rgda_
  *   wgt : [Cout][kh*kw][Cin] bf16  (mode 1: [Cin_of_fwd][kh*kw][Cout_of_fwd])
  *   y   : [N*Ho*Wo][ldy] bf16
  *   res : NULL or [N*Ho*Wo][ldres] bf16 added to the result before the store
+ *   res_relu_mask : NULL or uint8 [N*Ho*Wo][Cout/8] sign bits (rgda_bn_train_apply): res is added only where its
+ *          bit is set -- the gradient of a residual connection gated by the ReLU it passed through, so that gated
+ *          copy never has to be written to memory
  *   stats: NULL or f32[RGDA_STAT_REPLICAS][2][Cout]; per-channel sum and sum of squares of the
  *          (bf16-rounded) outputs are atomically accumulated (BatchNorm batch stats)
  *   mode 0: y[n,ho,wo] = sum x[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil] * w
@@ -131,8 +134,9 @@ int rgda_class_count(const int64_t* label, int32_t* cnt, int64_t n, int c, rgda_
  *           (terms with a non-integer or out-of-range source are zero)
  * Requires Cin % 32 == 0, Cout % 8 == 0, ld* % 8 == 0. */
 int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res,
-                int ldres, float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo,
-                int Cout, int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream);
+                int ldres, const uint8_t* res_relu_mask, float* stats, int stat_groups, int N, int H, int W,
+                int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int mode,
+                rgda_stream_t stream);
 
 /* Forward conv with an INFERENCE-mode BatchNorm (+ residual + ReLU) folded into the epilogue -- the EMA teacher's
  * conv + BN + ReLU units (regda/models/Encoder.py:152-155 runs the model in eval()):
@@ -149,7 +153,7 @@ int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void* y, int ldy
  * sums[group][REPLICAS][2][Cout] += (sum g', sum g' * xhat) -- exactly what rgda_bn_bwd_reduce would compute
  * from the stored tensor, without re-reading it. */
 int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                      float* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
+                      const uint8_t* res_relu_mask, float* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
                       const void* bn_x, int bn_ldx,
                       const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N, int H,
                       int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,

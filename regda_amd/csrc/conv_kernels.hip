@@ -34,6 +34,7 @@ struct ConvArgs {
     int skip;                  // tuning only: 1 = no DMA inside the K loop, 2 = no LDS reads / MFMA
     // optional fused BatchNorm-backward reduction of the CONSUMER of this (data-gradient) output: with g = the stored
     // result, g' = g * [bn_y > 0] * nscale, xhat = (bn_x - mean) * invstd, `stats` receives sum(g'), sum(g' * xhat)
+    const unsigned char* res_mask;  // [M][Cout/8] sign bits: the residual is added only where its bit is set
     const bf16_t* bn_y;
     const unsigned char* bn_mask;   // [M][Cout/8] ReLU sign bits of bn_y (read instead of bn_y when given)
     const bf16_t* bn_x;
@@ -360,6 +361,11 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
                 }
             } else if (a.res) {
                 u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
+                if (a.res_mask) {       // residual = upstream gradient gated by the ReLU of the layer it passed through
+                    const unsigned mb = a.res_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] = ((mb >> e) & 1u) ? rv[e] : (bf16_t)0;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     unsigned pk = pack2bf(bf2f(val[e]) + bf2f(rv[e]), bf2f(val[e + 1]) + bf2f(rv[e + 1]));
@@ -468,7 +474,7 @@ struct BnBwdFuse { const void* y; int ldy; const unsigned char* mask; const void
 struct BnEvalFuse { const float* rm; const float* rv; const float* gamma; const float* beta; float eps; int relu; };
 
 static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                         float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                         const unsigned char* res_mask, float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int kh, int kw, int stride, int pad, int dil, int mode, const BnBwdFuse* bnb,
                          rgda_stream_t stream, const BnEvalFuse* bne = nullptr) {
     if (!x || !wgt || !y) return RGDA_ERR_ARG;
@@ -479,6 +485,8 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         return RGDA_ERR_ARG;
     ConvArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)wgt; a.y = (bf16_t*)y; a.res = (const bf16_t*)res; a.stats = stats;
+    if (res_mask && (!res || bne)) return RGDA_ERR_ARG;
+    a.res_mask = res_mask;
     a.ldx = ldx; a.ldy = ldy; a.ldres = ldres;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.KH = kh; a.KW = kw;
     a.stride = stride; a.pad = pad; a.dil = dil; a.mode = mode;
@@ -539,9 +547,10 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
 }
 
 extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                           float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                           int kh, int kw, int stride, int pad, int dil, int mode, rgda_stream_t stream) {
-    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, stats, stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
+                           const uint8_t* res_relu_mask, float* stats, int stat_groups, int N, int H, int W, int Cin,
+                           int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int mode,
+                           rgda_stream_t stream) {
+    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, res_relu_mask, stats, stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
                          pad, dil, mode, nullptr, stream);
 }
 
@@ -550,19 +559,19 @@ extern "C" int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void*
                                   const float* beta, float eps, int relu, int N, int H, int W, int Cin, int Ho, int Wo,
                                   int Cout, int kh, int kw, int stride, int pad, int dil, rgda_stream_t stream) {
     BnEvalFuse e = {running_mean, running_var, gamma, beta, eps, relu};
-    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, nullptr, 1, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil,
-                         0, nullptr, stream, &e);
+    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, nullptr, nullptr, 1, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
+                         pad, dil, 0, nullptr, stream, &e);
 }
 
 extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                                 float* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
+                                 const uint8_t* res_relu_mask, float* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
                                  const void* bn_x, int bn_ldx,
                                  const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N,
                                  int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                                  int dil, int mode, rgda_stream_t stream) {
     BnBwdFuse b = {bn_y, bn_ldy, bn_relu_mask, bn_x, bn_ldx, bn_mi, bn_nscale, rows_per_image, relu};
-    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, sums, groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad,
-                         dil, mode, &b, stream);
+    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, res_relu_mask, sums, groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw,
+                         stride, pad, dil, mode, &b, stream);
 }
 
 // ======================================================================================

@@ -628,9 +628,10 @@ class Deeplabv2(nn.Module):
             T['on_progress'](offset)
 
     def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False,
-                 consumer=None):
+                 consumer=None, dx_res_mask=None):
         """Backward of one conv+BN(+ReLU) unit.  `consumer` = (tape key, relu) of the unit that will consume this
-        unit's data gradient: its BN-backward reduction is then folded into our data-gradient conv's epilogue."""
+        unit's data gradient: its BN-backward reduction is then folded into our data-gradient conv's epilogue.
+        `dx_res` (+ optional ReLU sign mask gating it) is added to the data gradient in the same epilogue."""
         x, c, y, mi, (N, H, W, Ho, Wo), nscale, rmask = T[key]
         M, C, G = N * Ho * Wo, conv.co, T['groups']
         sums = T.pop('sums:' + key, None)
@@ -666,14 +667,14 @@ class Deeplabv2(nn.Module):
                 try:
                     ops.conv2d_bnbwd(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil,
                                      1, dx_res, csums, G, cy if (crelu and cmask is None) else None, cc, cmi, crelu,
-                                     cns, cHo * cWo, relu_mask=cmask)
+                                     cns, cHo * cWo, relu_mask=cmask, res_mask=dx_res_mask)
                     T['sums:' + ckey] = csums
                     fused = True
                 except ValueError:          # row groups do not tile (tiny maps): plain conv, standalone reduction
                     T['presums:' + ckey] = csums
             if not fused:
                 ops.conv2d(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil, 1,
-                           dx_res, None)
+                           dx_res, None, res_mask=dx_res_mask)
         return dx, gm
 
     # ------------------------------------------------------------------ forward plan
@@ -806,12 +807,19 @@ class Deeplabv2(nn.Module):
                 hh, ww = hh * stride, ww * stride
             # the gradient that leaves this block is consumed by bn3 of the block above it in the net
             below = (order[bi - 1] + '.3', True) if bi > 0 else None
-            da2, gm = self._cbr_bwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], g, True, want_gmask=True,
-                                    consumer=(p + '.2', True))
+            # identity blocks: the skip-path gradient g * [y3 > 0] is never written -- conv1's data-gradient epilogue
+            # adds g gated by bn3's ReLU sign mask (when the unit kept one)
+            g3, m3 = g, T[p + '.3'][6]
+            gate_in_epilogue = (not ds) and (m3 is not None)
+            da2, gm = self._cbr_bwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], g, True,
+                                    want_gmask=not gate_in_epilogue, consumer=(p + '.2', True))
             da1, _ = self._cbr_bwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], da2, True, consumer=(p + '.1', True))
             if ds:
                 dxd, _ = self._cbr_bwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], gm, False)
                 g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=dxd, consumer=below)
+            elif gate_in_epilogue:
+                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=g3,
+                                     dx_res_mask=m3, consumer=below)
             else:
                 g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm, consumer=below)
             self._progress(T, self._offset_of(p + '.conv1'))

@@ -188,13 +188,14 @@ def _ld(t):
     return t.stride(0)
 
 
-def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1):
+def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1,
+           res_mask=None):
     """x [N*H*W, Cin(view)], w bf16 [Cout, kh*kw, Cin] contiguous, y [N*Ho*Wo, Cout(view)].
     stats: f32 [stat_groups][8][2][Cout] accumulators (zeroed by the caller)."""
     Cout, taps, Cin = w.shape
     assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
     lib().call('rgda_conv2d', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
-               _ld(res) if res is not None else 0, _p(stats), stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
+               _ld(res) if res is not None else 0, _p(res_mask), _p(stats), stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
                pad, dil, mode, _stream())
 
 
@@ -208,12 +209,12 @@ def conv2d_bneval(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, ga
 
 
 def conv2d_bnbwd(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, bn_mi, relu,
-                 nscale=None, rows_per_image=0, relu_mask=None):
+                 nscale=None, rows_per_image=0, relu_mask=None, res_mask=None):
     """conv2d whose epilogue also accumulates the BN-backward sums of the consumer of `y` (see rgda_conv2d_bnbwd)."""
     Cout, taps, Cin = w.shape
     assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
     lib().call('rgda_conv2d_bnbwd', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
-               _ld(res) if res is not None else 0, sums.data_ptr(), groups, _p(bn_y), _ld(bn_y) if bn_y is not None else 0,
+               _ld(res) if res is not None else 0, _p(res_mask), sums.data_ptr(), groups, _p(bn_y), _ld(bn_y) if bn_y is not None else 0,
                _p(relu_mask), bn_x.data_ptr(), _ld(bn_x), bn_mi.data_ptr(), _p(nscale), rows_per_image, int(relu), N, H, W, Cin, Ho, Wo,
                Cout, kh, kw, stride, pad, dil, mode, _stream())
 

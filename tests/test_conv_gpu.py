@@ -478,3 +478,23 @@ def test_weight_layout_table_modes(ops):
     ops.weight_transpose_batched(table, len(rows), blk)
     for dst, ref in outs:
         assert torch.equal(dst, ref.contiguous())
+
+
+def test_conv_residual_gated_by_relu_mask(ops):
+    """res_relu_mask: the residual enters the epilogue only where its sign bit is set (= adding a pre-gated copy)."""
+    g = torch.Generator().manual_seed(51)
+    N, H, W, Ci, Co = 2, 8, 8, 64, 128
+    M = N * H * W
+    x = torch.randn(M, Ci, generator=g).to(BF).cuda()
+    w = (torch.randn(Co, 1, Ci, generator=g) * 0.1).to(BF).cuda()
+    res = torch.randn(M, Co, generator=g).to(BF).cuda()
+    keep = torch.rand(M, Co, generator=g) > 0.4
+    mask = (keep.reshape(M, Co // 8, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(-1).to(torch.uint8).cuda()
+    gated = torch.where(keep.cuda(), res, torch.zeros_like(res))
+    y1 = torch.empty(M, Co, dtype=BF, device='cuda')
+    y2 = torch.empty(M, Co, dtype=BF, device='cuda')
+    ops.conv2d(x, w, y1, N, H, W, H, W, 1, 1, 1, 0, 1, 0, res, None, res_mask=mask)
+    ops.conv2d(x, w, y2, N, H, W, H, W, 1, 1, 1, 0, 1, 0, gated, None)
+    assert torch.equal(y1, y2)
+    with pytest.raises(ValueError):
+        ops.conv2d(x, w, y1, N, H, W, H, W, 1, 1, 1, 0, 1, 0, None, None, res_mask=mask)

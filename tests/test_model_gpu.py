@@ -155,14 +155,19 @@ def test_layerwise_backward_consistency():
     rec = []
     orig = E.Deeplabv2._cbr_bwd
 
-    def spy(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False, consumer=None):
+    def spy(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False, consumer=None,
+            dx_res_mask=None):
         x, c, y, mi, dims, nscale, rmask = T[key]
         g0 = conv.g.clone()
         dg0, db0 = bn.dgamma.clone(), bn.dbeta.clone()
-        out = orig(self, T, key, conv, bn, g, relu, need_dx, want_gmask, dx_res, stem, consumer)
+        out = orig(self, T, key, conv, bn, g, relu, need_dx, want_gmask, dx_res, stem, consumer, dx_res_mask)
         if not stem and nscale is None:
+            res_eff = dx_res
+            if dx_res is not None and dx_res_mask is not None:      # residual gated by a ReLU sign mask in the epilogue
+                bits = ((dx_res_mask.unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8, device='cuda')) & 1).bool()
+                res_eff = torch.where(bits.reshape(dx_res.shape), dx_res, torch.zeros_like(dx_res))
             rec.append((key, conv, bn, x.clone(), c.clone(), y.clone(), g.clone(), dims, relu,
-                        None if dx_res is None else dx_res.clone(), None if out[0] is None else out[0].clone(),
+                        None if res_eff is None else res_eff.clone(), None if out[0] is None else out[0].clone(),
                         (conv.g - g0).clone(), (bn.dgamma - dg0).clone(), (bn.dbeta - db0).clone()))
         return out
     E.Deeplabv2._cbr_bwd = spy

@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_PAIR_STUDENT = 1087.0     # (fwd + dgrad + wgrad) x (src + tgt) conv FLOPs
 GFLOP_PER_PAIR_TEACHER = 181.17     # + one eval forward of the EMA teacher on the target image
-MFMA_PEAK_TFLOPS = 2500.0           # bf16 dense, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0       # bf16 dense, MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 achievable)
 
 
 def parse():
@@ -55,9 +56,11 @@ def conv_flops_probe(step_fn):
     o_conv, o_wgrad, o_bne, o_bnb = ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd
     o_wgrad_g = ops.conv2d_wgrad_grouped
 
-    def timed(kind, w, N, Ho, Wo, kh, kw, stride, dil, rows_per_group, launch):
+    def timed(kind, w, N, Ho, Wo, kh, kw, stride, dil, rows_per_group, launch, extra_bytes=0.0, in_rows=None):
         co, taps, ci = w.shape
         M = N * Ho * Wo
+        # algorithmic HBM bytes of the launch: input rows + weights + output (+ what the fused epilogue reads)
+        abytes = 2.0 * (in_rows if in_rows is not None else M) * ci + 2.0 * co * taps * ci + 2.0 * M * co + extra_bytes
         code = L.raw('rgda_conv2d_tile')(M, co, kh, kw, ci, rows_per_group)
         bc, bp, stg = code & 1023, (code >> 10) & 1023, code >> 20
         st3 = stg % 80 if stg >= 80 else stg
@@ -67,20 +70,30 @@ def conv_flops_probe(step_fn):
         e0.record()
         launch()
         e1.record()
-        rec.append((name, 2.0 * M * co * taps * ci, e0, e1, (kind, M, co, ci, taps, stride, dil)))
+        rec.append((name, 2.0 * M * co * taps * ci, e0, e1, (kind, M, co, ci, taps, stride, dil), 1, abytes))
 
     def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1, **k):
         rpg = (N * Ho * Wo // stat_groups) if (stats is not None and stat_groups > 1) else 0
+        M, co = N * Ho * Wo, w.shape[0]
+        extra = (2.0 * M * co if res is not None else 0.0) + (M * co / 8.0 if k.get('res_mask') is not None else 0.0)
         timed('dgrad' if mode else 'fwd', w, N, Ho, Wo, kh, kw, stride, dil, rpg,
-              lambda: o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups, **k))
+              lambda: o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups, **k),
+              extra, N * H * W)
 
-    def conv_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, *a, **k):
+    def conv_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, gamma, beta, relu, res=None, **k):
+        M, co = N * Ho * Wo, w.shape[0]
         timed('fwd-ev', w, N, Ho, Wo, kh, kw, stride, dil, 0,
-              lambda: o_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, *a, **k))
+              lambda: o_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, gamma, beta, relu, res, **k),
+              2.0 * M * co if res is not None else 0.0, N * H * W)
 
-    def conv_bnb(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, *a, **k):
+    def conv_bnb(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, *a, **k):
+        M, co = N * Ho * Wo, w.shape[0]
+        extra = (2.0 * M * co if res is not None else 0.0) + 2.0 * M * co          # residual, consumer's raw conv output
+        extra += 2.0 * M * co if bn_y is not None else (M * co / 8.0 if k.get('relu_mask') is not None else 0.0)
+        extra += M * co / 8.0 if k.get('res_mask') is not None else 0.0
         timed('dgrad+bn' if mode else 'fwd+bn', w, N, Ho, Wo, kh, kw, stride, dil, (N * Ho * Wo // groups) if groups > 1 else 0,
-              lambda: o_bnb(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, *a, **k))
+              lambda: o_bnb(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, *a, **k),
+              extra, N * H * W)
 
     def wgrad_kernel_name(item):
         x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil = item
@@ -106,8 +119,10 @@ def conv_flops_probe(step_fn):
             o_wgrad_g(its)
             e1.record()
             fl = sum(2.0 * it[3] * it[6] * it[7] * it[2].numel() for it in its)
+            by = sum(2.0 * it[3] * it[4] * it[5] * it[2].shape[2] + 2.0 * it[3] * it[6] * it[7] * it[2].shape[0] +
+                     4.0 * it[2].numel() for it in its)
             rec.append((name, fl, e0, e1, ('wgrad x%d' % len(its),) + (its[0][3] * its[0][6] * its[0][7],) + tuple(its[0][2].shape[i] for i in (0, 2, 1)) + (its[0][10], its[0][12]),
-                        -(-len(its) // 16)))
+                        -(-len(its) // 16), by))
 
     def wgrad(*item):
         wgrad_grouped([item])
@@ -121,11 +136,10 @@ def conv_flops_probe(step_fn):
         ops.conv2d_wgrad_grouped = o_wgrad_g
     kern, shapes = {}, {}
     for r in rec:
-        name, fl, e0, e1, shp = r[:5]
-        nl = r[5] if len(r) > 5 else 1          # kernel launches inside the bracket
+        name, fl, e0, e1, shp, nl, by = r          # nl = kernel launches inside the bracket, by = algorithmic bytes
         dt = e0.elapsed_time(e1)
-        k = kern.setdefault(name, [0.0, 0.0, 0])
-        k[0] += fl; k[1] += dt; k[2] += nl
+        k = kern.setdefault(name, [0.0, 0.0, 0, 0.0])
+        k[0] += fl; k[1] += dt; k[2] += nl; k[3] += by
         q = shapes.setdefault(shp, [0.0, 0.0, 0])
         q[0] += fl; q[1] += dt; q[2] += nl
     if os.environ.get('RGDA_CONV_REPORT'):
@@ -133,7 +147,8 @@ def conv_flops_probe(step_fn):
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 f.write('%-8s M=%-7d Co=%-5d Ci=%-5d taps=%d s=%d d=%d  n=%-3d ms=%8.3f  TF/s=%7.1f\n' % (k + (v[2], v[1], v[0] / 1e9 / max(v[1], 1e-9))))
     return {k: dict(gflop=v[0] / 1e9, ms=v[1], launches=v[2], tflops=v[0] / 1e9 / max(v[1], 1e-9),
-                    avg_us=v[1] / v[2] * 1e3) for k, v in kern.items()}
+                    avg_us=v[1] / v[2] * 1e3, algorithmic_mb=v[3] / 1e6, gbps=v[3] / 1e6 / max(v[1], 1e-9))
+            for k, v in kern.items()}
 
 
 def cpu_baseline(args):
@@ -279,10 +294,20 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')      # written from the rocprofv3 --pmc passes
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom)
-        res['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': d['tflops'], 'peak': MFMA_PEAK_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': d['tflops'] / MFMA_PEAK_TFLOPS, 'traffic': traffic,
+        # which roof bounds it: algorithmic FLOP per algorithmic byte against the machine balance (2500 TF / 8 TB/s)
+        intensity = d['gflop'] * 1e3 / max(d['algorithmic_mb'], 1e-9)                # FLOP per byte
+        if intensity >= MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBPS:
+            roof = {'bound': 'mfma', 'achieved': d['tflops'], 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': d['tflops'] / MFMA_PEAK_TFLOPS}
+        else:
+            roof = {'bound': 'hbm', 'achieved': d['gbps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                    'frac': d['gbps'] / HBM_PEAK_GBPS}
+        res['roofline'] = {**roof, 'kernel': dom, 'traffic': traffic,
+                           'flop_per_byte': intensity, 'mfma_frac': d['tflops'] / MFMA_PEAK_TFLOPS,
+                           'hbm_frac': d['gbps'] / HBM_PEAK_GBPS,
                            'launches_per_step': d['launches'], 'avg_launch_us': d['avg_us'],
                            'gflop_per_launch': d['gflop'] / d['launches'],
+                           'algorithmic_mb_per_launch': d['algorithmic_mb'] / d['launches'],
                            'all_conv_kernels': {'achieved': gf / ms, 'frac': gf / ms / MFMA_PEAK_TFLOPS,
                                                 'gflop_per_step': gf, 'ms_per_step': ms},
                            'by_kernel': kern}

@@ -25,7 +25,7 @@ def make_buckets(boundaries, total, bucket_elems):
 
 
 class FlatGradReducer:
-    def __init__(self, flat_g, boundaries, bucket_elems=24 << 20, group=None):
+    def __init__(self, flat_g, boundaries, bucket_elems=12 << 20, group=None):
         self.flat_g = flat_g
         self.group = group
         import os

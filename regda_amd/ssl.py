@@ -18,7 +18,7 @@ from .ddp import FlatGradReducer
 class SSLStep:
     def __init__(self, model, prototypes, class_num=6, ignore_label=-1, momentum=0.9, weight_decay=5e-4,
                  max_norm=32.0, cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996, refine_temp=2.0,
-                 sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=24 << 20,
+                 sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=12 << 20,
                  process_group=None, overlap_wgrad=True, overlap_comm=True):
         self.model = model
         self.C, self.ig = class_num, ignore_label

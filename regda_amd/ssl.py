@@ -68,10 +68,15 @@ class SSLStep:
             raise RuntimeError('whole-step graphs are single-GPU; the multi-GPU path stays eager')
         self._static = [None if t is None else t.clone() for t in (images_s, label_s, images_t, soft_t, regs_t)]
         torch.cuda.synchronize()
+        m = self.model
+        m._hw_ready = m._wt_ready = None          # everything recorded before the synchronize is complete
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             with ops.use_stream(torch.cuda.current_stream()):
                 self._out = self._step(*self._static)
+                if self.wgrad_stream is not None:   # the weight re-layouts issued on the second stream at the end
+                    torch.cuda.current_stream().wait_stream(self.wgrad_stream)     # of the step join the graph
+        m._hw_ready = m._wt_ready = None          # (they are events inside the graph now: nothing to wait for outside)
         self._graph = g
 
     def _replay(self, images_s, label_s, images_t, soft_t, regs_t, lr):

@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 24.7 vs 24.1 ms)')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--phases', action='store_true', help='HIP-event phase marks of one extra step, to stderr')
+    ap.add_argument('--tta-tiles', type=int, default=0, help='also time the teacher harness (SURVEY 8f.1): 8-view TTA '
+                    'sliding-window inference of this many 512x512 target tiles; adds "teacher_harness" to the JSON')
     return ap.parse_args()
 
 
@@ -311,6 +313,23 @@ def main():
                            'all_conv_kernels': {'achieved': gf / ms, 'frac': gf / ms / MFMA_PEAK_TFLOPS,
                                                 'gflop_per_step': gf, 'ms_per_step': ms},
                            'by_kernel': kern}
+    if rank == 0 and world == 1 and args.tta_tiles > 0:
+        from regda_amd.utils.tools import pre_slide
+        tm = step.teacher if step.teacher is not None else model
+        tm.eval()
+        tile = batch['images_t'][:1].contiguous()
+        with torch.no_grad():
+            pre_slide(tm, tile, num_classes=6, tile_size=(args.size, args.size), tta=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.tta_tiles):
+                pre_slide(tm, tile, num_classes=6, tile_size=(args.size, args.size), tta=True)
+            torch.cuda.synchronize()
+        dt_t = (time.perf_counter() - t0) / args.tta_tiles
+        res['teacher_harness'] = {'tiles_per_s': 1.0 / dt_t, 'ms_per_tile': dt_t * 1e3, 'views': 8,
+                                  'what': f'pre_slide(tta=True) of one {args.size}x{args.size} tile: 8 dihedral views '
+                                          'through the eval network as one batch, de-augmented and averaged'}
+        model.train()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:

@@ -299,6 +299,33 @@ int rgda_unpad_acc_f32(const float* src, float* dst, int R, int K, int Kp, rgda_
 int rgda_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t M,
                   int C, rgda_stream_t stream);
 
+/* ------------------------------------------------------------- teacher / pseudo-label harness */
+
+/* One view of the 8-view test-time augmentation of regda/utils/tools.py:132-152 (ttach 0.0.3:
+ * Compose([HorizontalFlip(), Rotate90([0,90,180,270])]), un-vendored, restated).  With R = torch.rot90(., 1, (2,3))
+ * and F = flip(3): flip_first=1 -> dst = R^k(F^f(src)) (augment_image), flip_first=0 -> dst = F^f(R^k(src))
+ * (deaugment_mask with k := (4-k)%4).  dst (+)= scale * view; fp32 NCHW; output is Ws x Hs for odd k. */
+int rgda_dihedral_nchw(const float* src, float* dst, int N, int C, int Hs, int Ws, int hflip, int rot_k,
+                       int flip_first, float scale, int accumulate, rgda_stream_t stream);
+
+/* Sliding-window inference of regda/utils/tools.py:61-97 (pre_slide): crop + zero-pad one window to the tile size
+ * (tools.py:79-80), add a tile of predictions into the full map and bump the visit count (tools.py:91-93),
+ * divide by the count (tools.py:95). */
+/* pad_image exactly as written (tools.py:51-58): tnf.pad(img, (0, 0, top, bottom)) pads the ROW dimension (top by
+ * rows_missing, bottom by cols_missing; negative = crop) and leaves W alone; dst has h + top + bottom rows. */
+int rgda_pad_rows_nchw(const float* src, float* dst, int N, int C, int h, int w, int top, int bottom,
+                       rgda_stream_t stream);
+int rgda_window_crop(const float* full, float* tile, int N, int C, int Hf, int Wf, int y1, int x1, int h, int w,
+                     int Th, int Tw, rgda_stream_t stream);
+int rgda_window_accumulate(const float* tile, float* full, float* count, int N, int C, int Hf, int Wf, int y1,
+                           int x1, int h, int w, int Th, int Tw, rgda_stream_t stream);
+int rgda_window_normalise(float* full, const float* count, int N, int C, int Hf, int Wf, rgda_stream_t stream);
+
+/* tnf.interpolate(mode='bilinear', align_corners=True) of the soft labels to the dataset size
+ * (regda/gast/pseudo_generation.py:135). */
+int rgda_resize_bilinear_ac(const float* src, float* dst, int N, int C, int h, int w, int H, int W,
+                            rgda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

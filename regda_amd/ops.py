@@ -371,3 +371,52 @@ def unpad_acc_f32(src, dst, R, K, Kp):
 
 def add_bf16(a, b, out, M, C):
     lib().call('rgda_add_bf16', a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), out.data_ptr(), _ld(out), M, C, _stream())
+
+
+# ----------------------------------------------------------------------------- teacher / pseudo-label harness
+def dihedral(src, hflip, k, flip_first, dst=None, scale=1.0, accumulate=False):
+    """One TTA view (rgda_dihedral_nchw): fp32 NCHW; returns dst (allocated when None)."""
+    _need_cuda(src)
+    n, c, h, w = src.shape
+    k = k % 4
+    ho, wo = (w, h) if (k & 1) else (h, w)
+    if dst is None:
+        assert not accumulate
+        dst = torch.empty(n, c, ho, wo, device=src.device)
+    assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.float32
+    assert tuple(dst.shape) == (n, c, ho, wo)
+    lib().call('rgda_dihedral_nchw', src.data_ptr(), dst.data_ptr(), n, c, h, w, int(bool(hflip)), k, int(bool(flip_first)),
+               float(scale), int(bool(accumulate)), _stream())
+    return dst
+
+
+def window_crop(full, y1, x1, h, w, Th, Tw):
+    n, c, Hf, Wf = full.shape
+    tile = torch.empty(n, c, Th, Tw, device=full.device)
+    lib().call('rgda_window_crop', full.data_ptr(), tile.data_ptr(), n, c, Hf, Wf, y1, x1, h, w, Th, Tw, _stream())
+    return tile
+
+
+def window_accumulate(tile, full, count, y1, x1, h, w):
+    n, c, Hf, Wf = full.shape
+    lib().call('rgda_window_accumulate', tile.data_ptr(), full.data_ptr(), count.data_ptr(), n, c, Hf, Wf, y1, x1, h, w,
+               tile.shape[2], tile.shape[3], _stream())
+
+
+def window_normalise(full, count):
+    n, c, Hf, Wf = full.shape
+    lib().call('rgda_window_normalise', full.data_ptr(), count.data_ptr(), n, c, Hf, Wf, _stream())
+
+
+def resize_bilinear_ac(src, size):
+    n, c, h, w = src.shape
+    dst = torch.empty(n, c, size[0], size[1], device=src.device)
+    lib().call('rgda_resize_bilinear_ac', src.contiguous().data_ptr(), dst.data_ptr(), n, c, h, w, size[0], size[1], _stream())
+    return dst
+
+
+def pad_rows(src, top, bottom):
+    n, c, h, w = src.shape
+    dst = torch.empty(n, c, h + top + bottom, w, device=src.device)
+    lib().call('rgda_pad_rows_nchw', src.contiguous().data_ptr(), dst.data_ptr(), n, c, h, w, top, bottom, _stream())
+    return dst

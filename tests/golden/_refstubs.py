@@ -77,6 +77,45 @@ def _scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum'):
     return torch.zeros(size, dtype=src.dtype).scatter_add_(dim, index, src)
 
 
+# ttach==0.0.3 (requirement.txt:165) is neither vendored nor installed: the two transforms the reference composes
+# (tools.py:133-137) are restated here from its published behaviour so that the reference's own pre_slide /
+# tta_predict can run.  What this pins: the reference's window arithmetic, padding, averaging -- NOT ttach itself.
+class _TtaChain:
+    def __init__(self, hflip, k):
+        self.hflip, self.k = hflip, k
+
+    def augment_image(self, x):
+        x = x.flip(3) if self.hflip else x
+        return torch.rot90(x, self.k, (2, 3))
+
+    def deaugment_mask(self, m):
+        m = torch.rot90(m, -self.k, (2, 3))
+        return m.flip(3) if self.hflip else m
+
+
+class _HorizontalFlip:
+    params = (False, True)
+
+
+class _Rotate90:
+    def __init__(self, angles):
+        self.params = tuple(a // 90 for a in angles)
+
+
+class _Compose:
+    def __init__(self, transforms):
+        assert isinstance(transforms[0], _HorizontalFlip) and isinstance(transforms[1], _Rotate90)
+        self.t = transforms
+
+    def __iter__(self):
+        for f in self.t[0].params:          # itertools.product order: first transform outermost
+            for k in self.t[1].params:
+                yield _TtaChain(f, k)
+
+    def __len__(self):
+        return len(self.t[0].params) * len(self.t[1].params)
+
+
 def install():
     def mod(name, **attrs):
         m = types.ModuleType(name)
@@ -104,6 +143,7 @@ def install():
     ever.ERModule = _ERModule
     ever.registry = reg
     mod('torch_scatter', scatter=_scatter)
+    mod('ttach', Compose=_Compose, HorizontalFlip=_HorizontalFlip, Rotate90=_Rotate90)
     class _Dummy:
         def __init__(self, *a, **k):
             pass

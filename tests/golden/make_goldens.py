@@ -303,7 +303,39 @@ def gold_model():
          nbt=sdn['encoder.resnet.bn1.num_batches_tracked'].numpy(), probs=probs.numpy(), **grads)
 
 
+def gold_tta():
+    """The reference's own pre_slide / tta_predict (regda/utils/tools.py:61-97,132-152) on a small deterministic
+    'model' that is not equivariant under flips / rotations, plus the align_corners=True soft-label resize of
+    pseudo_generation.py:135.  ttach is the restatement in _refstubs (un-vendored dependency)."""
+    import torch.nn.functional as F
+    from regda.utils import tools as rtools
+    torch.manual_seed(17)
+    wgt, bias = torch.randn(5, 3, 3, 3) * 0.7, torch.randn(5) * 0.3
+
+    def model(x):                       # stands in for Deeplabv2.eval(): per-pixel class probabilities
+        return torch.softmax(F.conv2d(x, wgt, bias, padding=1), dim=1)
+    out = dict(wgt=wgt.numpy(), bias=bias.numpy())
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the reference allocates with .cuda(); CPU-only box
+    try:
+        cases = [((1, 3, 16, 16), (16, 16)),      # one window, no padding (the 512 x 512 production case)
+                 ((1, 3, 40, 24), (16, 16)),      # 4 x 2 windows, overlaps, last window re-aligned
+                 ((1, 3, 12, 20), (16, 16))]      # image smaller than the tile in one dimension: zero padding
+        for i, (shape, tile) in enumerate(cases):
+            img = torch.randn(*shape)
+            out[f'img{i}'] = img.numpy()
+            out[f'tile{i}'] = np.array(tile)
+            for tta in (False, True):
+                out[f'probs{i}_tta{int(tta)}'] = rtools.pre_slide(model, img, num_classes=5, tile_size=tile, tta=tta).numpy()
+        out['tta_single'] = rtools.tta_predict(model, torch.from_numpy(out['img0'])).numpy()
+    finally:
+        torch.Tensor.cuda = cuda
+    cls = torch.from_numpy(out['probs1_tta1'])
+    out['resized'] = F.interpolate(cls, (64, 48), mode='bilinear', align_corners=True).squeeze(dim=0).numpy()
+    save('tta.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model']
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta']
     for w in which:
         globals()['gold_' + w]()

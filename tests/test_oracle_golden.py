@@ -160,3 +160,25 @@ def test_full_step_small(small_case):
         sd_eval = {k: v.detach() for k, v in st.sd.items()}
         probs = model.forward(sd_eval, t('xt'), False)
     np.testing.assert_allclose(probs.numpy(), g['probs'], rtol=2e-3, atol=2e-5)
+
+
+def test_teacher_harness_oracle_vs_reference(gold):
+    """oracle/teacher.py (pre_slide, tta_predict, soft-label resize) against the reference's own functions
+    (tests/golden/tta.npz; ttach restated, see the oracle's header)."""
+    import torch.nn.functional as F
+    from oracle import teacher
+    g = gold('tta.npz')
+    wgt, bias = torch.from_numpy(g['wgt']), torch.from_numpy(g['bias'])
+
+    def model(x):
+        return torch.softmax(F.conv2d(x, wgt, bias, padding=1), dim=1)
+    for i in range(3):
+        img, tile = torch.from_numpy(g[f'img{i}']), tuple(int(v) for v in g[f'tile{i}'])
+        for tta in (0, 1):
+            got = teacher.pre_slide(model, img, num_classes=5, tile_size=tile, tta=bool(tta))
+            np.testing.assert_allclose(got.numpy(), g[f'probs{i}_tta{tta}'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(teacher.tta_predict(model, torch.from_numpy(g['img0'])).numpy(), g['tta_single'],
+                               rtol=0, atol=1e-6)
+    np.testing.assert_allclose(teacher.soft_label(torch.from_numpy(g['probs1_tta1']), (64, 48)).numpy(), g['resized'],
+                               rtol=0, atol=1e-6)
+    assert teacher.windows(40, 24, (16, 16))[-1] == (24, 40, 8, 24)      # last window re-aligned to the border

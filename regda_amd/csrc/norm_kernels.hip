@@ -46,7 +46,9 @@ static __device__ __forceinline__ void cvt8(const u16x8& v, float (&f)[8]) {
 }
 // rows handled per thread per batch in the streaming kernels: all loads of a batch are issued before the first
 // use, so every wave keeps 4 (x up to 3 operands) 16-byte loads in flight
+#ifndef ROW_BATCH
 #define ROW_BATCH 4
+#endif
 // sign mask of 8 packed bf16 values: bit e = [value e > 0]
 static __device__ __forceinline__ unsigned char relu_bits(const uint4& v) {
     auto pos = [](unsigned h) { return (unsigned)((h & 0x7fffu) != 0 && (h & 0x8000u) == 0); };

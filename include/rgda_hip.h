@@ -326,6 +326,16 @@ int rgda_window_normalise(float* full, const float* count, int N, int C, int Hf,
 int rgda_resize_bilinear_ac(const float* src, float* dst, int N, int C, int h, int w, int H, int W,
                             rgda_stream_t stream);
 
+/* ------------------------------------------------------------- evaluation path */
+
+/* cls.argmax(dim=1) of the (N,C,H,W) probabilities (regda/utils/eval.py:43): int64 (N,H,W), first maximum wins. */
+int rgda_argmax_nchw(const float* probs, int64_t* out, int N, int C, int64_t HW, rgda_stream_t stream);
+/* Confusion matrix of the pixels with y_true >= 0 (eval.py:45-50; what ever's PixelMetric.forward accumulates):
+ * cm int64 [C][C] (row = true class, column = prediction) += counts.  flag |= 1 if a label >= C or a prediction
+ * outside [0,C) was seen (those pixels are not counted).  C <= 64. */
+int rgda_confusion_accumulate(const int64_t* y_true, const int64_t* y_pred, int64_t* cm, int* flag, int64_t n,
+                              int C, rgda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,3 +165,59 @@ extern "C" int rgda_pad_rows_nchw(const float* src, float* dst, int N, int C, in
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
+
+// ------------------------------------------------------------------ evaluation path
+// cls.argmax(dim=1) (regda/utils/eval.py:43): first maximum wins, NaN-free inputs (probabilities)
+__global__ void __launch_bounds__(256) argmax_nchw_kernel(const float* __restrict__ probs, int64_t* __restrict__ out, int N,
+                                                          int C, long long HW) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW, p = i % HW;
+        const float* s = probs + n * C * HW + p;
+        float best = s[0];
+        int arg = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = s[(long long)c * HW];
+            if (v > best) { best = v; arg = c; }
+        }
+        out[i] = arg;
+    }
+}
+
+extern "C" int rgda_argmax_nchw(const float* probs, int64_t* out, int N, int C, int64_t HW, rgda_stream_t stream) {
+    if (!probs || !out || N <= 0 || C <= 0 || HW <= 0) return RGDA_ERR_ARG;
+    argmax_nchw_kernel<<<grid_for((long long)N * HW), 256, 0, to_stream(stream)>>>(probs, out, N, C, HW);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// cm[t][p] += #{i : y_true[i] == t >= 0, y_pred[i] == p}  (eval.py:45-50: mask = cls_gt >= 0, then the confusion matrix
+// PixelMetric accumulates).  LDS histogram per workgroup, one 64-bit atomic per nonzero cell per workgroup.
+__global__ void __launch_bounds__(256) confusion_kernel(const int64_t* __restrict__ yt, const int64_t* __restrict__ yp,
+                                                        unsigned long long* __restrict__ cm, long long n, int C, int* flag) {
+    extern __shared__ unsigned int hist[];       // [C*C]
+    for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0;
+    __syncthreads();
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long t = yt[i], p = yp[i];
+        if (t < 0) continue;
+        if (t >= C || p < 0 || p >= C) { bad = 1; continue; }
+        atomicAdd(&hist[(int)t * C + (int)p], 1u);
+    }
+    if (bad) atomicOr(flag, 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256)
+        if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
+}
+
+extern "C" int rgda_confusion_accumulate(const int64_t* y_true, const int64_t* y_pred, int64_t* cm, int* flag, int64_t n,
+                                         int C, rgda_stream_t stream) {
+    if (!y_true || !y_pred || !cm || !flag || n < 0 || C <= 0 || C > 64) return RGDA_ERR_ARG;
+    if (n == 0) return RGDA_OK;
+    int grid = grid_for(n);
+    if (grid > 1024) grid = 1024;               // each workgroup counts < 2^32 elements into its 32-bit LDS cells
+    confusion_kernel<<<grid, 256, (size_t)C * C * 4, to_stream(stream)>>>(y_true, y_pred, (unsigned long long*)cm, n, C, flag);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}

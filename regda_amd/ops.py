@@ -420,3 +420,20 @@ def pad_rows(src, top, bottom):
     dst = torch.empty(n, c, h + top + bottom, w, device=src.device)
     lib().call('rgda_pad_rows_nchw', src.contiguous().data_ptr(), dst.data_ptr(), n, c, h, w, top, bottom, _stream())
     return dst
+
+
+# ----------------------------------------------------------------------------- evaluation path
+def argmax_nchw(probs):
+    n, c, h, w = probs.shape
+    out = torch.empty(n, h, w, dtype=torch.int64, device=probs.device)
+    lib().call('rgda_argmax_nchw', probs.contiguous().float().data_ptr(), out.data_ptr(), n, c, h * w, _stream())
+    return out
+
+
+def confusion_accumulate(y_true, y_pred, cm, flag):
+    """cm int64 [C, C] += counts over the pixels with y_true >= 0 (row = true class)."""
+    assert cm.dtype == torch.int64 and cm.is_contiguous() and cm.shape[0] == cm.shape[1]
+    yt, yp = y_true.contiguous().view(-1), y_pred.contiguous().view(-1)
+    assert yt.dtype == yp.dtype == torch.int64 and yt.numel() == yp.numel()
+    lib().call('rgda_confusion_accumulate', yt.data_ptr(), yp.data_ptr(), cm.data_ptr(), flag.data_ptr(), yt.numel(),
+               cm.shape[0], _stream())

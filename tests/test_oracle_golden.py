@@ -182,3 +182,16 @@ def test_teacher_harness_oracle_vs_reference(gold):
     np.testing.assert_allclose(teacher.soft_label(torch.from_numpy(g['probs1_tta1']), (64, 48)).numpy(), g['resized'],
                                rtol=0, atol=1e-6)
     assert teacher.windows(40, 24, (16, 16))[-1] == (24, 40, 8, 24)      # last window re-aligned to the border
+
+
+def test_eval_path_oracle_definitions():
+    """oracle/evalpath.py on a hand-checked 3-class confusion matrix (no reference vector exists for this row: the
+    reference's metric class sits on the un-vendored `ever` package -- see the oracle's header)."""
+    from oracle import evalpath
+    y_true = np.array([0, 0, 1, 1, 1, 2, -1, 2])
+    y_pred = np.array([0, 1, 1, 1, 0, 2, 2, 1])
+    cm = evalpath.confusion_matrix(y_true, y_pred, 3)
+    assert cm.tolist() == [[1, 1, 0], [1, 2, 0], [0, 1, 1]]
+    s = evalpath.summary(cm, ignore_labels=[0])
+    assert s['iou'] == [0.4, 0.5] and s['miou'] == 0.45                 # class 0 dropped: (2/5 + 1/2) / 2
+    assert s['recall'] == [round(2 / 3, 5), 0.5] and s['precision'] == [0.5, 1.0]

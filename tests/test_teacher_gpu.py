@@ -121,3 +121,56 @@ def test_batched_tta_equals_view_by_view_on_the_real_network():
     assert tuple(got.shape) == (1, 6, 64, 64)
     assert torch.allclose(got.sum(1), torch.ones_like(got.sum(1)), atol=1e-4)
     assert (got - acc).abs().max().item() < 2e-2
+
+
+def test_argmax_and_confusion_matrix_are_exact(ops):
+    from oracle import evalpath
+    g = torch.Generator().manual_seed(3)
+    probs = torch.softmax(torch.randn(3, 6, 37, 29, generator=g) * 2, 1)
+    probs[0, :, 5, 5] = 0.25                                     # a tie: the first maximum wins
+    pred = ops.argmax_nchw(probs.cuda())
+    assert torch.equal(pred.cpu(), probs.argmax(1)) and int(pred[0, 5, 5]) == 0
+    y_true = torch.randint(-1, 6, (3, 37, 29), generator=g)
+    cm = torch.zeros(6, 6, dtype=torch.int64, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.confusion_accumulate(y_true.cuda(), pred, cm, flag)
+    ops.confusion_accumulate(y_true.cuda(), pred, cm, flag)      # accumulates
+    ref = evalpath.confusion_matrix(y_true.numpy(), pred.cpu().numpy(), 6)
+    assert np.array_equal(cm.cpu().numpy(), 2 * ref) and int(flag) == 0
+    big_t = torch.randint(-1, 6, (4, 512, 512), generator=g)
+    big_p = torch.randint(0, 6, (4, 512, 512), generator=g)
+    cm.zero_()
+    ops.confusion_accumulate(big_t.cuda(), big_p.cuda(), cm, flag)
+    assert np.array_equal(cm.cpu().numpy(), evalpath.confusion_matrix(big_t.numpy(), big_p.numpy(), 6))
+    assert int(cm.sum()) == int((big_t >= 0).sum())
+    ops.confusion_accumulate(torch.full((8,), 6, dtype=torch.int64).cuda(), torch.zeros(8, dtype=torch.int64).cuda(), cm, flag)
+    assert int(flag) == 1                                        # label out of range: flagged, not counted
+
+
+def test_evaluate_returns_the_oracle_miou(gold):
+    """regda_amd.utils.eval.evaluate over a two-tile loader: table + mIoU with class 0 dropped (IsprsDA) equal the
+    oracle's summary of the oracle's predictions."""
+    from regda_amd.utils.eval import evaluate
+    from oracle import evalpath, teacher
+    g = gold('tta.npz')
+    model = fake_model(g)
+    gen = torch.Generator().manual_seed(4)
+    imgs = [torch.randn(1, 3, 40, 24, generator=gen) for _ in range(2)]
+    gts = [torch.randint(-1, 5, (1, 40, 24), generator=gen) for _ in range(2)]
+    loader = [(im, {'cls': gt, 'fname': ['t.tif']}) for im, gt in zip(imgs, gts)]
+
+    class Cfg:
+        DATASETS = 'IsprsDA'
+        NUM_CLASSES = 5
+        SNAPSHOT_DIR = None
+    table, miou = evaluate(model, Cfg, is_training=True, dataloader=loader, slide=True, tta=False)
+    wgt, bias = torch.from_numpy(g['wgt']), torch.from_numpy(g['bias'])
+    cpu_model = lambda x: torch.softmax(F.conv2d(x, wgt, bias, padding=1), dim=1)       # noqa: E731
+    cm = np.zeros((5, 5), np.int64)
+    for im, gt in zip(imgs, gts):
+        pred = teacher.pre_slide(cpu_model, im, num_classes=5, tile_size=(512, 512), tta=False).argmax(1)
+        cm += evalpath.confusion_matrix(gt.numpy(), pred.numpy(), 5)
+    ref = evalpath.summary(cm, ignore_labels=[0])
+    assert miou == ref['miou'] and 'mean' in table and len(table.splitlines()) == 1 + 4 + 1
+    with pytest.raises(ValueError):
+        evaluate(model, Cfg, is_training=True)

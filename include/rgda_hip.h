@@ -336,6 +336,19 @@ int rgda_argmax_nchw(const float* probs, int64_t* out, int N, int C, int64_t HW,
 int rgda_confusion_accumulate(const int64_t* y_true, const int64_t* y_pred, int64_t* cm, int* flag, int64_t n,
                               int C, rgda_stream_t stream);
 
+/* ------------------------------------------------------------- stage 2, "align"  */
+
+/* PrototypeContrastiveLoss (regda/loss.py:10-47), forward + gradient w.r.t. the features in one pass:
+ *   feat f32 NCHW (b,K,h,w); labels int64 (b,h,w), `ignore_label` pixels are removed; protos f32 (C,K), C = 6.
+ *   logits = normalize(feat_p) . normalize(protos)^T / temperature   (tnf.normalize: x / max(||x||, 1e-12))
+ *   loss[0] += weight * mean over the kept pixels of cross_entropy(logits, label)      (NaN-free only if one is kept)
+ *   dfeat (optional) bf16 [b*h*w][lddf], pixel-major -- the layout rgda_instnorm_bwd consumes: (+)= weight * dloss/dfeat
+ * ws (rgda_pcl_loss_workspace bytes): normalised prototypes, valid-pixel count, flag (bit 2: label outside [0,C)). */
+size_t rgda_pcl_loss_workspace(int C, int K);
+int rgda_pcl_loss(const float* feat, const int64_t* labels, const float* protos, float* loss, void* dfeat,
+                  int lddf, int accumulate, int b, int K, int C, int h, int w, int ignore_label,
+                  float temperature, float weight, void* ws, size_t ws_bytes, rgda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,3 +150,19 @@ def teacher_probs(x1, x2, size):
     x1 = F.interpolate(x1, size, mode='bilinear', align_corners=True)
     x2 = F.interpolate(x2, size, mode='bilinear', align_corners=True)
     return (x1.softmax(dim=1) + x2.softmax(dim=1)) / 2
+
+
+def prototype_contrastive_loss(protos, feat, labels, temperature=8.0, ignore_label=-1):
+    """regda/loss.py:10-47 (PrototypeContrastiveLoss.forward): drop ignored pixels, L2-normalise features and
+    prototypes (tnf.normalize, eps 1e-12), logits = f . P^T / temperature, mean cross entropy."""
+    import torch.nn.functional as F
+    if feat.dim() != 2:
+        k = feat.size(1)
+        feat = feat.permute(0, 2, 3, 1).reshape(-1, k)
+    labels = labels.reshape(-1)
+    mask = labels != ignore_label
+    labels, feat = labels[mask], feat[mask]
+    feat = F.normalize(feat, p=2, dim=1)
+    protos = F.normalize(protos, p=2, dim=1)
+    logits = feat.mm(protos.permute(1, 0).contiguous()) / temperature
+    return F.cross_entropy(logits, labels)

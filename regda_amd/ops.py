@@ -437,3 +437,23 @@ def confusion_accumulate(y_true, y_pred, cm, flag):
     assert yt.dtype == yp.dtype == torch.int64 and yt.numel() == yp.numel()
     lib().call('rgda_confusion_accumulate', yt.data_ptr(), yp.data_ptr(), cm.data_ptr(), flag.data_ptr(), yt.numel(),
                cm.shape[0], _stream())
+
+
+# ----------------------------------------------------------------------------- stage 2 ("align")
+def pcl_loss(feat, labels, protos, temperature=8.0, ignore_label=-1, weight=1.0, loss=None, dfeat=None, accumulate=False):
+    """PrototypeContrastiveLoss forward (+ gradient w.r.t. feat into `dfeat` bf16 [b*h*w, K] when given).
+    Returns the (accumulating) fp32 loss tensor."""
+    _need_cuda(feat, labels, protos)
+    feat = feat.contiguous().float()
+    b, K, h, w = feat.shape
+    labels = labels.contiguous().view(b, h, w)
+    assert labels.dtype == torch.int64 and protos.is_contiguous() and protos.dtype == torch.float32
+    C = protos.shape[0]
+    if loss is None:
+        loss = torch.zeros(1, device=feat.device)
+    L = lib()
+    ws = _ws(L.size('rgda_pcl_loss_workspace', C, K), feat.device)
+    L.call('rgda_pcl_loss', feat.data_ptr(), labels.data_ptr(), protos.data_ptr(), loss.data_ptr(), _p(dfeat),
+           _ld(dfeat) if dfeat is not None else 0, int(bool(accumulate)), b, K, C, h, w, ignore_label, float(temperature),
+           float(weight), ws.data_ptr(), ws.numel(), _stream())
+    return loss

@@ -335,7 +335,27 @@ def gold_tta():
     save('tta.npz', **out)
 
 
+def gold_pcl():
+    """PrototypeContrastiveLoss (regda/loss.py:10-47) and its gradient w.r.t. the features, from the reference class."""
+    from regda.loss import PrototypeContrastiveLoss
+    torch.manual_seed(23)
+    b, K, h, w, C = 2, 64, 5, 7, 6
+    out = {}
+    for i, (temp, frac_ign) in enumerate([(8.0, 0.3), (2.0, 0.0), (8.0, 0.97)]):
+        feat = (torch.randn(b, K, h, w) * 1.5 + 0.2).requires_grad_(True)
+        protos = torch.randn(C, K)
+        lab = torch.randint(0, C, (b, h, w))
+        lab[torch.rand(b, h, w) < frac_ign] = -1
+        if i == 2:
+            lab[0, 0, 0] = 3
+        loss = PrototypeContrastiveLoss(temperature=temp, ignore_label=-1)(protos, feat, lab)
+        loss.backward()
+        out.update({f'feat{i}': feat.detach().numpy(), f'protos{i}': protos.numpy(), f'lab{i}': lab.numpy(),
+                    f'temp{i}': np.float32(temp), f'loss{i}': loss.detach().numpy(), f'gfeat{i}': feat.grad.numpy()})
+    save('pcl.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta']
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta', 'pcl']
     for w in which:
         globals()['gold_' + w]()

@@ -195,3 +195,16 @@ def test_eval_path_oracle_definitions():
     s = evalpath.summary(cm, ignore_labels=[0])
     assert s['iou'] == [0.4, 0.5] and s['miou'] == 0.45                 # class 0 dropped: (2/5 + 1/2) / 2
     assert s['recall'] == [round(2 / 3, 5), 0.5] and s['precision'] == [0.5, 1.0]
+
+
+def test_prototype_contrastive_loss_oracle_vs_reference(gold):
+    """oracle.labelpath.prototype_contrastive_loss against regda/loss.py's PrototypeContrastiveLoss (loss and the
+    gradient w.r.t. the features), tests/golden/pcl.npz."""
+    g = gold('pcl.npz')
+    for i in range(3):
+        feat = torch.from_numpy(g[f'feat{i}']).requires_grad_(True)
+        loss = labelpath.prototype_contrastive_loss(torch.from_numpy(g[f'protos{i}']), feat, torch.from_numpy(g[f'lab{i}']),
+                                                    temperature=float(g[f'temp{i}']), ignore_label=-1)
+        loss.backward()
+        np.testing.assert_allclose(loss.detach().numpy(), g[f'loss{i}'], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(feat.grad.numpy(), g[f'gfeat{i}'], rtol=1e-5, atol=1e-8)

@@ -76,3 +76,63 @@ class CpuStep:
                     grad_norm=float(total), hard=hard, soft=soft, grads=dict(zip(self.names, grads)),
                     preds=(s1.detach(), s2.detach(), t1.detach(), t2.detach()),
                     feats=(feat_s.detach(), feat_t.detach()))
+
+
+class CpuAlignStep(CpuStep):
+    """One stage-2 iteration, tools/train_align_reg.py:144-196 (defaults: --align-domain 0, --refine-label 1,
+    --refine-mode all, --pcl-temp 8): source forward, update_prototype, target forward, the student's own
+    (softmax(up x1) + softmax(up x2)) / 2 as soft labels, label_refine, pseudo_selection, LRH, DownscaleLabel,
+    loss = CE(source) + 0.5 * (PCL(source) + PCL(target)), backward, clip, SGD."""
+
+    def __init__(self, *a, pcl_temp=8.0, **k):
+        super().__init__(*a, **k)
+        self.pcl_temp = pcl_temp
+
+    def step(self, images_s, label_s, images_t, regs_t, drop_masks_s=None, drop_masks_t=None, lr=None):
+        import torch.nn.functional as F
+        sd = self.sd
+        ns = {}
+        s1, s2, feat_s = model.forward(sd, images_s, True, drop_masks_s, self.rt, ns)
+        for k, v in ns.items():
+            sd[k] = v
+        with torch.no_grad():
+            self.prototypes, label_s_down = labelpath.update_prototype(feat_s, label_s, self.prototypes, self.pdecay,
+                                                                       self.C, self.ig)
+        ns = {}
+        t1, t2, feat_t = model.forward(sd, images_t, True, drop_masks_t, self.rt, ns)
+        for k, v in ns.items():
+            sd[k] = v
+        with torch.no_grad():
+            size = images_t.shape[-2:]
+            x1 = F.interpolate(t1, size, mode='bilinear', align_corners=True)
+            x2 = F.interpolate(t2, size, mode='bilinear', align_corners=True)
+            soft_t = (x1.softmax(dim=1) + x2.softmax(dim=1)) * 0.5
+            soft = labelpath.label_refine(feat_t, self.prototypes, [t1, t2], soft_t, True, 'all', self.temp)
+            hard = torch.from_numpy(labels.pseudo_selection(soft.numpy(), self.top, self.low, self.ig))
+            if self.sam:
+                hard = torch.from_numpy(labels.homogenize(hard.numpy(), regs_t.squeeze(1).numpy(),
+                                                          self.percent, self.C, self.ig))
+            label_t = torch.from_numpy(labels.downscale_label(hard.numpy(), 16, self.C, self.ig, 0.75))
+        loss_seg = labelpath.loss_calc([s1, s2], label_s, self.ig)
+        loss_align = (labelpath.prototype_contrastive_loss(self.prototypes, feat_s, label_s_down, self.pcl_temp, self.ig) +
+                      labelpath.prototype_contrastive_loss(self.prototypes, feat_t, label_t, self.pcl_temp, self.ig)) * 0.5
+        loss = loss_seg + loss_align
+        params = [sd[k] for k in self.names]
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        grads = [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)]
+        with torch.no_grad():
+            total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+            coef = torch.clamp(self.max_norm / (total + 1e-6), max=1.0)
+            lr = self.lr if lr is None else lr
+            for k, g in zip(self.names, grads):
+                g = g * coef
+                p = sd[k]
+                d = g + self.wd * p
+                if self.mom[k] is None:
+                    self.mom[k] = d.clone()
+                else:
+                    self.mom[k].mul_(self.m).add_(d)
+                p.sub_(lr * self.mom[k])
+        return dict(loss=float(loss.detach()), loss_seg=float(loss_seg.detach()), loss_align=float(loss_align.detach()),
+                    grad_norm=float(total), hard=hard, label_t=label_t, label_s_down=label_s_down,
+                    grads=dict(zip(self.names, grads)), feats=(feat_s.detach(), feat_t.detach()))

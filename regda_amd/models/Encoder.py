@@ -760,7 +760,9 @@ class Deeplabv2(nn.Module):
         return logits[0], logits[1], feat
 
     # ------------------------------------------------------------------ backward plan
-    def _backward_plan(self, T, g1, g2, on_progress=None):
+    def _backward_plan(self, T, g1, g2, on_progress=None, gfeat=None):
+        """g1, g2: d(loss)/d(logits) of the two heads (N, classes, h, w) f32.  gfeat (optional): d(loss)/d(feat) of the
+        third forward output, bf16 pixel-major [N*h*w, 2048] -- the stage-2 prototype loss acts on the features."""
         dev = self.device
         if getattr(self, '_wt_ready', None) is not None:       # transposed weights rebuilt on another stream
             torch.cuda.current_stream().wait_event(self._wt_ready)
@@ -795,7 +797,7 @@ class Deeplabv2(nn.Module):
         gpool = torch.empty(M, 2048, dtype=BF, device=dev)
         ops.spatial_mix_multi(dpools, [mats[s][1] for s in POOL_SCALES], gpool, N, HW, 2048)
         g = torch.empty(M, 2048, dtype=BF, device=dev)
-        ops.instnorm_bwd(dfeat, None, gpool, y4, imi, g, N, HW, 2048)
+        ops.instnorm_bwd(dfeat, gfeat, gpool, y4, imi, g, N, HW, 2048)
         del dfeat, gpool
         self._progress(T, self._offset_of('layer5.ppm.0.1'))
         hh, ww = h, w

@@ -144,7 +144,14 @@ class SSLStep:
         loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
         loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
         self._mark('label path + losses done')
-        # ---- backward (both domains in one pass); all-reduce buckets are released as it moves down the net
+        self._backward_and_update(T, main, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]))
+        self.last_hard = hard
+        return loss_s, loss_t, self.gn
+
+    def _backward_and_update(self, T, main, g1, g2, gfeat=None):
+        """Backward (both domains in one pass; all-reduce buckets are released as it moves down the net), then clip +
+        SGD (+ EMA) in one pass over the flat buffers."""
+        m = self.model
         self.reducer.reset()
         T['wgrad_stream'] = self.wgrad_stream
         T['main_stream'] = main
@@ -161,7 +168,7 @@ class SSLStep:
                         self.reducer.ready_down_to(offset)
                 else:
                     self.reducer.ready_down_to(offset)
-        m._backward_plan(T, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]), on_progress=progress)
+        m._backward_plan(T, g1, g2, on_progress=progress, gfeat=gfeat)
         self._mark('backward done (streams joined)')
         self.reducer.finish()
         # ---- clip + SGD (+ EMA) in one pass over the flat buffers
@@ -173,8 +180,6 @@ class SSLStep:
         m.sync_derived_weights(self.wgrad_stream)
         m._synced_version = m.flat_p._version
         self._mark('optimizer + weight mirrors done')
-        self.last_hard = hard
-        return loss_s, loss_t, self.gn
 
     @torch.no_grad()
     def teacher_probs(self, images_t):

@@ -58,3 +58,47 @@ def test_pcl_loss_production_shape_weight_and_accumulate():
     assert torch.isnan(none).all() and float(df.float().abs().max()) == 0.0
     with pytest.raises(ValueError):
         ops.pcl_loss(feat.cuda(), lab.cuda(), torch.randn(5, K).cuda())
+
+
+def test_align_step_matches_the_oracle_stage2_step():
+    """regda_amd.align.AlignStep (stage 2, tools/train_align_reg.py:144-196) end to end against oracle.step.CpuAlignStep
+    on the shallow topology: losses, labels, gradient norm, prototype update, SGD direction."""
+    from oracle import model as omodel
+    from oracle.step import CpuAlignStep
+    from regda_amd.align import AlignStep
+    from regda_amd.models.Encoder import Deeplabv2
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=6)
+    b = make_batch(b=4, size=128, seed=11, device='cpu')
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(1))
+    ones = torch.ones(4, 512)
+    cpu = CpuAlignStep(sd, protos, resnet_type=rt, lr=1e-3, proto_decay=0.999)
+    ref = cpu.step(b['images_s'], b['label_s'], b['images_t'], b['regs_t'], (ones, ones), (ones, ones))
+    m = Deeplabv2(dict(backbone=dict(resnet_type=rt, output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+                       use_ppm=True, ppm=dict(num_classes=6, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=6,
+                       is_ins_norm=True))
+    m.load_state_dict(sd, strict=True)
+    m.set_drop_masks(ones, ones)
+    st = AlignStep(m, protos)
+    g = {k: v.cuda() for k, v in b.items()}
+    lseg, lal, gn = st.step(g['images_s'], g['label_s'], g['images_t'], g['regs_t'], 1e-3)
+    # stated tolerances: bf16 network (DESIGN.md section 5)
+    assert lseg.item() == pytest.approx(ref['loss_seg'], rel=0.02)
+    assert lal.item() == pytest.approx(ref['loss_align'], rel=0.02)
+    assert gn.sqrt().item() == pytest.approx(ref['grad_norm'], rel=0.06)
+    # the source-side integer path is exact (same labels in), the target side may move a few borderline pixels
+    assert torch.equal(st.last_label_s_down.cpu(), ref['label_s_down'])
+    assert (st.last_hard.cpu() != ref['hard']).float().mean().item() < 0.03
+    assert (st.last_label_t.cpu() != ref['label_t']).float().mean().item() < 0.05
+    assert ((st.prototypes.cpu() - cpu.prototypes).norm() / cpu.prototypes.norm()).item() < 2e-3
+    named = dict(m.named_parameters())
+    for k, tol in (('encoder.resnet.layer4.1.conv3.weight', 0.97), ('encoder.resnet.conv1.weight', 0.9)):
+        d_ref = cpu.sd[k].detach() - sd[k]
+        d_got = named[k].detach().cpu() - sd[k]
+        cos = (d_ref.flatten() @ d_got.flatten() / (d_ref.norm() * d_got.norm())).item()
+        assert cos > tol, (k, cos)
+    # the classifier sees only the source CE: its update must match closely
+    k = 'layer5.conv_last.4.weight'
+    d_ref, d_got = cpu.sd[k].detach() - sd[k], named[k].detach().cpu() - sd[k]
+    assert ((d_got - d_ref).norm() / d_ref.norm()).item() < 0.08

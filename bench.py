@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 24.7 vs 24.1 ms)')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--phases', action='store_true', help='HIP-event phase marks of one extra step, to stderr')
+    ap.add_argument('--align-steps', type=int, default=0, help='also time this many stage-2 ("align", SURVEY 8f.2) '
+                    'iterations on the same model and batch; adds "align_step" to the JSON')
     ap.add_argument('--tta-tiles', type=int, default=0, help='also time the teacher harness (SURVEY 8f.1): 8-view TTA '
                     'sliding-window inference of this many 512x512 target tiles; adds "teacher_harness" to the JSON')
     return ap.parse_args()
@@ -313,6 +315,21 @@ def main():
                            'all_conv_kernels': {'achieved': gf / ms, 'frac': gf / ms / MFMA_PEAK_TFLOPS,
                                                 'gflop_per_step': gf, 'ms_per_step': ms},
                            'by_kernel': kern}
+    if rank == 0 and world == 1 and args.align_steps > 0:
+        from regda_amd.align import AlignStep
+        ast = AlignStep(model, step.prototypes, overlap_wgrad=not args.serial)
+        for _ in range(2):
+            ast.step(batch['images_s'], batch['label_s'], batch['images_t'], batch['regs_t'], 1e-3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.align_steps):
+            oa = ast.step(batch['images_s'], batch['label_s'], batch['images_t'], batch['regs_t'], 1e-3)
+        torch.cuda.synchronize()
+        dt_a = (time.perf_counter() - t0) / args.align_steps
+        res['align_step'] = {'pairs_per_s': args.batch / dt_a, 'ms_per_step': dt_a * 1e3,
+                             'loss_seg': float(oa[0].item()), 'loss_align': float(oa[1].item()),
+                             'what': 'stage-2 iteration (tools/train_align_reg.py:144-196): no teacher forward, prototype '
+                                     'contrastive loss on the features'}
     if rank == 0 and world == 1 and args.tta_tiles > 0:
         from regda_amd.utils.tools import pre_slide
         tm = step.teacher if step.teacher is not None else model

@@ -303,6 +303,62 @@ def gold_model():
          nbt=sdn['encoder.resnet.bn1.num_batches_tracked'].numpy(), probs=probs.numpy(), **grads)
 
 
+def gold_align():
+    """One stage-2 iteration on the reference model, composed exactly like tools/train_align_reg.py:144-196 (defaults
+    --align-domain 0, --refine-label 1, --refine-mode all, --refine-temp 2, --sam-refine, --pcl-temp 8), same inputs as
+    gold_model so the fixture stays small: only what differs is stored."""
+    import torch.nn.functional as tnf
+    from regda.loss import PrototypeContrastiveLoss
+    src = np.load(os.path.join(HERE, 'model_small.npz'))
+    m = build_ref_model()
+    sd = omodel.init_state_dict('resnet101', 6, seed=1)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    masks = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            i, o = inp[0].detach(), out.detach()
+            keep = ((o != 0).flatten(2).any(-1) | (i == 0).flatten(2).all(-1))
+            masks.setdefault(name, []).append(keep.numpy().astype(np.uint8))
+        return fn
+    m.layer5.conv_last[3].register_forward_hook(hook('m5'))
+    m.layer6.conv_last[3].register_forward_hook(hook('m6'))
+    xs, xt = torch.from_numpy(src['xs']), torch.from_numpy(src['xt'])
+    lab_s = torch.from_numpy(src['lab_s'].astype(np.int64))
+    regs = torch.from_numpy(src['regs'].astype(np.int64))
+    al = Aligner(logger=_Log(), feat_channels=2048, class_num=6, ignore_label=-1, decay=0.999, resume=None)
+    al.prototypes = torch.from_numpy(src['protos']).clone()
+    hom = Homogenizer(percent=0.5, class_num=6, ignore_label=-1)
+    ce = CrossEntropy(ignore_label=-1, class_balancer=None)
+    pcl = PrototypeContrastiveLoss(temperature=8.0, ignore_label=-1)
+    torch.manual_seed(77)
+    s1, s2, fs = m(xs)
+    label_s_down = al.update_prototype(fs, lab_s)
+    t1, t2, ft = m(xt)
+    x1 = tnf.interpolate(t1, xt.shape[-2:], mode='bilinear', align_corners=True)
+    x2 = tnf.interpolate(t2, xt.shape[-2:], mode='bilinear', align_corners=True)
+    soft = ((x1.softmax(dim=1) + x2.softmax(dim=1)) * 0.5).detach()
+    soft = al.label_refine(None, ft, [t1, t2], soft, refine=True, mode='all', temp=2.0)
+    hard = pseudo_selection(soft, cutoff_top=0.8, cutoff_low=0.6, return_type='tensor', ignore_label=-1)
+    hard = hom(hard, regs.squeeze(dim=1))
+    label_t = al.downscale_gt(hard)
+    loss_seg = loss_calc([s1, s2], lab_s, loss_fn=ce, multi=True)
+    loss_align = (pcl(al.prototypes, fs, label_s_down) + pcl(al.prototypes, ft, label_t)) * 0.5
+    loss = loss_seg + loss_align
+    loss.backward()
+    named = dict(m.named_parameters())
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None)).item()
+    sel = ['encoder.resnet.conv1.weight', 'encoder.resnet.bn1.bias', 'layer5.conv_last.4.weight',
+           'encoder.resnet.layer4.2.bn3.bias', 'layer6.ppm.3.2.bias']
+    grads = {('grad:' + k): named[k].grad.numpy() for k in sel}
+    grads['grad:layer3.10.conv2.weight[:2]'] = named['encoder.resnet.layer3.10.conv2.weight'].grad[:2].numpy()
+    save('align_small.npz', m5=np.stack(masks['m5']), m6=np.stack(masks['m6']),
+         label_s_down=label_s_down.numpy().astype(np.int8), soft=soft.numpy(), hard=hard.numpy().astype(np.int8),
+         label_t=label_t.numpy().astype(np.int8), protos_new=al.prototypes.numpy(),
+         loss_seg=loss_seg.detach().numpy(), loss_align=loss_align.detach().numpy(), grad_norm=np.float64(gn), **grads)
+
+
 def gold_tta():
     """The reference's own pre_slide / tta_predict (regda/utils/tools.py:61-97,132-152) on a small deterministic
     'model' that is not equivariant under flips / rotations, plus the align_corners=True soft-label resize of
@@ -356,6 +412,6 @@ def gold_pcl():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta', 'pcl']
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta', 'pcl', 'align']
     for w in which:
         globals()['gold_' + w]()

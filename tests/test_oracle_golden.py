@@ -208,3 +208,25 @@ def test_prototype_contrastive_loss_oracle_vs_reference(gold):
         loss.backward()
         np.testing.assert_allclose(loss.detach().numpy(), g[f'loss{i}'], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(feat.grad.numpy(), g[f'gfeat{i}'], rtol=1e-5, atol=1e-8)
+
+
+def test_full_stage2_step_small(small_case, gold):
+    """End-to-end: oracle.step.CpuAlignStep vs the reference's stage-2 iteration composed as
+    tools/train_align_reg.py:144-196 (tests/golden/align_small.npz; same inputs as the SSL fixture)."""
+    g, sd = small_case
+    a = gold('align_small.npz')
+    t = lambda k: torch.from_numpy(g[k])        # noqa: E731
+    st = step.CpuAlignStep(sd, t('protos'), lr=0.0, proto_decay=0.999)
+    m5, m6 = torch.from_numpy(a['m5']), torch.from_numpy(a['m6'])
+    r = st.step(t('xs'), t('lab_s').long(), t('xt'), t('regs').long(), (m5[0], m6[0]), (m5[1], m6[1]))
+    assert np.array_equal(r['label_s_down'].numpy(), a['label_s_down'].astype(np.int64))
+    assert (r['hard'].numpy() != a['hard'].astype(np.int64)).mean() < 2e-3
+    assert (r['label_t'].numpy() != a['label_t'].astype(np.int64)).mean() < 0.07      # 32 cells: at most two flips
+    np.testing.assert_allclose(st.prototypes.numpy(), a['protos_new'], rtol=1e-4, atol=1e-6)
+    assert r['loss_seg'] == pytest.approx(float(a['loss_seg']), rel=1e-4)
+    assert r['loss_align'] == pytest.approx(float(a['loss_align']), rel=1e-3)
+    assert r['grad_norm'] == pytest.approx(float(a['grad_norm']), rel=5e-3)
+    for k in ['encoder.resnet.conv1.weight', 'layer5.conv_last.4.weight', 'encoder.resnet.bn1.bias',
+              'encoder.resnet.layer4.2.bn3.bias', 'layer6.ppm.3.2.bias']:
+        ref, got = a['grad:' + k], r['grads'][k].numpy()
+        assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, k

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 1
+#define RGDA_ABI_VERSION 2
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the fp32 atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore f32[RGDA_STAT_REPLICAS][2][C], zeroed by the caller. */

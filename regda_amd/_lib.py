@@ -62,8 +62,9 @@ class _Lib:
                 continue
             fn.restype = restype
             fn.argtypes = argtypes
-        if self._dll.rgda_abi_version() != 1:
-            raise ImportError('librgda_hip.so ABI version mismatch')
+        want = int(re.search(r'#define\s+RGDA_ABI_VERSION\s+(\d+)', open(HEADER_PATH).read()).group(1))
+        if self._dll.rgda_abi_version() != want:
+            raise ImportError('librgda_hip.so ABI version mismatch: rebuild with `make -C regda_amd/csrc`')
 
     def raw(self, name):
         return getattr(self._dll, name)

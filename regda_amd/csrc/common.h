@@ -41,5 +41,15 @@ static __device__ __forceinline__ float wave_max(float v) {
 }
 
 #define NREP RGDA_STAT_REPLICAS
+
+// Tuning hooks (tile overrides, per-workgroup timestamps, ablation switches) read environment variables.  They exist
+// only in a tuning build (`make TUNING=1`, what tests/dev_*.py expect); the product library never looks at the
+// environment.
+#include <stdlib.h>
+#ifdef RGDA_TUNING
+#define TUNE_ENV(name) getenv(name)
+#else
+#define TUNE_ENV(name) ((const char*)nullptr)
+#endif
 static inline hipStream_t to_stream(rgda_stream_t s) { return (hipStream_t)s; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

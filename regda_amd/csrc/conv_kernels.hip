@@ -450,8 +450,8 @@ static int pick_tile(long long M, int Cout, long long ktot, int rows_per_group, 
     bp = 64;
     int waves = 4;
     int t82 = 512, t83 = 256;
-    if (const char* e = getenv("RGDA_T82")) t82 = atoi(e);     // tuning experiments only
-    if (const char* e = getenv("RGDA_T83")) t83 = atoi(e);     // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_T82")) t82 = atoi(e);     // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_T83")) t83 = atoi(e);     // tuning experiments only
     if (bc == 128 && ktot >= 4096 && (long long)cdiv(M, 256) * cdiv(Cout, bc) >= 240) { bp = 256; waves = 8; }
     else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= t82) { bp = 128; waves = 8; }
     else if (bc == 128 && (long long)cdiv(M, 128) * cdiv(Cout, bc) >= t83) { bp = 128; waves = 9; }
@@ -514,16 +514,16 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         a.ev_relu = bne->relu;
     }
     a.dbg = nullptr; a.skip = 0;
-    if (const char* e = getenv("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
-    if (const char* e = getenv("RGDA_CONV_SKIP")) a.skip = atoi(e);                                      // tuning only
+    if (const char* e = TUNE_ENV("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
+    if (const char* e = TUNE_ENV("RGDA_CONV_SKIP")) a.skip = atoi(e);                                      // tuning only
     int bc, bp, stages;
     if (pick_tile(M, Cout, (long long)kh * kw * Cin, (stats && stat_groups > 1) ? a.rows_per_group : 0, bc, bp, stages))
         return RGDA_ERR_UNSUPPORTED;
-    if (const char* e = getenv("RGDA_TILE")) sscanf(e, "%d,%d,%d", &bc, &bp, &stages);   // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_TILE")) sscanf(e, "%d,%d,%d", &bc, &bp, &stages);   // tuning experiments only
     a.tiles_c = cdiv(Cout, bc);
     a.tiles_p = cdiv(M, bp);
     int grid = a.tiles_c * a.tiles_p;
-    static const bool pipe = getenv("RGDA_NO_PIPE") == nullptr;                           // (off switch: tuning experiments only)
+    static const bool pipe = TUNE_ENV("RGDA_NO_PIPE") == nullptr;                           // (off switch: tuning experiments only)
     if (pipe && bc == 128 && bp == 128 && stages == 83) conv_igemm_kernel<128, 128, 3, 2, 4, true><<<grid, 512, 0, st>>>(a);
     else if (pipe && bc == 128 && bp == 256 && stages == 83) conv_igemm_kernel<128, 256, 3, 2, 4, true><<<grid, 512, 0, st>>>(a);
     else if (pipe && bc == 128 && bp == 64 && stages == 3) conv_igemm_kernel<128, 64, 3, 2, 2, true><<<grid, 256, 0, st>>>(a);
@@ -1019,12 +1019,12 @@ static int wgrad_prepare(const rgda_wgrad_desc& d, WgradArgs& a) {
     a.howo_shift = ilog2_exact(d.Ho * d.Wo);
     a.wo_shift = ilog2_exact(d.Wo);
     a.dbg = nullptr;
-    if (const char* e = getenv("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
+    if (const char* e = TUNE_ENV("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
     a.splits = 1; a.kt_per_split = 0;
     // tap-fused path: 3x3, stride 1, "same" padding, the map tiles into 64-pixel row blocks
     a.tap_fused = 0;
     if (d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == d.dil && d.Ho == d.H && d.Wo == d.W &&
-        cdiv(d.Cout, 64) * cdiv(d.Cin, 64) >= 8 && !getenv("RGDA_WGRAD_GENERIC")) {
+        cdiv(d.Cout, 64) * cdiv(d.Cin, 64) >= 8 && !TUNE_ENV("RGDA_WGRAD_GENERIC")) {
         int wt = (d.W >= 64) ? 64 : d.W;
         if ((wt == 64 || wt == 32 || wt == 16) && (d.W % wt) == 0 && (d.H % (64 / wt)) == 0 && (d.dil == 1 || d.dil == 2)) {
             a.tap_fused = 1;
@@ -1055,7 +1055,7 @@ static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
     for (int l = 0; l < g.n; ++l) total += wgrad_tiles(g.a[l]);
     const int target = (kind >= WK_F64_1) ? 256 : 512;
     int minkt = 16;
-    if (const char* e = getenv("RGDA_WGRAD_MINKT")) minkt = atoi(e);                     // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_WGRAD_MINKT")) minkt = atoi(e);                     // tuning experiments only
     int items = 0;
     for (int l = 0; l < g.n; ++l) {
         WgradArgs& a = g.a[l];
@@ -1063,7 +1063,7 @@ static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
         int splits = cdiv(target, total);
         if (splits > KT / minkt) splits = KT / minkt;
         if (splits < 1) splits = 1;
-        if (const char* e = getenv("RGDA_WGRAD_SPLITS")) splits = atoi(e);               // tuning experiments only
+        if (const char* e = TUNE_ENV("RGDA_WGRAD_SPLITS")) splits = atoi(e);               // tuning experiments only
         a.kt_per_split = cdiv(KT, splits);
         a.splits = cdiv(KT, a.kt_per_split);
         g.first[l] = items;
@@ -1074,7 +1074,7 @@ static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
     // times (the taps of the small-channel 3x3 layers in the 64x64 kernel: 297 -> 220 us; tap-fused: 2 %); the
     // grouped 1x1 layers of the 128x128 kernel measured 9 % SLOWER with it (207 -> 225 us), so they keep b -> item b
     g.remap = (kind != WK_G128_128);
-    if (const char* e = getenv("RGDA_WGRAD_REMAP")) g.remap = atoi(e);                   // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_WGRAD_REMAP")) g.remap = atoi(e);                   // tuning experiments only
     switch (kind) {
         case WK_G128_128: conv_wgrad_kernel<128, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
         case WK_G128_64: conv_wgrad_kernel<128, 64, 4, 2><<<items, 512, 0, st>>>(g); break;

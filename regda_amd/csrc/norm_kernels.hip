@@ -301,11 +301,11 @@ static void elementwise_grid(long long M, int C, int groups, RowLayout& L, int& 
     // small maps (<= 16M elements per launch): at most 128 channels per workgroup -- every workgroup first rebuilds
     // (or loads) the statistics of its channels, 16 floats each, which must stay small next to the rows it streams
     if ((long long)M * groups * C <= (1ll << 24) && L.vpb > 16) { L.vpb = 16; L.rpb = 16; }
-    if (const char* e = getenv("RGDA_BN_VPB")) {                  // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_BN_VPB")) {                  // tuning experiments only
         int v = atoi(e);
         if (v < L.vpb) { L.vpb = v; L.rpb = 256 / v; }
     }
-    if (const char* e = getenv("RGDA_BN_ROWS")) rows_mult = atoi(e);   // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_BN_ROWS")) rows_mult = atoi(e);   // tuning experiments only
     rows_per_block = L.rpb * rows_mult;
     while ((long long)cdiv(M, rows_per_block) * groups * cdiv(L.vpr, L.vpb) > 8192) rows_per_block *= 2;
     bpg = cdiv(M, rows_per_block);
@@ -1127,7 +1127,7 @@ extern "C" int rgda_classifier_bwd(const void* hidden, int ldh, const float* w, 
     // every workgroup ends with ncls*C fp32 atomics onto the SAME addresses (cross-XCD same-address atomics are slow):
     // few, long workgroups
     int rows_per_block = 256;
-    if (const char* e = getenv("RGDA_CLS_ROWS")) rows_per_block = atoi(e);     // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_CLS_ROWS")) rows_per_block = atoi(e);     // tuning experiments only
     while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 1024) rows_per_block *= 2;
     dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
     classifier_bwd_kernel<6><<<grid, 256, (size_t)256 * 8 * 6 * 4, to_stream(stream)>>>(

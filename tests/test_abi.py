@@ -7,7 +7,7 @@ from regda_amd import _lib
 def test_library_loads_and_exports_all_symbols():
     L = _lib.lib()
     assert L.missing == [], f'declared but not exported: {L.missing}'
-    assert L.raw('rgda_abi_version')() == 1
+    assert L.raw('rgda_abi_version')() == 2
     assert L.raw('rgda_strerror')(0) == b'ok'
     assert b'workspace' in L.raw('rgda_strerror')(-2)
     assert len(L.protos) >= 30

@@ -349,6 +349,21 @@ int rgda_pcl_loss(const float* feat, const int64_t* labels, const float* protos,
                   int lddf, int accumulate, int b, int K, int C, int h, int w, int ignore_label,
                   float temperature, float weight, void* ws, size_t ws_bytes, rgda_stream_t stream);
 
+/* ------------------------------------------------------------- ASPP head */
+
+/* Classifier_Module (regda/models/Encoder.py:68-84): out = sum_d Conv2d(K -> C, 3x3, padding = dilation = dil[d],
+ * bias)(x), for the model's two heads at once.  The 2*4 convolutions' taps are computed as ONE 1x1 convolution
+ * (rgda_conv2d) Z = x @ Wstack^T, Z bf16 [N*h*w][ldz] with column ((head*4 + d)*C + c)*9 + tap -- the stacked filter
+ * is the eight [C][3][3][K] weights back to back -- and these two entry points do the rest:
+ *   gather : out_head f32 (N,C,h,w) = sum_d bias[head*4+d][c] + sum_{d,tap} Z[(y + dy*dil[d], x + dx*dil[d])][col]
+ *   scatter: dZ (bf16 [N*h*w][lddz], zc >= 72*C columns, the pad columns zeroed) from the two logit gradients
+ *            g_head f32 (N,C,h,w), and dbias[head*4+d][c] += sum g_head[:,c]   (deterministic).
+ * bias / dbias: HOST arrays of eight DEVICE pointers; dil: HOST array of four dilations. */
+int rgda_aspp_gather(const void* z, int ldz, const float* const* bias, float* out1, float* out2, int N, int h,
+                     int w, int C, const int* dil, rgda_stream_t stream);
+int rgda_aspp_scatter(const float* g1, const float* g2, void* dz, int lddz, int zc, float* const* dbias, int N,
+                      int h, int w, int C, const int* dil, rgda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

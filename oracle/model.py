@@ -1,6 +1,7 @@
 """Functional fp32 CPU restatement of the reference network.  TEST INFRASTRUCTURE ONLY.
 
   Deeplabv2.forward (PPM branch)  <- regda/models/Encoder.py:129,145-155
+  Classifier_Module (ASPP heads)  <- regda/models/Encoder.py:68-84,111-114   (head='aspp': use_ppm=False)
   PPMBilinear.forward             <- regda/models/Encoder.py:43-55
   ResNetEncoder.forward (OS16)    <- regda/resnet.py:140-166,192-207
   Bottleneck.forward              <- regda/_resnets.py:92-112
@@ -15,6 +16,7 @@ import torch.nn.functional as F
 LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3),
           'resnet17t': (2, 1, 1, 2)}   # resnet17t: test-only shallow topology (same code paths, 6 blocks)
 POOL_SCALES = (1, 2, 3, 6)
+ASPP_DILATIONS = (6, 12, 18, 24)       # dilation_series = padding_series, Encoder.py:111-114
 
 
 def layer_specs(resnet_type='resnet101'):
@@ -34,7 +36,7 @@ def layer_specs(resnet_type='resnet101'):
 
 
 def init_state_dict(resnet_type='resnet101', num_classes=6, seed=0, dtype=torch.float32, res_gamma=0.1,
-                    ppm0_gamma=0.0):
+                    ppm0_gamma=0.0, head='ppm'):
     """Seeded random weights in the reference layout: conv kaiming_normal(fan_out)
     (_resnets.py:164-169), BN gamma ~ U(0.5,1.5), beta ~ N(0,0.1) (non-trivial on
     purpose so affine terms are exercised), running stats (0,1).  The last BN of every
@@ -71,11 +73,16 @@ def init_state_dict(resnet_type='resnet101', num_classes=6, seed=0, dtype=torch.
         conv(p + '.conv3', planes * 4, planes, 1); bn(p + '.bn3', planes * 4, res_gamma)
         if ds:
             conv(p + '.downsample.0', planes * 4, inpl, 1); bn(p + '.downsample.1', planes * 4)
-    for head in ('layer5', 'layer6'):
+    for hd in ('layer5', 'layer6'):
+        if head == 'aspp':
+            for i in range(len(ASPP_DILATIONS)):
+                sd[f'{hd}.conv2d_list.{i}.weight'] = torch.randn(num_classes, 2048, 3, 3, generator=g, dtype=dtype) * 0.01
+                sd[f'{hd}.conv2d_list.{i}.bias'] = torch.randn(num_classes, generator=g, dtype=dtype) * 0.1
+            continue
         for i in range(4):
-            conv(f'{head}.ppm.{i}.1', 512, 2048, 1); bn(f'{head}.ppm.{i}.2', 512, ppm0_gamma if i == 0 else 1.0)
-        conv(f'{head}.conv_last.0', 512, 2048 + 4 * 512, 3); bn(f'{head}.conv_last.1', 512)
-        conv(f'{head}.conv_last.4', num_classes, 512, 1, bias=True)
+            conv(f'{hd}.ppm.{i}.1', 512, 2048, 1); bn(f'{hd}.ppm.{i}.2', 512, ppm0_gamma if i == 0 else 1.0)
+        conv(f'{hd}.conv_last.0', 512, 2048 + 4 * 512, 3); bn(f'{hd}.conv_last.1', 512)
+        conv(f'{hd}.conv_last.4', num_classes, 512, 1, bias=True)
     return sd
 
 
@@ -96,6 +103,15 @@ def _bn(x, sd, name, training, new_stats):
 def _rb(x):
     """Round to bf16 with a straight-through gradient (used by emulate_bf16)."""
     return x + (x.to(torch.bfloat16).float() - x).detach()
+
+
+def aspp_head(x, weights, biases, dilations=ASPP_DILATIONS):
+    """Classifier_Module.forward (Encoder.py:80-84): sum of Conv2d(3x3, padding = dilation = d, bias)(x)."""
+    out = None
+    for w, b, d in zip(weights, biases, dilations):
+        t = F.conv2d(x, w, b, 1, d, d)
+        out = t if out is None else out + t
+    return out
 
 
 def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_stats=None,
@@ -122,6 +138,7 @@ def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_
         return t
 
     rb = _rb if emulate_bf16 else (lambda t: t)
+    aspp = 'layer5.conv2d_list.0.weight' in sd
     if emulate_bf16:
         sd = {k: (_rb(v) if (v.dim() == 4 and 'conv_last.4' not in k) else v) for k, v in sd.items()}
         x = _rb(x)
@@ -147,7 +164,11 @@ def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_
     tap('feat', feat)
     featq = rb(feat)
     outs = []
-    for hi, head in enumerate(('layer5', 'layer6')):
+    for head in (('layer5', 'layer6') if aspp else ()):
+        # Classifier_Module.forward (Encoder.py:80-84): the four dilated 3x3 convs, summed
+        outs.append(aspp_head(featq, [sd[f'{head}.conv2d_list.{i}.weight'] for i in range(len(ASPP_DILATIONS))],
+                              [sd[f'{head}.conv2d_list.{i}.bias'] for i in range(len(ASPP_DILATIONS))]))
+    for hi, head in enumerate(() if aspp else ('layer5', 'layer6')):
         size = feat.shape[-2:]
         parts = [featq]
         for i, s in enumerate(POOL_SCALES):

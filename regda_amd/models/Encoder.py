@@ -1,7 +1,8 @@
 """Deeplabv2 (ResNet encoder, output stride 16, InstanceNorm, two PPMBilinear heads) -- the host-side
 mirror of regda/models/Encoder.py:87-186 + regda/resnet.py:43-207 + regda/_resnets.py:72-112 for the
 configuration every st.regda.* entry point builds (tools/train_ssl_reg.py:94-111):
-    multi_layer=True, cascade=False, use_ppm=True, is_ins_norm=True.
+    multi_layer=True, cascade=False, use_ppm=True, is_ins_norm=True,
+and for its use_ppm=False sibling with two ASPP heads (Classifier_Module, Encoder.py:68-84,111-114).
 
 Same constructor (a config dict), same train()/eval() outputs ((x1, x2, feat) / class probabilities),
 same state_dict layout (688 keys for ResNet-101) as the reference, so checkpoints interchange.
@@ -28,6 +29,7 @@ LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3),
           'resnet17t': (2, 1, 1, 2)}   # resnet17t: test-only shallow topology (same code paths, 6 blocks)
 POOL_SCALES = (1, 2, 3, 6)
 NREP = 8                # RGDA_STAT_REPLICAS (include/rgda_hip.h)
+ASPP_DILATIONS = (6, 12, 18, 24)     # dilation_series = padding_series of every Classifier_Module (Encoder.py:101-114)
 STEM_KP = 192           # 7*7*3 = 147 im2col columns, zero padded to a multiple of 64
 
 
@@ -153,9 +155,13 @@ class Deeplabv2(nn.Module):
                 cfg[k] = v
         self.config = cfg
         rt = cfg['backbone']['resnet_type']
-        if not (cfg['multi_layer'] and cfg['use_ppm'] and not cfg['cascade'] and cfg['is_ins_norm']):
+        if not (cfg['multi_layer'] and not cfg['cascade'] and cfg['is_ins_norm']):
             raise NotImplementedError('regda_amd builds the st.regda.* model: multi_layer=True, cascade=False, '
-                                      'use_ppm=True, is_ins_norm=True (ASPP/cascade heads: DESIGN.md "next")')
+                                      'is_ins_norm=True, with the PPM heads (use_ppm=True) or the ASPP heads '
+                                      '(use_ppm=False); the cascade / single-head variants are not built')
+        # 'ppm': PPMBilinear heads (Encoder.py:10-64, what every st.regda entry point uses);
+        # 'aspp': Classifier_Module heads, dilations = paddings = 6/12/18/24 (Encoder.py:68-84,111-114)
+        self.head_kind = 'ppm' if cfg['use_ppm'] else 'aspp'
         if rt not in LAYERS or cfg['backbone'].get('output_stride', 16) != 16:
             raise NotImplementedError('resnet50/resnet101 at output_stride 16 only')
         if not torch.cuda.is_available():
@@ -205,10 +211,15 @@ class Deeplabv2(nn.Module):
             if ds:
                 conv(p + '.downsample.0', planes * 4, inpl, 1); bn(p + '.downsample.1', planes * 4)
         for head in ('layer5', 'layer6'):
+            if self.head_kind == 'aspp':
+                for i in range(len(ASPP_DILATIONS)):
+                    conv(f'{head}.conv2d_list.{i}', self.num_classes, 2048, 3, bias=True)
+                continue
             for i in range(4):
                 conv(f'{head}.ppm.{i}.1', 512, 2048, 1); bn(f'{head}.ppm.{i}.2', 512)
             conv(f'{head}.conv_last.0', 512, 2048 + 4 * 512, 3); bn(f'{head}.conv_last.1', 512)
             conv(f'{head}.conv_last.4', self.num_classes, 512, 1, bias=True)
+        self._head_first = 'ppm.0.1' if self.head_kind == 'ppm' else 'conv2d_list.0'
 
         n_param = sum(_pad64(math.prod(s)) for _, k, s in entries if k in ('convw', 'vec'))
         n_buf = sum(_pad64(math.prod(s)) for _, k, s in entries if k == 'buf')
@@ -277,7 +288,11 @@ class Deeplabv2(nn.Module):
             if ds:
                 self.convs[p + '.downsample.0'].stride = stride
         for head in ('layer5', 'layer6'):
-            self.convs[f'{head}.conv_last.0'].pad = 1
+            if self.head_kind == 'aspp':
+                for i, d in enumerate(ASPP_DILATIONS):
+                    self.convs[f'{head}.conv2d_list.{i}'].pad = self.convs[f'{head}.conv2d_list.{i}'].dil = d
+            else:
+                self.convs[f'{head}.conv_last.0'].pad = 1
         # transposed bf16 weights for the data-gradient pass (every conv but the stem and the classifiers)
         self.flat_wt = torch.zeros(wt_total, dtype=BF, device=dev)
         o = 0
@@ -303,6 +318,10 @@ class Deeplabv2(nn.Module):
         #   wzt[i] [512][1][9*512]          its transpose, for the gradient w.r.t. q_i
         #   gfeat / gz[i]                   fp32 landing buffers of the two kinds of weight gradient
         self.head_w = {}
+        self._hw_ready = None
+        if self.head_kind == 'aspp':
+            self._build_aspp_weights()
+            return
         for head in ('layer5', 'layer6'):
             self.head_w[head] = {
                 'wfeat': torch.zeros(512, 9, 2048, dtype=BF, device=dev),
@@ -334,6 +353,25 @@ class Deeplabv2(nn.Module):
         self._hw_fwd_table, self._hw_fwd_blocks = table(('fwd',))
         self._hw_bwd_table, self._hw_bwd_blocks = table(('bwd',))
 
+    def _build_aspp_weights(self):
+        """ASPP heads as one 1x1 convolution (csrc/aspp_kernels.hip): `aspp_wz` [ZC][1][2048] bf16 is the eight
+        master weights [C][3][3][2048] back to back (one row per (head, dilation, class, tap), zero rows up to a
+        multiple of 64), `aspp_wzt` its transpose for the gradient w.r.t. the features, `aspp_gz` the fp32
+        landing buffer of the weight gradient."""
+        dev, C = self.device, self.num_classes
+        self.aspp_rows = 2 * len(ASPP_DILATIONS) * C * 9
+        self.aspp_zc = (self.aspp_rows + 63) // 64 * 64
+        self.aspp_wz = torch.zeros(self.aspp_zc, 1, 2048, dtype=BF, device=dev)
+        self.aspp_wzt = torch.zeros(2048, 1, self.aspp_zc, dtype=BF, device=dev)
+        self.aspp_gz = torch.zeros(self.aspp_zc, 1, 2048, device=dev)
+        self.aspp_convs = [self.convs[f'{head}.conv2d_list.{i}'] for head in ('layer5', 'layer6')
+                           for i in range(len(ASPP_DILATIONS))]
+        rows, blk = [], 0
+        for j, c in enumerate(self.aspp_convs):          # mode 2: fp32 master slice -> bf16, same layout
+            rows.append([c.w.data_ptr(), self.aspp_wz.data_ptr() + 2 * j * C * 9 * 2048, C, 9, 2048, blk, 2048, 2])
+            blk += (2048 // 32) * ((C + 31) // 32) * 9
+        self._hw_fwd_table, self._hw_fwd_blocks = torch.tensor(rows, dtype=torch.int64, device=dev), blk
+
     def _init_weights(self):
         """kaiming_normal_(fan_out, relu) convs, BN weight 1 / bias 0 (_resnets.py:164-169); heads keep the
         torch defaults of nn.Conv2d (kaiming_uniform(a=sqrt(5)))."""
@@ -343,6 +381,8 @@ class Deeplabv2(nn.Module):
                     co, ci, k, _ = par.shape
                     if name.startswith('encoder.'):
                         par.copy_(torch.randn(co, ci, k, k, device=self.device) * math.sqrt(2.0 / (co * k * k)))
+                    elif '.conv2d_list.' in name:                       # Encoder.py:77-78: normal_(0, 0.01)
+                        par.copy_(torch.randn(co, ci, k, k, device=self.device) * 0.01)
                     else:
                         bound = 1.0 / math.sqrt(ci * k * k)
                         par.copy_((torch.rand(co, ci, k, k, device=self.device) * 2 - 1) * bound)
@@ -352,7 +392,7 @@ class Deeplabv2(nn.Module):
                     par.zero_()
             for c in self.convs.values():
                 if c.bias is not None:
-                    bound = 1.0 / math.sqrt(c.ci)
+                    bound = 1.0 / math.sqrt(c.ci * c.k * c.k)
                     c.bias.copy_((torch.rand(c.co, device=self.device) * 2 - 1) * bound)
             for b in self.bns.values():
                 b.rv.fill_(1.0)
@@ -385,7 +425,10 @@ class Deeplabv2(nn.Module):
         """Re-slice the head convs' weights from the fp32 master (same rounding as the bf16 mirror)."""
         ops.weight_transpose_batched(self._hw_fwd_table, self._hw_fwd_table.shape[0], self._hw_fwd_blocks)
         if with_transposes:
-            ops.weight_transpose_batched(self._hw_bwd_table, self._hw_bwd_table.shape[0], self._hw_bwd_blocks)
+            if self.head_kind == 'aspp':
+                self.aspp_wzt.view(2048, self.aspp_zc).copy_(self.aspp_wz.view(self.aspp_zc, 2048).t())
+            else:
+                ops.weight_transpose_batched(self._hw_bwd_table, self._hw_bwd_table.shape[0], self._hw_bwd_blocks)
 
     def _maybe_sync(self):
         if self.flat_p._version != self._synced_version:
@@ -408,7 +451,7 @@ class Deeplabv2(nn.Module):
         """Element offsets (into flat_p / flat_g) where a residual block / head starts: legal bucket cuts."""
         base = self.flat_p.data_ptr()
         offs = [(self.convs[p + '.conv1'].w.data_ptr() - base) // 4 for p, *_ in self.blocks]
-        offs += [(self.convs[f'{h}.ppm.0.1'].w.data_ptr() - base) // 4 for h in ('layer5', 'layer6')]
+        offs += [(self.convs[f'{h}.{self._head_first}'].w.data_ptr() - base) // 4 for h in ('layer5', 'layer6')]
         return sorted(offs)
 
     def _offset_of(self, conv_name):
@@ -586,6 +629,35 @@ class Deeplabv2(nn.Module):
             self._flush_wgrads(T)
         return dfeat, dqs
 
+    def _aspp_fwd(self, T, xn, N, h, w):
+        """Both Classifier_Module heads (Encoder.py:80-84): one 1x1 convolution for all 2 x 4 x 9 taps, then the
+        dilated gather (csrc/aspp_kernels.hip)."""
+        dev, C = self.device, self.num_classes
+        z = torch.empty(N * h * w, self.aspp_zc, dtype=BF, device=dev)
+        ops.conv2d(xn, self.aspp_wz, z, N, h, w, h, w, 1, 1, 1, 0, 1, 0)
+        x1 = torch.empty(N, C, h, w, device=dev)
+        x2 = torch.empty(N, C, h, w, device=dev)
+        ops.aspp_gather(z, [c.bias for c in self.aspp_convs], x1, x2, N, h, w, C, ASPP_DILATIONS)
+        if T is not None:
+            T['aspp'] = (xn, (N, h, w))
+        return x1, x2
+
+    def _aspp_bwd(self, T, g1, g2):
+        """-> d(loss)/d(xn) bf16 [M, 2048]; weight and bias gradients are accumulated into the master gradients."""
+        dev, C = self.device, self.num_classes
+        xn, (N, h, w) = T['aspp']
+        dz = torch.empty(N * h * w, self.aspp_zc, dtype=BF, device=dev)
+        ops.aspp_scatter(g1.contiguous().float(), g2.contiguous().float(), dz, [c.gbias for c in self.aspp_convs],
+                         N, h, w, C, ASPP_DILATIONS)
+        dxn = torch.empty(N * h * w, 2048, dtype=BF, device=dev)
+        ops.conv2d(dz, self.aspp_wzt, dxn, N, h, w, h, w, 1, 1, 1, 0, 1, 0)
+        self.aspp_gz.zero_()
+        ops.conv2d_wgrad(xn, dz, self.aspp_gz, N, h, w, h, w, 1, 1, 1, 0, 1)
+        n = C * 9 * 2048
+        for j, c in enumerate(self.aspp_convs):      # the rows of one conv are its master layout [C][3][3][2048]
+            c.g.view(-1).add_(self.aspp_gz.view(-1)[j * n:(j + 1) * n])
+        return dxn
+
     def _flush_wgrads(self, T):
         """Launch the queued weight gradients (grouped by kernel) -- on the second HIP stream when there is one,
         next to the BN-backward / data-gradient chain of the layers below, which is the critical path -- and
@@ -726,6 +798,9 @@ class Deeplabv2(nn.Module):
             self._hw_ready = None
         if T is not None:
             T['inorm'] = (y, imi, (N, h, w))
+        if self.head_kind == 'aspp':
+            x1, x2 = self._aspp_fwd(T, xn, N, h, w)
+            return x1, x2, feat
         mats = self._mats(h, w)
         if T is not None:
             if self._drop_override is not None:
@@ -773,14 +848,17 @@ class Deeplabv2(nn.Module):
         C, B = self.convs, self.bns
         y4, imi, (N, h, w) = T['inorm']
         HW, M = h * w, N * h * w
-        mats = self._mats(h, w)
+        mats = self._mats(h, w) if self.head_kind == 'ppm' else None
         dfeat = None
         dpools = [None] * len(POOL_SCALES)
         dbg = getattr(self, '_debug_grads', None)
 
         def nchw(t, hh, ww):
             return t.float().reshape(N, hh, ww, -1).permute(0, 3, 1, 2)
-        for hi, (head, gl) in enumerate((('layer5', g1), ('layer6', g2))):
+        if self.head_kind == 'aspp':
+            g = torch.empty(M, 2048, dtype=BF, device=dev)
+            ops.instnorm_bwd(self._aspp_bwd(T, g1, g2), gfeat, None, y4, imi, g, N, HW, 2048)
+        for hi, (head, gl) in enumerate((('layer5', g1), ('layer6', g2)) if self.head_kind == 'ppm' else ()):
             hid, _ = T[f'{head}.cls']
             cl = C[f'{head}.conv_last.4']
             dh = torch.empty(M, 512, dtype=BF, device=dev)
@@ -794,12 +872,13 @@ class Deeplabv2(nn.Module):
                 # ... and so are the gradients of the shared pooled maps
                 dpools[i], _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
                                              dqs[i], True, dx_res=dpools[i])
-        gpool = torch.empty(M, 2048, dtype=BF, device=dev)
-        ops.spatial_mix_multi(dpools, [mats[s][1] for s in POOL_SCALES], gpool, N, HW, 2048)
-        g = torch.empty(M, 2048, dtype=BF, device=dev)
-        ops.instnorm_bwd(dfeat, gfeat, gpool, y4, imi, g, N, HW, 2048)
-        del dfeat, gpool
-        self._progress(T, self._offset_of('layer5.ppm.0.1'))
+        if self.head_kind == 'ppm':
+            gpool = torch.empty(M, 2048, dtype=BF, device=dev)
+            ops.spatial_mix_multi(dpools, [mats[s][1] for s in POOL_SCALES], gpool, N, HW, 2048)
+            g = torch.empty(M, 2048, dtype=BF, device=dev)
+            ops.instnorm_bwd(dfeat, gfeat, gpool, y4, imi, g, N, HW, 2048)
+            del dfeat, gpool
+        self._progress(T, self._offset_of('layer5.' + self._head_first))
         hh, ww = h, w
         order = [b[0] for b in self.blocks]
         for bi in range(len(self.blocks) - 1, -1, -1):

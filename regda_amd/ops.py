@@ -457,3 +457,29 @@ def pcl_loss(feat, labels, protos, temperature=8.0, ignore_label=-1, weight=1.0,
            _ld(dfeat) if dfeat is not None else 0, int(bool(accumulate)), b, K, C, h, w, ignore_label, float(temperature),
            float(weight), ws.data_ptr(), ws.numel(), _stream())
     return loss
+
+
+# ---------------------------------------------------------------- ASPP head (Classifier_Module)
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def aspp_gather(z, biases, out1, out2, N, h, w, C, dils):
+    """z bf16 [N*h*w, >= 72*C]; biases: eight f32 [C] tensors ([head][dilation]); out1/out2 f32 (N,C,h,w)."""
+    import ctypes
+    assert len(biases) == 8 and len(dils) == 4
+    P = _ptr_array(biases)
+    D = (ctypes.c_int * 4)(*[int(d) for d in dils])
+    lib().call('rgda_aspp_gather', z.data_ptr(), _ld(z), ctypes.cast(P, ctypes.c_void_p), out1.data_ptr(),
+               out2.data_ptr(), N, h, w, C, ctypes.cast(D, ctypes.c_void_p), _stream())
+
+
+def aspp_scatter(g1, g2, dz, dbiases, N, h, w, C, dils):
+    """g1/g2 f32 (N,C,h,w) contiguous -> dz bf16 [N*h*w, zc]; dbiases: eight f32 [C] tensors, accumulated."""
+    import ctypes
+    assert len(dbiases) == 8 and len(dils) == 4 and g1.is_contiguous() and g2.is_contiguous()
+    P = _ptr_array(dbiases)
+    D = (ctypes.c_int * 4)(*[int(d) for d in dils])
+    lib().call('rgda_aspp_scatter', g1.data_ptr(), g2.data_ptr(), dz.data_ptr(), _ld(dz), dz.shape[1],
+               ctypes.cast(P, ctypes.c_void_p), N, h, w, C, ctypes.cast(D, ctypes.c_void_p), _stream())

@@ -1,0 +1,32 @@
+"""Per-workgroup phase timestamps of the HBM-bound small-K convolutions (tuning build only: make TUNING=1)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from regda_amd import ops
+BF = torch.bfloat16
+shapes = [(16, 128, 128, 64, 256), (16, 128, 128, 256, 64), (16, 64, 64, 128, 512), (16, 64, 64, 512, 128), (16, 64, 64, 1024, 256)]
+for (N, H, W, Ci, Co) in shapes:
+    M = N * H * W
+    x = torch.randn(M, Ci, device='cuda').to(BF)
+    w = (torch.randn(Co, 1, Ci, device='cuda') * 0.05).to(BF)
+    y = torch.empty(M, Co, dtype=BF, device='cuda')
+    def go(): ops.conv2d(x, w, y, N, H, W, H, W, 1, 1, 1, 0, 1, 0)
+    for _ in range(3): go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): go()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    dbg = torch.zeros(8192 * 8, dtype=torch.int64, device='cuda')
+    os.environ['RGDA_CONV_DBG'] = str(dbg.data_ptr())
+    go(); torch.cuda.synchronize()
+    os.environ.pop('RGDA_CONV_DBG')
+    allv = dbg.view(-1, 4).cpu()
+    nw = int((allv[:, 2] > 0).sum())
+    t = allv[:nw]
+    d1, d2, d3 = (t[:, 1] - t[:, 0]).float(), (t[:, 2] - t[:, 1]).float(), (t[:, 3] - t[:, 2]).float()
+    span = (t[:, 3].max() - t[:, 0].min()).item()
+    byt = (M * Ci + M * Co) * 2
+    print((M, Ci, Co), 'wgs', nw, '%.1f us  %.2f TB/s | first-tile wait %.0f  kloop %.0f  epilogue %.0f  total/WG %.0f | span %d ticks; WG-lifetime sum / span = %.2f concurrent WGs' % (
+        us, byt / us / 1e6, d1.median(), d2.median(), d3.median(), (t[:, 3] - t[:, 0]).float().median(), span, (t[:, 3] - t[:, 0]).float().sum().item() / span))

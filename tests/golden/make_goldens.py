@@ -411,7 +411,47 @@ def gold_pcl():
     save('pcl.npz', **out)
 
 
+def gold_aspp():
+    """ASPP heads (use_ppm=False): (1) the reference's Classifier_Module alone (Encoder.py:68-84) on a small map,
+    forward and all gradients; (2) the reference Deeplabv2(use_ppm=False) ResNet-101 at 2x3x64x64 with
+    oracle.model.init_state_dict(seed=2, head='aspp'): train-mode outputs, a loss, selected gradients, eval probs."""
+    from regda.models.Encoder import Classifier_Module
+    torch.manual_seed(5)
+    cm = Classifier_Module(64, [6, 12, 18, 24], [6, 12, 18, 24], 6)
+    x = torch.randn(2, 64, 20, 28, requires_grad=True)
+    gy = torch.randn(2, 6, 20, 28)
+    y = cm(x)
+    (y * gy).sum().backward()
+    out = dict(cm_x=x.detach().numpy(), cm_gy=gy.numpy(), cm_y=y.detach().numpy(), cm_gx=x.grad.numpy())
+    for i, m in enumerate(cm.conv2d_list):
+        out[f'cm_w{i}'], out[f'cm_b{i}'] = m.weight.detach().numpy(), m.bias.detach().numpy()
+        out[f'cm_gw{i}'], out[f'cm_gb{i}'] = m.weight.grad.numpy(), m.bias.grad.numpy()
+    m = Deeplabv2(dict(backbone=dict(resnet_type='resnet101', output_stride=16, pretrained=False),
+                       multi_layer=True, cascade=False, use_ppm=False, inchannels=2048, num_classes=6,
+                       is_ins_norm=True))
+    sd = omodel.init_state_dict('resnet101', 6, seed=2, head='aspp')
+    m.load_state_dict(sd, strict=True)
+    out['keys'] = np.array(list(m.state_dict().keys()))
+    m.train()
+    g = torch.Generator().manual_seed(77)
+    xs = torch.randn(2, 3, 64, 64, generator=g)
+    lab = torch.from_numpy(np.kron(np.random.default_rng(7).integers(-1, 6, size=(2, 4, 4)), np.ones((16, 16), np.int64)))
+    x1, x2, feat = m(xs)
+    loss = loss_calc([x1, x2], lab, loss_fn=CrossEntropy(ignore_label=-1, class_balancer=None), multi=True)
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k in ('layer5.conv2d_list.0.bias', 'layer6.conv2d_list.3.bias', 'encoder.resnet.bn1.weight'):
+        out['grad:' + k] = named[k].grad.numpy()
+    out['grad:layer5.conv2d_list.1.weight[:, :32]'] = named['layer5.conv2d_list.1.weight'].grad[:, :32].numpy()
+    m.eval()
+    with torch.no_grad():
+        probs = m(xs)
+    out.update(xs=xs.numpy(), lab=lab.numpy().astype(np.int8), x1=x1.detach().numpy(), x2=x2.detach().numpy(),
+               feat=feat.detach().numpy()[:, :32], loss=loss.detach().numpy(), probs=probs.numpy())
+    save('aspp.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta', 'pcl', 'align']
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta', 'pcl', 'align', 'aspp']
     for w in which:
         globals()['gold_' + w]()

@@ -111,3 +111,26 @@ extern "C" int probe_run_bw(int mode, int depth, int blocks, int threads, const 
     else probe_bw<1, 1><<<blocks, threads, 0, st>>>((const float4*)src, tile_bytes, iters, (float*)sink);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// store-bandwidth probe: every thread writes (mode 0: plain, 1: nontemporal) or copies (mode 2: plain, 3: nontemporal
+// store) 16-byte vectors, grid-stride.
+typedef float pf4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ void probe_store(pf4* __restrict__ dst, const pf4* __restrict__ src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    pf4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (; i < n; i += stride) {
+        if (MODE >= 2) v = src[i];
+        if (MODE & 1) __builtin_nontemporal_store(v, dst + i);
+        else dst[i] = v;
+    }
+}
+extern "C" int probe_run_store(int mode, int blocks, int threads, void* dst, const void* src, size_t nvec, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) probe_store<0><<<blocks, threads, 0, st>>>((pf4*)dst, (const pf4*)src, nvec);
+    else if (mode == 1) probe_store<1><<<blocks, threads, 0, st>>>((pf4*)dst, (const pf4*)src, nvec);
+    else if (mode == 2) probe_store<2><<<blocks, threads, 0, st>>>((pf4*)dst, (const pf4*)src, nvec);
+    else probe_store<3><<<blocks, threads, 0, st>>>((pf4*)dst, (const pf4*)src, nvec);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

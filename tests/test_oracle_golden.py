@@ -230,3 +230,47 @@ def test_full_stage2_step_small(small_case, gold):
               'encoder.resnet.layer4.2.bn3.bias', 'layer6.ppm.3.2.bias']:
         ref, got = a['grad:' + k], r['grads'][k].numpy()
         assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, k
+
+
+# ---------------------------------------------------------------- ASPP heads
+def test_aspp_head_matches_reference_module(gold):
+    """oracle.model.aspp_head vs the reference's Classifier_Module (Encoder.py:68-84): output and every gradient."""
+    g = gold('aspp.npz')
+    x = torch.from_numpy(g['cm_x']).requires_grad_(True)
+    ws = [torch.from_numpy(g[f'cm_w{i}']).requires_grad_(True) for i in range(4)]
+    bs = [torch.from_numpy(g[f'cm_b{i}']).requires_grad_(True) for i in range(4)]
+    y = model.aspp_head(x, ws, bs)
+    np.testing.assert_allclose(y.detach().numpy(), g['cm_y'], rtol=1e-5, atol=1e-6)
+    (y * torch.from_numpy(g['cm_gy'])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g['cm_gx'], rtol=1e-4, atol=1e-6)
+    for i in range(4):
+        np.testing.assert_allclose(ws[i].grad.numpy(), g[f'cm_gw{i}'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(bs[i].grad.numpy(), g[f'cm_gb{i}'], rtol=1e-4, atol=1e-5)
+
+
+def test_aspp_model_matches_reference(gold):
+    """The use_ppm=False network: state_dict layout, train outputs, loss, gradients and eval probabilities against
+    the reference Deeplabv2 (tests/golden/make_goldens.py gold_aspp)."""
+    g = gold('aspp.npz')
+    sd = model.init_state_dict('resnet101', 6, seed=2, head='aspp')
+    assert list(g['keys']) == list(sd.keys())
+    names = model.param_names(sd)
+    sdr = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    ns = {}
+    xs, lab = torch.from_numpy(g['xs']), torch.from_numpy(g['lab']).long()
+    x1, x2, feat = model.forward(sdr, xs, True, None, 'resnet101', ns)
+    np.testing.assert_allclose(x1.detach().numpy(), g['x1'], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(x2.detach().numpy(), g['x2'], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(feat.detach().numpy()[:, :32], g['feat'], rtol=1e-3, atol=2e-4)
+    loss = labelpath.loss_calc([x1, x2], lab, -1)
+    assert loss.item() == pytest.approx(float(g['loss']), rel=1e-4)
+    grads = dict(zip(names, torch.autograd.grad(loss, [sdr[k] for k in names])))
+    for k in ('layer5.conv2d_list.0.bias', 'layer6.conv2d_list.3.bias', 'encoder.resnet.bn1.weight'):
+        ref = g['grad:' + k]
+        assert np.abs(grads[k].numpy() - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7, k
+    ref = g['grad:layer5.conv2d_list.1.weight[:, :32]']
+    assert np.abs(grads['layer5.conv2d_list.1.weight'][:, :32].numpy() - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-7
+    sd_eval = {k: ns.get(k, v).detach() for k, v in sd.items()}
+    with torch.no_grad():
+        probs = model.forward(sd_eval, xs, False, None, 'resnet101')
+    np.testing.assert_allclose(probs.numpy(), g['probs'], rtol=1e-3, atol=1e-4)

@@ -349,6 +349,21 @@ int rgda_pcl_loss(const float* feat, const int64_t* labels, const float* protos,
                   int lddf, int accumulate, int b, int K, int C, int h, int w, int ignore_label,
                   float temperature, float weight, void* ws, size_t ws_bytes, rgda_stream_t stream);
 
+/* Factored form of the PPM heads' tap-shifted bilinear maps (regda/models/Encoder.py:30-51: Upsample(bilinear,
+ * align_corners=False) of the s x s branches into the 3x3 / pad 1 conv_last): the map V[(y,x)][(jy,jx),(ky,kx)] =
+ * Uy[y+ky-1][jy] * Ux[x+kx-1][jx] is separable, so V and V^T are applied as two short maps (csrc/mix_kernels.hip).
+ *   rgda_group_mix : out[g][i][c] = sum_j W[i][j] * in[g][j][c] for G groups of J consecutive rows, W f32 [I][J]
+ *                    (the x direction: one group per image row);
+ *   rgda_sparse_mix: out[n][i][c] = sum_k vals[k] * ins[cols[k] >> 24][n][cols[k] & 0xffffff][c] over CSR row i
+ *                    (rowptr int32 [I+1], cols int32, vals f32: DEVICE arrays; ins/ldins/Js: HOST arrays, nsrc <= 4)
+ *                    (the y direction, and the gather from the four branch tensors).
+ * in/out bf16, or f32 where in_f32 / out_f32 != 0; C % 8 == 0; deterministic. */
+int rgda_group_mix(const void* in, int ldin, int in_f32, const float* W, void* out, int ldout, int out_f32,
+                   int G, int I, int J, int C, rgda_stream_t stream);
+int rgda_sparse_mix(int nsrc, const void* const* ins, const int* ldins, const int* Js, int in_f32,
+                    const int* rowptr, const int* cols, const float* vals, void* out, int ldout, int out_f32,
+                    int N, int I, int C, rgda_stream_t stream);
+
 /* ------------------------------------------------------------- ASPP head */
 
 /* Classifier_Module (regda/models/Encoder.py:68-84): out = sum_d Conv2d(K -> C, 3x3, padding = dilation = dil[d],

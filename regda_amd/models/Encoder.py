@@ -94,6 +94,67 @@ def ppm_tap_matrix(h, w, s):
     return V.reshape(h * w, s * s * 9).contiguous()
 
 
+def upsample_taps_1d(n_in, n_out):
+    """One axis of upsample_matrix (bilinear, align_corners=False): [n_out, n_in], same float32 arithmetic."""
+    import numpy as np
+    U = torch.zeros(n_out, n_in)
+    sc = np.float32(n_in) / np.float32(n_out)
+    for d in range(n_out):
+        src = max(np.float32(sc) * (np.float32(d) + np.float32(0.5)) - np.float32(0.5), np.float32(0))
+        i0 = int(src)
+        i1 = i0 + (1 if i0 < n_in - 1 else 0)
+        l1 = np.float32(src) - np.float32(i0)
+        U[d, i0] += float(np.float32(1) - l1)
+        U[d, i1] += float(l1)
+    return U
+
+
+def _csr(mats):
+    """Dense [I, J_q] matrices of up to four sources -> (rowptr int32 [I+1], cols int32 = (q << 24) | j, vals f32),
+    the operand format of rgda_sparse_mix."""
+    I = mats[0].shape[0]
+    rows, cols, vals = [], [], []
+    for q, m in enumerate(mats):
+        assert m.shape[0] == I and m.shape[1] < (1 << 24)
+        nz = m.nonzero()
+        rows.append(nz[:, 0])
+        cols.append(nz[:, 1] + (q << 24))
+        vals.append(m[nz[:, 0], nz[:, 1]])
+    rows, cols, vals = torch.cat(rows), torch.cat(cols), torch.cat(vals)
+    order = torch.argsort(rows * (1 << 32) + cols)
+    rowptr = torch.zeros(I + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=I), 0)
+    return rowptr.to(torch.int32), cols[order].to(torch.int32), vals[order].float().contiguous()
+
+
+def ppm_factored_maps(h, w):
+    """ppm_tap_matrix is separable: V_s[(y,x)][(jy,jx),(ky,kx)] = Uy_s[y+ky-1][jy] * Ux_s[x+kx-1][jx] (0 where the
+    shifted row / column is padding).  With r = (s, jx, kx) indexing R = 3 * sum(s) intermediate rows per image row:
+        Wx  [R, w]              Wx[r][x] = Ux_s[x+kx-1][jx]                     (the x direction, rgda_group_mix)
+        Ay_s [h*R, 9*s*s]       Ay_s[y*R + r][(jy*s+jx)*9 + ky*3+kx] = Uy_s[y+ky-1][jy]   (the y direction, CSR)
+    so that  V_s = blockdiag_y(Wx^T) @ Ay_s.  Returns dense Wx and the dense Ay_s list (callers build the CSR forms)."""
+    R = 3 * sum(POOL_SCALES)
+    Wx = torch.zeros(R, w)
+    Ay = []
+    off = 0
+    for s in POOL_SCALES:
+        Uy, Ux = upsample_taps_1d(s, h), upsample_taps_1d(s, w)
+        A = torch.zeros(h * R, 9 * s * s)
+        for jx in range(s):
+            for kx in range(3):
+                r = off + jx * 3 + kx
+                x0, x1 = max(0, 1 - kx), min(w, w + 1 - kx)
+                Wx[r, x0:x1] = Ux[x0 + kx - 1:x1 + kx - 1, jx]
+                for jy in range(s):
+                    for ky in range(3):
+                        y0, y1 = max(0, 1 - ky), min(h, h + 1 - ky)
+                        ys = torch.arange(y0, y1)
+                        A[ys * R + r, (jy * s + jx) * 9 + ky * 3 + kx] = Uy[ys + ky - 1, jy]
+        Ay.append(A)
+        off += 3 * s
+    return Wx, Ay
+
+
 # ----------------------------------------------------------------------------- parameter specs
 def _block_specs(resnet_type):
     """[(prefix, inplanes, planes, stride, dilation, has_downsample)] at output stride 16
@@ -181,6 +242,9 @@ class Deeplabv2(nn.Module):
         # many channels (0 / False = never, True = always).  Pays only where y is big: the 1024-channel bn3 outputs,
         # whose BN-backward operands make the fused data-gradient epilogue HBM-bound (-0.1 ms/step)
         self.relu_sign_mask = 1024
+        # PPM heads: apply the tap-shifted bilinear maps in their separable form (csrc/mix_kernels.hip); False = the
+        # one-pass sparse maps (rgda_spatial_mix / rgda_spatial_mix_multi), kept as the cross-check
+        self.factored_ppm = True
         self._mat_cache = {}
         self._synced_version = -1
         self.sync_weights()
@@ -494,6 +558,19 @@ class Deeplabv2(nn.Module):
             self._mat_cache[key] = d
         return self._mat_cache[key]
 
+    def _ppm_maps(self, h, w):
+        """Device operands of the factored tap-shifted bilinear maps (ppm_factored_maps)."""
+        key = ('ppm', h, w)
+        if key not in self._mat_cache:
+            dev = self.device
+            Wx, Ay = ppm_factored_maps(h, w)
+            self._mat_cache[key] = {
+                'R': Wx.shape[0], 'Wx': Wx.to(dev).contiguous(), 'Wxt': Wx.t().contiguous().to(dev),
+                'fwd': tuple(t.to(dev) for t in _csr(Ay)),                       # B rows <- the four Z_s
+                'bwd': [tuple(t.to(dev) for t in _csr([A.t().contiguous()])) for A in Ay],   # dZ_s rows <- A
+            }
+        return self._mat_cache[key]
+
     def _conv_stats(self, x, w, c, stats, G, N, H, W, Ho, Wo, k, stride, pad, dil, res=None):
         """Forward conv (+ `res` added in the epilogue, before the statistics) with BatchNorm statistics per row
         group; falls back to one launch per group when the groups are not a multiple of the pixel tile (tiny PPM
@@ -567,7 +644,13 @@ class Deeplabv2(nn.Module):
             ops.conv2d(qs[i], hw['wz'][i], z, N, s, s, s, s, 1, 1, 1, 0, 1)
             zs.append(z.view(N * s * s * 9, 512))
         ppm = torch.empty(M, 512, dtype=BF, device=dev)
-        ops.spatial_mix_multi(zs, [mats[s][4] for s in POOL_SCALES], ppm, N, HW, 512)
+        if self.factored_ppm:       # V @ Z as the y map (gather from the four Z_s) then the x map (LDS-staged rows)
+            fm = self._ppm_maps(h, w)
+            rows = torch.empty(N * h * fm['R'], 512, device=dev)
+            ops.sparse_mix(zs, fm['fwd'], rows, N, h * fm['R'], 512)
+            ops.group_mix(rows, fm['Wxt'], ppm, N * h, w, fm['R'], 512)
+        else:
+            ops.spatial_mix_multi(zs, [mats[s][4] for s in POOL_SCALES], ppm, N, HW, 512)
         train = T is not None
         G = T['groups'] if train else 1
         c = torch.empty(M, 512, dtype=BF, device=dev)
@@ -612,9 +695,16 @@ class Deeplabv2(nn.Module):
         dfeat = torch.empty(M, 2048, dtype=BF, device=dev)
         ops.conv2d(dc, conv.wtb[:2048], dfeat, N, h, w, h, w, 3, 3, 1, 1, 1, 1, dfeat_prev, None)
         dqs = []
+        if self.factored_ppm:       # V^T @ dc: the x map once for all scales, then one y map per scale
+            fm = self._ppm_maps(h, w)
+            rows = torch.empty(N * h * fm['R'], 512, device=dev)
+            ops.group_mix(dc, fm['Wx'], rows, N * h, fm['R'], w, 512)
         for i, s in enumerate(POOL_SCALES):
             dz = torch.empty(N * s * s * 9, 512, dtype=BF, device=dev)
-            ops.spatial_mix(dc, mats[s][5], dz, N, 9 * s * s, HW, 512)
+            if self.factored_ppm:
+                ops.sparse_mix([rows], fm['bwd'][i], dz, N, 9 * s * s, 512)
+            else:
+                ops.spatial_mix(dc, mats[s][5], dz, N, 9 * s * s, HW, 512)
             dzr = dz.view(N * s * s, 9 * 512)
             dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
             ops.conv2d(dzr, hw['wzt'][i], dq, N, s, s, s, s, 1, 1, 1, 0, 1)

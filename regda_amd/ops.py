@@ -328,6 +328,29 @@ def spatial_mix(inp, Mx, out, N, I, J, C, accumulate=False):
                int(accumulate), int(out.dtype == torch.float32), _stream())
 
 
+def group_mix(inp, W, out, G, I, J, C):
+    """out[g][i][:] = sum_j W[i][j] * inp[g][j][:] for G groups of J consecutive rows (bf16 or f32 tensors)."""
+    assert W.shape == (I, J) and W.is_contiguous() and W.dtype == torch.float32
+    assert inp.shape[0] == G * J and out.shape[0] == G * I
+    lib().call('rgda_group_mix', inp.data_ptr(), _ld(inp), int(inp.dtype == torch.float32), W.data_ptr(),
+               out.data_ptr(), _ld(out), int(out.dtype == torch.float32), G, I, J, C, _stream())
+
+
+def sparse_mix(ins, csr, out, N, I, C):
+    """out[n][i][:] = sum_k vals[k] * ins[cols[k] >> 24][n][cols[k] & 0xffffff][:] over CSR row i.
+    csr = (rowptr int32 [I+1], cols int32, vals f32) on the device; ins: <= 4 tensors of one dtype."""
+    import ctypes
+    rowptr, cols, vals = csr
+    assert rowptr.dtype == torch.int32 and cols.dtype == torch.int32 and vals.dtype == torch.float32
+    assert rowptr.numel() == I + 1 and out.shape[0] == N * I
+    n = len(ins)
+    P = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ins])
+    L = (ctypes.c_int * n)(*[_ld(t) for t in ins])
+    J = (ctypes.c_int * n)(*[t.shape[0] // N for t in ins])
+    lib().call('rgda_sparse_mix', n, P, L, J, int(ins[0].dtype == torch.float32), rowptr.data_ptr(), cols.data_ptr(),
+               vals.data_ptr(), out.data_ptr(), _ld(out), int(out.dtype == torch.float32), N, I, C, _stream())
+
+
 def classifier_fwd(hidden, w, bias, logits, N, HW, C, ncls):
     lib().call('rgda_classifier_fwd', hidden.data_ptr(), _ld(hidden), w.data_ptr(), bias.data_ptr(), logits.data_ptr(),
                N, HW, C, ncls, _stream())

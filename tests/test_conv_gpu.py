@@ -498,3 +498,90 @@ def test_conv_residual_gated_by_relu_mask(ops):
     assert torch.equal(y1, y2)
     with pytest.raises(ValueError):
         ops.conv2d(x, w, y1, N, H, W, H, W, 1, 1, 1, 0, 1, 0, None, None, res_mask=mask)
+
+
+# ---------------------------------------------------------------- factored spatial maps (csrc/mix_kernels.hip)
+@pytest.mark.parametrize('in_f32,out_f32', [(False, True), (True, False), (False, False)])
+def test_group_mix_matches_dense(in_f32, out_f32):
+    from regda_amd import ops
+    g = torch.Generator().manual_seed(5)
+    G, I, J, C = 37, 36, 32, 512
+    W = torch.randn(I, J, generator=g)
+    W[torch.rand(I, J, generator=g) < 0.4] = 0
+    x = torch.randn(G * J, C, generator=g)
+    xin = (x if in_f32 else x.to(BF)).cuda()
+    out = torch.empty(G * I, C, dtype=torch.float32 if out_f32 else BF, device='cuda')
+    ops.group_mix(xin, W.cuda(), out, G, I, J, C)
+    ref = torch.einsum('ij,gjc->gic', W, xin.float().cpu().view(G, J, C)).reshape(G * I, C)
+    tol = 1e-5 if out_f32 else 1e-2
+    assert ((out.float().cpu() - ref).norm() / ref.norm()).item() < tol
+    # a narrower channel count and odd I (the last output row has no partner)
+    G, I, J, C = 5, 7, 9, 72
+    W = torch.randn(I, J, generator=g)
+    x = torch.randn(G * J, C, generator=g).to(BF).cuda()
+    out = torch.empty(G * I, C, device='cuda')
+    ops.group_mix(x, W.cuda(), out, G, I, J, C)
+    ref = torch.einsum('ij,gjc->gic', W, x.float().cpu().view(G, J, C)).reshape(G * I, C)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_mix_matches_dense_multi_source():
+    from regda_amd import ops
+    from regda_amd.models.Encoder import _csr
+    g = torch.Generator().manual_seed(6)
+    N, I, C = 3, 50, 512
+    Js = (9, 36, 81, 324)
+    mats = []
+    for J in Js:
+        m = torch.randn(I, J, generator=g)
+        m[torch.rand(I, J, generator=g) < 0.9] = 0
+        mats.append(m)
+    mats[0][7] = 0; mats[1][7] = 0; mats[2][7] = 0; mats[3][7] = 0          # an empty row
+    ins = [torch.randn(N * J, C, generator=g).to(BF) for J in Js]
+    csr = tuple(t.cuda() for t in _csr(mats))
+    out = torch.empty(N * I, C, device='cuda')
+    ops.sparse_mix([t.cuda() for t in ins], csr, out, N, I, C)
+    ref = sum(torch.einsum('ij,njc->nic', m, t.float().view(N, -1, C)) for m, t in zip(mats, ins)).reshape(N * I, C)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+    assert float(out.view(N, I, C)[:, 7].abs().max()) == 0.0
+    # f32 in -> bf16 out, single source
+    a = torch.randn(N * 81, C, generator=g)
+    csr1 = tuple(t.cuda() for t in _csr([mats[2]]))
+    o2 = torch.empty(N * I, C, dtype=BF, device='cuda')
+    ops.sparse_mix([a.cuda()], csr1, o2, N, I, C)
+    ref2 = torch.einsum('ij,njc->nic', mats[2], a.view(N, 81, C)).reshape(N * I, C)
+    assert ((o2.float().cpu() - ref2).norm() / ref2.norm()).item() < 1e-2
+
+
+def test_factored_ppm_maps_equal_the_one_pass_maps_per_op():
+    """Same Z / dc in, both forms of V and V^T (models/Encoder.py:_head_last_fwd/_bwd): they differ only by the bf16
+    rounding of the outputs (fp32 accumulation in a different order)."""
+    from regda_amd import ops
+    from regda_amd.models.Encoder import POOL_SCALES, _csr, ppm_factored_maps, ppm_tap_matrix
+    g = torch.Generator().manual_seed(9)
+    N, h, w, C = 3, 32, 32, 512
+    Wx, Ay = ppm_factored_maps(h, w)
+    R = Wx.shape[0]
+    fwd = tuple(t.cuda() for t in _csr(Ay))
+    zs = [torch.randn(N * s * s * 9, C, generator=g).to(BF).cuda() for s in POOL_SCALES]
+    Vs = [ppm_tap_matrix(h, w, s).cuda().contiguous() for s in POOL_SCALES]
+    one = torch.empty(N * h * w, C, dtype=BF, device='cuda')
+    ops.spatial_mix_multi(zs, Vs, one, N, h * w, C)
+    rows = torch.empty(N * h * R, C, device='cuda')
+    ops.sparse_mix(zs, fwd, rows, N, h * R, C)
+    two = torch.empty(N * h * w, C, dtype=BF, device='cuda')
+    ops.group_mix(rows, Wx.t().contiguous().cuda(), two, N * h, w, R, C)
+    ref = sum(torch.einsum('pj,njc->npc', V.cpu(), z.float().cpu().view(N, -1, C)) for V, z in zip(Vs, zs)).reshape(N * h * w, C)
+    assert ((two.float().cpu() - ref).norm() / ref.norm()).item() < 4e-3
+    assert ((two.float() - one.float()).norm() / one.float().norm()).item() < 5e-3
+    dc = torch.randn(N * h * w, C, generator=g).to(BF).cuda()
+    ops.group_mix(dc, Wx.cuda().contiguous(), rows, N * h, R, w, C)
+    for s, A, V in zip(POOL_SCALES, Ay, Vs):
+        csr = tuple(t.cuda() for t in _csr([A.t().contiguous()]))
+        dz2 = torch.empty(N * 9 * s * s, C, dtype=BF, device='cuda')
+        ops.sparse_mix([rows], csr, dz2, N, 9 * s * s, C)
+        dz1 = torch.empty(N * 9 * s * s, C, dtype=BF, device='cuda')
+        ops.spatial_mix(dc, V.t().contiguous(), dz1, N, 9 * s * s, h * w, C)
+        ref = torch.einsum('pj,npc->njc', V.cpu(), dc.float().cpu().view(N, h * w, C)).reshape(N * 9 * s * s, C)
+        assert ((dz2.float().cpu() - ref).norm() / ref.norm()).item() < 4e-3, s
+        assert ((dz2.float() - dz1.float()).norm() / dz1.float().norm()).item() < 5e-3, s

@@ -54,6 +54,34 @@ def test_spatial_matrices_match_torch():
                                        rtol=1e-5, atol=1e-6)
 
 
+def test_factored_ppm_maps_reproduce_the_head_conv():
+    """conv3x3(pad 1)(bilinear-upsample(q)) == V @ (q W_tap^T) (ppm_tap_matrix) and V == the two-stage separable form
+    (ppm_factored_maps), checked against torch's own conv / interpolate; the CSR operands decode back to the dense maps."""
+    from regda_amd.models.Encoder import POOL_SCALES, _csr, ppm_factored_maps, ppm_tap_matrix
+    g = torch.Generator().manual_seed(1)
+    for (h, w) in [(32, 32), (8, 8), (5, 7)]:
+        Wx, Ay = ppm_factored_maps(h, w)
+        R = Wx.shape[0]
+        assert R == 3 * sum(POOL_SCALES)
+        for s, A in zip(POOL_SCALES, Ay):
+            V = ppm_tap_matrix(h, w, s)
+            Vf = torch.einsum('rx,yrc->yxc', Wx, A.view(h, R, -1)).reshape(h * w, -1)
+            torch.testing.assert_close(Vf, V, rtol=0, atol=2e-7)
+            q = torch.randn(1, 4, s, s, generator=g)
+            wt = torch.randn(3, 4, 3, 3, generator=g)
+            ref = F.conv2d(F.interpolate(q, (h, w), mode='bilinear', align_corners=False), wt, None, 1, 1)
+            Z = torch.einsum('ocyx,cj->jyxo', wt, q.reshape(4, s * s)).reshape(s * s * 9, 3)     # Z[j*9+tap][o]
+            torch.testing.assert_close((V @ Z).t().reshape(1, 3, h, w), ref, rtol=1e-4, atol=1e-5)
+        rowptr, cols, vals = _csr(Ay)
+        dense = [torch.zeros_like(A) for A in Ay]
+        for i in range(h * R):
+            for k in range(int(rowptr[i]), int(rowptr[i + 1])):
+                dense[int(cols[k]) >> 24][i, int(cols[k]) & 0xffffff] = vals[k]
+        for d, A in zip(dense, Ay):
+            assert torch.equal(d, A)
+        assert int((rowptr[1:] - rowptr[:-1]).max()) <= 6
+
+
 def test_synthetic_batch_contract():
     from regda_amd.synthetic import make_batch
     b = make_batch(b=2, size=64, seed=1, device='cpu')

@@ -274,3 +274,28 @@ def test_relu_sign_mask_mode_gives_identical_gradients():
     ga, gb = out[0][2], out[1][2]
     cos = (ga @ gb / (ga.norm() * gb.norm())).item()
     assert cos > 0.99 and abs(gb.norm().item() / ga.norm().item() - 1) < 0.03
+
+
+def test_factored_ppm_maps_match_the_one_pass_maps():
+    """The separable two-stage form of the PPM heads' tap-shifted bilinear maps (csrc/mix_kernels.hip) against the
+    one-pass sparse maps it replaces: same logits and same gradients up to bf16 rounding of the stored tensors
+    (forward BN statistics are accumulated with atomics, so not even two runs of ONE path agree bitwise)."""
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=1)
+    gen = torch.Generator().manual_seed(3)
+    xs = torch.randn(4, 3, 128, 128, generator=gen).cuda()
+    masks = (torch.ones(4, 512), torch.ones(4, 512))
+    outs = []
+    for factored in (True, False):
+        m = build(rt)
+        m.factored_ppm = factored
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        m.set_drop_masks(*masks)
+        x1, x2, feat = m(xs)
+        (x1.square().mean() + x2.square().mean()).backward()
+        outs.append((x1.detach(), x2.detach(), m.flat_g.clone()))
+    (a1, a2, ga), (b1, b2, gb) = outs
+    assert l2(a1, b1) < 2e-2 and l2(a2, b2) < 2e-2
+    cos = (ga @ gb / (ga.norm() * gb.norm())).item()
+    assert cos > 0.99 and ga.norm().item() == pytest.approx(gb.norm().item(), rel=3e-2)       # the mask test's bound

@@ -355,14 +355,16 @@ int rgda_pcl_loss(const float* feat, const int64_t* labels, const float* protos,
  *   rgda_group_mix : out[g][i][c] = sum_j W[i][j] * in[g][j][c] for G groups of J consecutive rows, W f32 [I][J]
  *                    (the x direction: one group per image row);
  *   rgda_sparse_mix: out[n][i][c] = sum_k vals[k] * ins[cols[k] >> 24][n][cols[k] & 0xffffff][c] over CSR row i
- *                    (rowptr int32 [I+1], cols int32, vals f32: DEVICE arrays; ins/ldins/Js: HOST arrays, nsrc <= 4)
- *                    (the y direction, and the gather from the four branch tensors).
+ *                    (rowptr int32 [I+1], cols int32, vals f32: DEVICE arrays; ins/ldins/Js: HOST arrays, nsrc <= 4;
+ *                    the I = sum(out_rows) rows are split over ndst <= 4 image-major output tensors, out_rows[q]
+ *                    rows per image each: outs/ldouts/out_rows HOST arrays)
+ *                    (the y direction: the gather from the four branch tensors / the scatter back to them).
  * in/out bf16, or f32 where in_f32 / out_f32 != 0; C % 8 == 0; deterministic. */
 int rgda_group_mix(const void* in, int ldin, int in_f32, const float* W, void* out, int ldout, int out_f32,
                    int G, int I, int J, int C, rgda_stream_t stream);
 int rgda_sparse_mix(int nsrc, const void* const* ins, const int* ldins, const int* Js, int in_f32,
-                    const int* rowptr, const int* cols, const float* vals, void* out, int ldout, int out_f32,
-                    int N, int I, int C, rgda_stream_t stream);
+                    const int* rowptr, const int* cols, const float* vals, int ndst, void* const* outs,
+                    const int* ldouts, const int* out_rows, int out_f32, int N, int C, rgda_stream_t stream);
 
 /* ------------------------------------------------------------- ASPP head */
 

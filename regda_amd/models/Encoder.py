@@ -109,6 +109,35 @@ def upsample_taps_1d(n_in, n_out):
     return U
 
 
+def pool_taps_1d(n_in, s):
+    """One axis of pool_matrix (AdaptiveAvgPool bins floor/ceil): [s, n_in]."""
+    P = torch.zeros(s, n_in)
+    for i in range(s):
+        a, b = (i * n_in) // s, -((-(i + 1) * n_in) // s)
+        P[i, a:b] = 1.0 / (b - a)
+    return P
+
+
+def pool_factored_maps(h, w):
+    """pool_matrix is separable too: P_s[(jy,jx)][(y,x)] = Py_s[jy][y] * Px_s[jx][x].  With r = (s, jx) indexing
+    R = sum(s) intermediate rows per image row:  Px [R, w] (the x direction, rgda_group_mix) and the y direction as
+    dense Py_s-expanded matrices Qy_s [s*s, h*R], Qy_s[(jy,jx)][y*R + off_s + jx] = Py_s[jy][y] (CSR operands)."""
+    R = sum(POOL_SCALES)
+    Px = torch.zeros(R, w)
+    Qy = []
+    off = 0
+    for s in POOL_SCALES:
+        py, px = pool_taps_1d(h, s), pool_taps_1d(w, s)
+        Px[off:off + s] = px
+        Q = torch.zeros(s * s, h * R)
+        for jy in range(s):
+            for jx in range(s):
+                Q[jy * s + jx, torch.arange(h) * R + off + jx] = py[jy]
+        Qy.append(Q)
+        off += s
+    return Px, Qy
+
+
 def _csr(mats):
     """Dense [I, J_q] matrices of up to four sources -> (rowptr int32 [I+1], cols int32 = (q << 24) | j, vals f32),
     the operand format of rgda_sparse_mix."""
@@ -567,7 +596,20 @@ class Deeplabv2(nn.Module):
             self._mat_cache[key] = {
                 'R': Wx.shape[0], 'Wx': Wx.to(dev).contiguous(), 'Wxt': Wx.t().contiguous().to(dev),
                 'fwd': tuple(t.to(dev) for t in _csr(Ay)),                       # B rows <- the four Z_s
-                'bwd': [tuple(t.to(dev) for t in _csr([A.t().contiguous()])) for A in Ay],   # dZ_s rows <- A
+                'bwd': tuple(t.to(dev) for t in _csr([torch.cat([A.t() for A in Ay], 0).contiguous()])),  # dZ_s <- A
+            }
+        return self._mat_cache[key]
+
+    def _pool_maps(self, h, w):
+        """Device operands of the factored adaptive-average-pool maps (pool_factored_maps)."""
+        key = ('pool', h, w)
+        if key not in self._mat_cache:
+            dev = self.device
+            Px, Qy = pool_factored_maps(h, w)
+            self._mat_cache[key] = {
+                'R': Px.shape[0], 'Px': Px.to(dev).contiguous(), 'Pxt': Px.t().contiguous().to(dev),
+                'fwd': tuple(t.to(dev) for t in _csr([torch.cat(Qy, 0).contiguous()])),      # pooled_s rows <- x-pooled rows
+                'bwd': tuple(t.to(dev) for t in _csr([Q.t().contiguous() for Q in Qy])),     # rows <- the four dpool_s
             }
         return self._mat_cache[key]
 
@@ -647,7 +689,7 @@ class Deeplabv2(nn.Module):
         if self.factored_ppm:       # V @ Z as the y map (gather from the four Z_s) then the x map (LDS-staged rows)
             fm = self._ppm_maps(h, w)
             rows = torch.empty(N * h * fm['R'], 512, device=dev)
-            ops.sparse_mix(zs, fm['fwd'], rows, N, h * fm['R'], 512)
+            ops.sparse_mix(zs, fm['fwd'], rows, N, 512)
             ops.group_mix(rows, fm['Wxt'], ppm, N * h, w, fm['R'], 512)
         else:
             ops.spatial_mix_multi(zs, [mats[s][4] for s in POOL_SCALES], ppm, N, HW, 512)
@@ -699,11 +741,13 @@ class Deeplabv2(nn.Module):
             fm = self._ppm_maps(h, w)
             rows = torch.empty(N * h * fm['R'], 512, device=dev)
             ops.group_mix(dc, fm['Wx'], rows, N * h, fm['R'], w, 512)
+            dzs = [torch.empty(N * s * s * 9, 512, dtype=BF, device=dev) for s in POOL_SCALES]
+            ops.sparse_mix([rows], fm['bwd'], dzs, N, 512)
         for i, s in enumerate(POOL_SCALES):
-            dz = torch.empty(N * s * s * 9, 512, dtype=BF, device=dev)
             if self.factored_ppm:
-                ops.sparse_mix([rows], fm['bwd'][i], dz, N, 9 * s * s, 512)
+                dz = dzs[i]
             else:
+                dz = torch.empty(N * s * s * 9, 512, dtype=BF, device=dev)
                 ops.spatial_mix(dc, mats[s][5], dz, N, 9 * s * s, HW, 512)
             dzr = dz.view(N * s * s, 9 * 512)
             dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
@@ -900,11 +944,16 @@ class Deeplabv2(nn.Module):
         else:
             masks = [None, None]
         logits = []
-        pooled_all = []
-        for s in POOL_SCALES:       # both heads pool the same instance-normalised map: do it once
-            pooled = torch.empty(N * s * s, 2048, dtype=BF, device=dev)
-            ops.spatial_mix(xn, mats[s][0], pooled, N, s * s, HW, 2048)
-            pooled_all.append(pooled)
+        # both heads pool the same instance-normalised map: do it once
+        pooled_all = [torch.empty(N * s * s, 2048, dtype=BF, device=dev) for s in POOL_SCALES]
+        if self.factored_ppm:       # all four AdaptiveAvgPool2d in one read of xn: x direction, then y direction
+            pm = self._pool_maps(h, w)
+            prow = torch.empty(N * h * pm['R'], 2048, device=dev)
+            ops.group_mix(xn, pm['Px'], prow, N * h, pm['R'], w, 2048)
+            ops.sparse_mix([prow], pm['fwd'], pooled_all, N, 2048)
+        else:
+            for s, pooled in zip(POOL_SCALES, pooled_all):
+                ops.spatial_mix(xn, mats[s][0], pooled, N, s * s, HW, 2048)
         for hi, head in enumerate(('layer5', 'layer6')):
             qs = []
             for i, s in enumerate(POOL_SCALES):
@@ -964,7 +1013,13 @@ class Deeplabv2(nn.Module):
                                              dqs[i], True, dx_res=dpools[i])
         if self.head_kind == 'ppm':
             gpool = torch.empty(M, 2048, dtype=BF, device=dev)
-            ops.spatial_mix_multi(dpools, [mats[s][1] for s in POOL_SCALES], gpool, N, HW, 2048)
+            if self.factored_ppm:
+                pm = self._pool_maps(h, w)
+                prow = torch.empty(N * h * pm['R'], 2048, device=dev)
+                ops.sparse_mix(dpools, pm['bwd'], prow, N, 2048)
+                ops.group_mix(prow, pm['Pxt'], gpool, N * h, w, pm['R'], 2048)
+            else:
+                ops.spatial_mix_multi(dpools, [mats[s][1] for s in POOL_SCALES], gpool, N, HW, 2048)
             g = torch.empty(M, 2048, dtype=BF, device=dev)
             ops.instnorm_bwd(dfeat, gfeat, gpool, y4, imi, g, N, HW, 2048)
             del dfeat, gpool

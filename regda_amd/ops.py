@@ -336,19 +336,25 @@ def group_mix(inp, W, out, G, I, J, C):
                out.data_ptr(), _ld(out), int(out.dtype == torch.float32), G, I, J, C, _stream())
 
 
-def sparse_mix(ins, csr, out, N, I, C):
-    """out[n][i][:] = sum_k vals[k] * ins[cols[k] >> 24][n][cols[k] & 0xffffff][:] over CSR row i.
-    csr = (rowptr int32 [I+1], cols int32, vals f32) on the device; ins: <= 4 tensors of one dtype."""
+def sparse_mix(ins, csr, outs, N, C):
+    """outs[q][n][i][:] = sum_k vals[k] * ins[cols[k] >> 24][n][cols[k] & 0xffffff][:] over the CSR rows, which are
+    split in order over the (<= 4) image-major output tensors.  csr = (rowptr int32, cols int32, vals f32) on the
+    device; ins: <= 4 tensors of one dtype; outs: a tensor or a list of tensors of one dtype."""
     import ctypes
     rowptr, cols, vals = csr
+    outs = [outs] if torch.is_tensor(outs) else list(outs)
     assert rowptr.dtype == torch.int32 and cols.dtype == torch.int32 and vals.dtype == torch.float32
-    assert rowptr.numel() == I + 1 and out.shape[0] == N * I
-    n = len(ins)
+    rows = [o.shape[0] // N for o in outs]
+    assert rowptr.numel() == sum(rows) + 1 and all(o.shape[0] == N * r for o, r in zip(outs, rows))
+    n, m = len(ins), len(outs)
     P = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ins])
     L = (ctypes.c_int * n)(*[_ld(t) for t in ins])
     J = (ctypes.c_int * n)(*[t.shape[0] // N for t in ins])
+    O = (ctypes.c_void_p * m)(*[t.data_ptr() for t in outs])
+    OL = (ctypes.c_int * m)(*[_ld(t) for t in outs])
+    OR = (ctypes.c_int * m)(*rows)
     lib().call('rgda_sparse_mix', n, P, L, J, int(ins[0].dtype == torch.float32), rowptr.data_ptr(), cols.data_ptr(),
-               vals.data_ptr(), out.data_ptr(), _ld(out), int(out.dtype == torch.float32), N, I, C, _stream())
+               vals.data_ptr(), m, O, OL, OR, int(outs[0].dtype == torch.float32), N, C, _stream())
 
 
 def classifier_fwd(hidden, w, bias, logits, N, HW, C, ncls):

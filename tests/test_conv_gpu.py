@@ -540,7 +540,7 @@ def test_sparse_mix_matches_dense_multi_source():
     ins = [torch.randn(N * J, C, generator=g).to(BF) for J in Js]
     csr = tuple(t.cuda() for t in _csr(mats))
     out = torch.empty(N * I, C, device='cuda')
-    ops.sparse_mix([t.cuda() for t in ins], csr, out, N, I, C)
+    ops.sparse_mix([t.cuda() for t in ins], csr, out, N, C)
     ref = sum(torch.einsum('ij,njc->nic', m, t.float().view(N, -1, C)) for m, t in zip(mats, ins)).reshape(N * I, C)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
     assert float(out.view(N, I, C)[:, 7].abs().max()) == 0.0
@@ -548,7 +548,13 @@ def test_sparse_mix_matches_dense_multi_source():
     a = torch.randn(N * 81, C, generator=g)
     csr1 = tuple(t.cuda() for t in _csr([mats[2]]))
     o2 = torch.empty(N * I, C, dtype=BF, device='cuda')
-    ops.sparse_mix([a.cuda()], csr1, o2, N, I, C)
+    ops.sparse_mix([a.cuda()], csr1, o2, N, C)
+    # the same rows split over three output tensors (20 + 1 + 29 rows per image)
+    parts = [torch.empty(N * r, C, dtype=BF, device='cuda') for r in (20, 1, 29)]
+    ops.sparse_mix([a.cuda()], csr1, parts, N, C)
+    whole = o2.view(N, I, C)
+    for t, (lo, hi) in zip(parts, ((0, 20), (20, 21), (21, 50))):
+        assert torch.equal(t.view(N, hi - lo, C), whole[:, lo:hi])
     ref2 = torch.einsum('ij,njc->nic', mats[2], a.view(N, 81, C)).reshape(N * I, C)
     assert ((o2.float().cpu() - ref2).norm() / ref2.norm()).item() < 1e-2
 
@@ -568,7 +574,7 @@ def test_factored_ppm_maps_equal_the_one_pass_maps_per_op():
     one = torch.empty(N * h * w, C, dtype=BF, device='cuda')
     ops.spatial_mix_multi(zs, Vs, one, N, h * w, C)
     rows = torch.empty(N * h * R, C, device='cuda')
-    ops.sparse_mix(zs, fwd, rows, N, h * R, C)
+    ops.sparse_mix(zs, fwd, rows, N, C)
     two = torch.empty(N * h * w, C, dtype=BF, device='cuda')
     ops.group_mix(rows, Wx.t().contiguous().cuda(), two, N * h, w, R, C)
     ref = sum(torch.einsum('pj,njc->npc', V.cpu(), z.float().cpu().view(N, -1, C)) for V, z in zip(Vs, zs)).reshape(N * h * w, C)
@@ -576,10 +582,9 @@ def test_factored_ppm_maps_equal_the_one_pass_maps_per_op():
     assert ((two.float() - one.float()).norm() / one.float().norm()).item() < 5e-3
     dc = torch.randn(N * h * w, C, generator=g).to(BF).cuda()
     ops.group_mix(dc, Wx.cuda().contiguous(), rows, N * h, R, w, C)
-    for s, A, V in zip(POOL_SCALES, Ay, Vs):
-        csr = tuple(t.cuda() for t in _csr([A.t().contiguous()]))
-        dz2 = torch.empty(N * 9 * s * s, C, dtype=BF, device='cuda')
-        ops.sparse_mix([rows], csr, dz2, N, 9 * s * s, C)
+    dzs = [torch.empty(N * 9 * s * s, C, dtype=BF, device='cuda') for s in POOL_SCALES]
+    ops.sparse_mix([rows], tuple(t.cuda() for t in _csr([torch.cat([A.t() for A in Ay], 0).contiguous()])), dzs, N, C)
+    for s, dz2, V in zip(POOL_SCALES, dzs, Vs):
         dz1 = torch.empty(N * 9 * s * s, C, dtype=BF, device='cuda')
         ops.spatial_mix(dc, V.t().contiguous(), dz1, N, 9 * s * s, h * w, C)
         ref = torch.einsum('pj,npc->njc', V.cpu(), dc.float().cpu().view(N, h * w, C)).reshape(N * 9 * s * s, C)

@@ -82,6 +82,17 @@ def test_factored_ppm_maps_reproduce_the_head_conv():
         assert int((rowptr[1:] - rowptr[:-1]).max()) <= 6
 
 
+def test_factored_pool_maps_reproduce_adaptive_avg_pool():
+    from regda_amd.models.Encoder import POOL_SCALES, pool_factored_maps, pool_matrix
+    for (h, w) in [(32, 32), (8, 8), (5, 7)]:
+        Px, Qy = pool_factored_maps(h, w)
+        R = Px.shape[0]
+        assert R == sum(POOL_SCALES)
+        for s, Q in zip(POOL_SCALES, Qy):
+            Pf = torch.einsum('jyr,rx->jyx', Q.view(s * s, h, R), Px).reshape(s * s, h * w)
+            torch.testing.assert_close(Pf, pool_matrix(h, w, s), rtol=0, atol=1e-7)
+
+
 def test_synthetic_batch_contract():
     from regda_amd.synthetic import make_batch
     b = make_batch(b=2, size=64, seed=1, device='cpu')

@@ -31,6 +31,7 @@ extern "C" {
  * copy b % 8, i.e. the copy of the XCD it runs on, so the fp32 atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore f32[RGDA_STAT_REPLICAS][2][C], zeroed by the caller. */
 #define RGDA_STAT_REPLICAS 8
+#define RGDA_LAYOUT_TILE 64      /* tile edge of rgda_weight_transpose_batched (block accounting of its table) */
 
 typedef void* rgda_stream_t; /* hipStream_t */
 
@@ -288,7 +289,8 @@ int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, 
 /* every derived bf16 weight layout of a model in one launch: device table[n][8] int64 = {src f32*, dst bf16*,
  * Co, T, Ci, first_block, src_ld, mode}.  src element (co,tap,ci) = src[(co*T+tap)*src_ld + ci] (src_ld > Ci: a
  * channel slice of a wider tensor); mode 0: dst[ci][tap][co] (the data-gradient operand), 1: dst[tap][co][ci],
- * 2: dst[co][tap][ci].  A row owns ceil(Ci/32)*ceil(Co/32)*T consecutive blocks starting at first_block. */
+ * 2: dst[co][tap][ci].  A row owns ceil(Ci/RGDA_LAYOUT_TILE)*ceil(Co/RGDA_LAYOUT_TILE)*T consecutive blocks starting
+ * at first_block. */
 int rgda_weight_transpose_batched(const int64_t* table, int n, int64_t total_blocks, rgda_stream_t stream);
 int rgda_cast_bf16(const float* src, void* dst, int64_t n, rgda_stream_t stream);
 /* rows of K f32 -> rows of Kp bf16, zero padded (stem weights [64][147] -> [64][192]); and the

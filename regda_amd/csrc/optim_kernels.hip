@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float* __re
 // (nine 1x1 filters stacked), mode 2: dst[co][tap][ci] (plain slice).  A row owns ceil(Ci/32)*ceil(Co/32)*T
 // consecutive blocks starting at first_block (ascending).
 __global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const long long* __restrict__ table, int n) {
-    __shared__ float tile[32][33];
+    // 64 x 64 tiles: 256-byte fp32 row reads, 128-byte bf16 row writes in every mode (32-wide tiles wrote half lines)
+    constexpr int TS = RGDA_LAYOUT_TILE;
+    __shared__ float tile[TS][TS + 1];
     int lo = 0, hi = n - 1;
     const long long b = blockIdx.x;
     while (lo < hi) {                       // last entry with first_block <= b
@@ -158,24 +160,54 @@ __global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const lon
     const long long sld = e[6];
     const int mode = (int)e[7];
     int rel = (int)(b - e[5]);
-    const int nci = (Ci + 31) / 32, nco = (Co + 31) / 32;
+    const int nci = (Ci + TS - 1) / TS, nco = (Co + TS - 1) / TS;
     const int bx = rel % nci; rel /= nci;
     const int by = rel % nco;
     const int tap = rel / nco;
-    const int co0 = by * 32, ci0 = bx * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
+    const int co0 = by * TS, ci0 = bx * TS;
+    // fast path: 16-byte reads (4 floats along ci), 8-byte writes (4 bf16 along the destination's contiguous index)
+    const bool vec = !(Ci & 3) && !(sld & 3) && !((size_t)w & 15) && !((size_t)wt & 7) && (mode != 0 || !(Co & 3));
+    if (vec) {
+        const int q = threadIdx.x & 15, rq = threadIdx.x >> 4;          // 16 quads per row, 16 rows per pass
+        for (int r = rq; r < TS; r += 16) {
+            const int co = co0 + r, ci = ci0 + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < Co && ci < Ci) v = *(const float4*)(w + ((size_t)co * T + tap) * sld + ci);
+            tile[r][q * 4 + 0] = v.x; tile[r][q * 4 + 1] = v.y; tile[r][q * 4 + 2] = v.z; tile[r][q * 4 + 3] = v.w;
+        }
+        __syncthreads();
+        for (int r = rq; r < TS; r += 16) {
+            uint2 pk;
+            if (mode == 0) {
+                const int ci = ci0 + r, co = co0 + q * 4;
+                if (ci >= Ci || co >= Co) continue;
+                pk.x = pack2bf(tile[q * 4 + 0][r], tile[q * 4 + 1][r]);
+                pk.y = pack2bf(tile[q * 4 + 2][r], tile[q * 4 + 3][r]);
+                *(uint2*)(wt + ((size_t)ci * T + tap) * Co + co) = pk;
+            } else {
+                const int co = co0 + r, ci = ci0 + q * 4;
+                if (ci >= Ci || co >= Co) continue;
+                pk.x = pack2bf(tile[r][q * 4 + 0], tile[r][q * 4 + 1]);
+                pk.y = pack2bf(tile[r][q * 4 + 2], tile[r][q * 4 + 3]);
+                *(uint2*)(wt + (mode == 1 ? ((size_t)tap * Co + co) : ((size_t)co * T + tap)) * Ci + ci) = pk;
+            }
+        }
+        return;
+    }
+    const int tx = threadIdx.x & (TS - 1), ty = threadIdx.x / TS;
+    constexpr int RS = 256 / TS;            // rows per pass
+    for (int r = ty; r < TS; r += RS) {
         int co = co0 + r, ci = ci0 + tx;
         tile[r][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + tap) * sld + ci] : 0.f;
     }
     __syncthreads();
     if (mode == 0) {
-        for (int r = ty; r < 32; r += 8) {
+        for (int r = ty; r < TS; r += RS) {
             int ci = ci0 + r, co = co0 + tx;
             if (ci < Ci && co < Co) wt[((size_t)ci * T + tap) * Co + co] = f2bf(tile[tx][r]);
         }
     } else {
-        for (int r = ty; r < 32; r += 8) {
+        for (int r = ty; r < TS; r += RS) {
             int co = co0 + r, ci = ci0 + tx;
             if (ci < Ci && co < Co)
                 wt[(mode == 1 ? ((size_t)tap * Co + co) : ((size_t)co * T + tap)) * Ci + ci] = f2bf(tile[r][tx]);

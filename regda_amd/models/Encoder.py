@@ -29,6 +29,13 @@ LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3),
           'resnet17t': (2, 1, 1, 2)}   # resnet17t: test-only shallow topology (same code paths, 6 blocks)
 POOL_SCALES = (1, 2, 3, 6)
 NREP = 8                # RGDA_STAT_REPLICAS (include/rgda_hip.h)
+LAYOUT_TILE = 64        # RGDA_LAYOUT_TILE
+
+
+def _layout_blocks(co, ci, taps):
+    """Blocks one table row of rgda_weight_transpose_batched owns."""
+    return -(-ci // LAYOUT_TILE) * -(-co // LAYOUT_TILE) * taps
+
 ASPP_DILATIONS = (6, 12, 18, 24)     # dilation_series = padding_series of every Classifier_Module (Encoder.py:101-114)
 STEM_KP = 192           # 7*7*3 = 147 im2col columns, zero padded to a multiple of 64
 
@@ -400,7 +407,7 @@ class Deeplabv2(nn.Module):
             if c.wtb is not None:
                 T = c.k * c.k
                 rows.append([c.w.data_ptr(), c.wtb.data_ptr(), c.co, T, c.ci, blk, c.ci, 0])
-                blk += ((c.ci + 31) // 32) * ((c.co + 31) // 32) * T
+                blk += _layout_blocks(c.co, c.ci, T)
         self._wt_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._wt_blocks = blk
         self.stem_wb = torch.zeros(64, 1, STEM_KP, dtype=BF, device=dev)
@@ -433,15 +440,15 @@ class Deeplabv2(nn.Module):
                 wsrc = self.convs[f'{head}.conv_last.0'].w          # fp32 master, [512][9][4096]
                 if 'fwd' in kinds:
                     rows.append([wsrc.data_ptr(), hw['wfeat'].data_ptr(), 512, 9, 2048, blk, 4096, 2])
-                    blk += (2048 // 32) * (512 // 32) * 9
+                    blk += _layout_blocks(512, 2048, 9)
                 for i in range(len(POOL_SCALES)):
                     src = wsrc.data_ptr() + 4 * (2048 + 512 * i)
                     if 'fwd' in kinds:
                         rows.append([src, hw['wz'][i].data_ptr(), 512, 9, 512, blk, 4096, 1])
-                        blk += 16 * 16 * 9
+                        blk += _layout_blocks(512, 512, 9)
                     if 'bwd' in kinds:
                         rows.append([src, hw['wzt'][i].data_ptr(), 512, 9, 512, blk, 4096, 0])
-                        blk += 16 * 16 * 9
+                        blk += _layout_blocks(512, 512, 9)
             return torch.tensor(rows, dtype=torch.int64, device=dev), blk
         self._hw_fwd_table, self._hw_fwd_blocks = table(('fwd',))
         self._hw_bwd_table, self._hw_bwd_blocks = table(('bwd',))
@@ -462,7 +469,7 @@ class Deeplabv2(nn.Module):
         rows, blk = [], 0
         for j, c in enumerate(self.aspp_convs):          # mode 2: fp32 master slice -> bf16, same layout
             rows.append([c.w.data_ptr(), self.aspp_wz.data_ptr() + 2 * j * C * 9 * 2048, C, 9, 2048, blk, 2048, 2])
-            blk += (2048 // 32) * ((C + 31) // 32) * 9
+            blk += _layout_blocks(C, 2048, 9)
         self._hw_fwd_table, self._hw_fwd_blocks = torch.tensor(rows, dtype=torch.int64, device=dev), blk
 
     def _init_weights(self):

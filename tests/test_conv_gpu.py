@@ -470,7 +470,7 @@ def test_weight_layout_table_modes(ops):
         shape = {0: (Ci, T, Co), 1: (T, Co, Ci), 2: (Co, T, Ci)}[mode]
         dst = torch.zeros(shape, dtype=BF, device='cuda')
         rows.append([w.data_ptr() + 4 * off, dst.data_ptr(), Co, T, Ci, blk, Cw, mode])
-        blk += -(-Ci // 32) * -(-Co // 32) * T
+        blk += -(-Ci // 64) * -(-Co // 64) * T        # RGDA_LAYOUT_TILE
         sl = w[:, :, off:off + Ci]
         ref = {0: sl.permute(2, 1, 0), 1: sl.permute(1, 0, 2), 2: sl}[mode]
         outs.append((dst, ref.to(BF)))

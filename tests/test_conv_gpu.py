@@ -160,6 +160,22 @@ def test_stem_im2col_and_gemm(ops):
     assert relerr(from_pxc(y, N, Ho, Wo), ref) < 1e-2
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 32, 48), (1, 38, 270), (3, 16, 130)])
+def test_stem_im2col_columns_exact(ops, N, H, W):
+    """Every column vector, bit-exact: col[(n,ho,wo)][(kh*7+kw)*3 + c] = bf16(img[n, c, 2ho-3+kh, 2wo-3+kw]) or 0
+    (padding, and the columns 147..191); widths that are not a multiple of the 64-pixel workgroup tile included."""
+    g = torch.Generator().manual_seed(4)
+    img = torch.randn(N, 3, H, W, generator=g)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    col = torch.full((N * Ho * Wo, 192), 7.0, dtype=BF, device='cuda')
+    ops.stem_im2col(img.cuda(), col, N, H, W, Ho, Wo)
+    unf = F.unfold(img.to(BF).float(), 7, 1, 3, 2)                     # (N, 3*49, Ho*Wo), row = c*49 + kh*7 + kw
+    ref = unf.view(N, 3, 49, Ho * Wo).permute(0, 3, 2, 1).reshape(N * Ho * Wo, 147)
+    got = col.float().cpu()
+    assert torch.equal(got[:, :147], ref)
+    assert float(got[:, 147:].abs().max()) == 0.0
+
+
 def test_batchnorm_fwd_bwd(ops):
     g = torch.Generator().manual_seed(2)
     N, C, H, W = 4, 64, 8, 8

@@ -34,6 +34,24 @@ static __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// v + v[lane ^ O] for O = 8 / 16 / 32 without the LDS crossbar: DPP row rotate (rows are 16 lanes) and the gfx950
+// half / row-pair exchanges.  `__shfl_xor` is a ds_bpermute_b32: 32 of them per wave in a conv epilogue, from all eight
+// waves of the workgroup at once, cost ~3000 cycles on the shared LDS pipe (tests/dev_conv_phases2.py).
+template <int O>
+static __device__ __forceinline__ float xor_add(float v) {
+    static_assert(O == 8 || O == 16 || O == 32, "xor_add: 8, 16 or 32");
+    const unsigned u = __float_as_uint(v);
+    if constexpr (O == 8) {
+        return v + __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    } else if constexpr (O == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // rows (0,1) and (2,3) exchanged
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // the two half-waves exchanged
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+}
+
 static __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -407,11 +407,9 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         // lanes with equal cv inside a wave: strides VPR, 2*VPR, ... < 64
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = VPR; o < 64; o <<= 1) {
-                s[e] += __shfl_xor(s[e], o, 64);
-                q[e] += __shfl_xor(q[e], o, 64);
-            }
+            if constexpr (VPR <= 8) { s[e] = xor_add<8>(s[e]); q[e] = xor_add<8>(q[e]); }
+            if constexpr (VPR <= 16) { s[e] = xor_add<16>(s[e]); q[e] = xor_add<16>(q[e]); }
+            if constexpr (VPR <= 32) { s[e] = xor_add<32>(s[e]); q[e] = xor_add<32>(q[e]); }
         }
         float* red = (float*)(smem + BP * CSTR);     // [NW waves][2][BC]
         if (lane < VPR) {

@@ -49,7 +49,7 @@ def parse():
     return ap.parse_args()
 
 
-def conv_flops_probe(step_fn):
+def conv_flops_probe(step_fn, park_ms=150.0):
     """Run one step with HIP events (torch.cuda.Event on the launch stream) around every conv launch.
     Returns {kernel instantiation: dict(gflop, ms, launches, tflops, avg_us)}; names match rocprofv3's."""
     import torch
@@ -74,7 +74,8 @@ def conv_flops_probe(step_fn):
         e0.record()
         launch()
         e1.record()
-        rec.append((name, 2.0 * M * co * taps * ci, e0, e1, (kind, M, co, ci, taps, stride, dil), 1, abytes))
+        rec.append((name, 2.0 * M * co * taps * ci, e0, e1, (kind, M, co, ci, taps, stride, dil), 1, abytes,
+                    2.0 * M * co * taps * ci if taps == 9 else 0.0))
 
     def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1, **k):
         rpg = (N * Ho * Wo // stat_groups) if (stats is not None and stat_groups > 1) else 0
@@ -126,22 +127,33 @@ def conv_flops_probe(step_fn):
             by = sum(2.0 * it[3] * it[4] * it[5] * it[2].shape[2] + 2.0 * it[3] * it[6] * it[7] * it[2].shape[0] +
                      4.0 * it[2].numel() for it in its)
             rec.append((name, fl, e0, e1, ('wgrad x%d' % len(its),) + (its[0][3] * its[0][6] * its[0][7],) + tuple(its[0][2].shape[i] for i in (0, 2, 1)) + (its[0][10], its[0][12]),
-                        -(-len(its) // 16), by))
+                        -(-len(its) // 16), by,
+                        sum(2.0 * it[3] * it[6] * it[7] * it[2].numel() for it in its if it[8] == 3 and it[9] == 3)))
 
     def wgrad(*item):
         wgrad_grouped([item])
     ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd = conv, wgrad, conv_bne, conv_bnb
     ops.conv2d_wgrad_grouped = wgrad_grouped
+    # The wrappers make the host slower than the GPU for the short kernels, and an event pair then also brackets the
+    # host's enqueue time between `e0.record()` and the launch.  Park the stream behind a spin kernel long enough for
+    # the host to enqueue the whole step first: every bracket then measures queue-to-queue GPU time only.
+    torch.cuda.synchronize()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record(); torch.cuda._sleep(1_000_000); c1.record(); torch.cuda.synchronize()
+    cycles_per_ms = 1_000_000 / max(c0.elapsed_time(c1), 1e-3)
     try:
+        torch.cuda._sleep(int(park_ms * cycles_per_ms))
         step_fn()
         torch.cuda.synchronize()
     finally:
         ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd = o_conv, o_wgrad, o_bne, o_bnb
         ops.conv2d_wgrad_grouped = o_wgrad_g
     kern, shapes = {}, {}
+    c3 = [0.0, 0.0]                                # FLOPs / ms of the 3x3 convolutions (forward, data and weight gradient)
     for r in rec:
-        name, fl, e0, e1, shp, nl, by = r          # nl = kernel launches inside the bracket, by = algorithmic bytes
+        name, fl, e0, e1, shp, nl, by, fl3 = r     # nl = kernel launches inside the bracket, by = algorithmic bytes
         dt = e0.elapsed_time(e1)
+        c3[0] += fl3; c3[1] += dt * fl3 / max(fl, 1.0)      # a mixed weight-gradient bucket is split by FLOPs
         k = kern.setdefault(name, [0.0, 0.0, 0, 0.0])
         k[0] += fl; k[1] += dt; k[2] += nl; k[3] += by
         q = shapes.setdefault(shp, [0.0, 0.0, 0])
@@ -150,9 +162,11 @@ def conv_flops_probe(step_fn):
         with open(os.environ['RGDA_CONV_REPORT'], 'w') as f:
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                 f.write('%-8s M=%-7d Co=%-5d Ci=%-5d taps=%d s=%d d=%d  n=%-3d ms=%8.3f  TF/s=%7.1f\n' % (k + (v[2], v[1], v[0] / 1e9 / max(v[1], 1e-9))))
-    return {k: dict(gflop=v[0] / 1e9, ms=v[1], launches=v[2], tflops=v[0] / 1e9 / max(v[1], 1e-9),
-                    avg_us=v[1] / v[2] * 1e3, algorithmic_mb=v[3] / 1e6, gbps=v[3] / 1e6 / max(v[1], 1e-9))
-            for k, v in kern.items()}
+    out = {k: dict(gflop=v[0] / 1e9, ms=v[1], launches=v[2], tflops=v[0] / 1e9 / max(v[1], 1e-9),
+                   avg_us=v[1] / v[2] * 1e3, algorithmic_mb=v[3] / 1e6, gbps=v[3] / 1e6 / max(v[1], 1e-9))
+           for k, v in kern.items()}
+    out['__conv3x3__'] = dict(gflop=c3[0] / 1e9, ms=c3[1], tflops=c3[0] / 1e9 / max(c3[1], 1e-9))
+    return out
 
 
 def cpu_baseline(args):
@@ -288,6 +302,7 @@ def main():
         step._graph = None          # the per-launch HIP-event probe needs the eager path ...
         side, step.wgrad_stream = step.wgrad_stream, None     # ... and one stream, so a launch's events bracket only itself
         kern = conv_flops_probe(one)
+        c3 = kern.pop('__conv3x3__')
         step.wgrad_stream = side
         # the dominant kernel = the conv instantiation with the most GPU time in the step
         dom = max(kern, key=lambda k: kern[k]['ms'])
@@ -314,6 +329,9 @@ def main():
                            'algorithmic_mb_per_launch': d['algorithmic_mb'] / d['launches'],
                            'all_conv_kernels': {'achieved': gf / ms, 'frac': gf / ms / MFMA_PEAK_TFLOPS,
                                                 'gflop_per_step': gf, 'ms_per_step': ms},
+                           # BASELINE.json's MFMA target is stated on the 3x3 convolutions (forward + both gradients)
+                           'conv3x3': {'achieved': c3['tflops'], 'frac': c3['tflops'] / MFMA_PEAK_TFLOPS,
+                                       'unit': 'TFLOP/s', 'gflop_per_step': c3['gflop'], 'ms_per_step': c3['ms']},
                            'by_kernel': kern}
     if rank == 0 and world == 1 and args.align_steps > 0:
         from regda_amd.align import AlignStep

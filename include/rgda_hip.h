@@ -278,8 +278,9 @@ int rgda_sumsq(const float* g, int64_t n, float* out, float* ws, rgda_stream_t s
  *   tools/train_ssl_reg.py:174-175,239-241; regda/utils/ema.py:46-51.
  * coef = min(1, max_norm / (sqrt(gnorm_sq[0]) * gscale + 1e-6)); g = g*gscale*coef (gscale = 1/world)
  * v = momentum*v + (g + wd*p); p -= lr*v; shadow = (1-d)*p + d*shadow (if shadow);
- * p_bf16 = bf16(p) (if given).  lr is read from device memory (lr_dev[0]). */
-int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf16,
+ * p_bf16 = bf16(p) (if given); shadow_bf16 = bf16(shadow) (if given: the EMA teacher's mirror).
+ * lr is read from device memory (lr_dev[0]). */
+int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf16, void* shadow_bf16,
                   const float* gnorm_sq, const float* lr_dev, int64_t n, float momentum,
                   float weight_decay, float max_norm, float gscale, float ema_decay,
                   int first_step, rgda_stream_t stream);

@@ -47,7 +47,8 @@ extern "C" int rgda_sumsq(const float* g, int64_t n, float* out, float* ws, rgda
 
 __global__ void __launch_bounds__(256) sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ v, float* __restrict__ shadow,
-                                                       bf16_t* __restrict__ pb, const float* __restrict__ gnorm_sq,
+                                                       bf16_t* __restrict__ pb, bf16_t* __restrict__ sb,
+                                                       const float* __restrict__ gnorm_sq,
                                                        const float* __restrict__ lr_dev, long long n4, float momentum,
                                                        float wd, float max_norm, float gscale, float ema_d,
                                                        int first_step) {
@@ -76,6 +77,12 @@ __global__ void __launch_bounds__(256) sgd_step_kernel(float* __restrict__ p, co
             const float a = 1.f - ema_d;
             ss.x = a * pp.x + ema_d * ss.x; ss.y = a * pp.y + ema_d * ss.y; ss.z = a * pp.z + ema_d * ss.z; ss.w = a * pp.w + ema_d * ss.w;
             s4[i] = ss;
+            if (sb) {           // the teacher's bf16 mirror, while the shadow weights are in registers
+                uint2 pk;
+                pk.x = pack2bf(ss.x, ss.y);
+                pk.y = pack2bf(ss.z, ss.w);
+                *(uint2*)(sb + (i << 2)) = pk;
+            }
         }
         if (pb) {
             uint2 pk;
@@ -86,13 +93,13 @@ __global__ void __launch_bounds__(256) sgd_step_kernel(float* __restrict__ p, co
     }
 }
 
-extern "C" int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf16, const float* gnorm_sq,
+extern "C" int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf16, void* shadow_bf16, const float* gnorm_sq,
                              const float* lr_dev, int64_t n, float momentum, float weight_decay, float max_norm,
                              float gscale, float ema_decay, int first_step, rgda_stream_t stream) {
     if (!p || !g || !v || !gnorm_sq || !lr_dev || n <= 0 || (n & 3)) return RGDA_ERR_ARG;
     long long n4 = n >> 2;
     int blocks = min(cdiv(n4, 256 * 4), 4096);
-    sgd_step_kernel<<<blocks, 256, 0, to_stream(stream)>>>(p, g, v, shadow, (bf16_t*)p_bf16, gnorm_sq, lr_dev, n4,
+    sgd_step_kernel<<<blocks, 256, 0, to_stream(stream)>>>(p, g, v, shadow, (bf16_t*)p_bf16, (bf16_t*)shadow_bf16, gnorm_sq, lr_dev, n4,
                                                             momentum, weight_decay, max_norm, gscale, ema_decay,
                                                             first_step);
     RGDA_CHECK_LAUNCH();

@@ -569,9 +569,11 @@ class Deeplabv2(nn.Module):
         t.eval()
         return t
 
-    def refresh_from_master(self):
-        """bf16 mirror + padded stem weights only (a forward-only model needs no transposed copies)."""
-        ops.cast_bf16(self.flat_p, self.flat_pb)
+    def refresh_from_master(self, mirror_is_fresh=False):
+        """bf16 mirror + padded stem weights only (a forward-only model needs no transposed copies).
+        mirror_is_fresh: the caller's optimizer already wrote flat_pb (rgda_sgd_step's shadow_bf16)."""
+        if not mirror_is_fresh:
+            ops.cast_bf16(self.flat_p, self.flat_pb)
         s = self.convs['encoder.resnet.conv1']
         ops.pad_cast_bf16(s.w, self.stem_wb, 64, 147, STEM_KP)
         self._sync_head_weights(False)
@@ -931,7 +933,7 @@ class Deeplabv2(nn.Module):
                 dbg[p] = y.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
         HW, M = h * w, N * h * w
         xn = torch.empty(M, 2048, dtype=BF, device=dev)          # instance-normalised features, shared by both heads
-        feat = torch.empty(N, 2048, h, w, device=dev)
+        feat = torch.empty(N, 2048, h, w, device=dev) if T is not None else None   # eval returns probabilities only
         imi = torch.empty(N, 2, 2048, device=dev)
         ops.instnorm_fwd(y, xn, None, feat, imi, N, HW, 2048)
         if self._hw_ready is not None:                             # head weight slices rebuilt on another stream

@@ -372,8 +372,9 @@ def sumsq(g, out, ws):
 
 
 def sgd_step(p, g, v, shadow, p_bf16, gnorm_sq, lr_dev, momentum, weight_decay, max_norm, gscale, ema_decay,
-             first_step):
-    lib().call('rgda_sgd_step', p.data_ptr(), g.data_ptr(), v.data_ptr(), _p(shadow), _p(p_bf16), gnorm_sq.data_ptr(),
+             first_step, shadow_bf16=None):
+    lib().call('rgda_sgd_step', p.data_ptr(), g.data_ptr(), v.data_ptr(), _p(shadow), _p(p_bf16), _p(shadow_bf16),
+               gnorm_sq.data_ptr(),
                lr_dev.data_ptr(), p.numel(), momentum, weight_decay, max_norm, gscale, ema_decay, int(first_step),
                _stream())
 

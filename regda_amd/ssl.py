@@ -175,7 +175,8 @@ class SSLStep:
         ops.sumsq(m.flat_g, self.gn, self.gn_ws)
         shadow = self.teacher.flat_p if self.teacher is not None else None
         ops.sgd_step(m.flat_p, m.flat_g, self.mom, shadow, m.flat_pb, self.gn, self.lr_dev, self.momentum, self.wd,
-                     self.max_norm, self.reducer.gscale, self.ema_decay if shadow is not None else 0.0, self.first)
+                     self.max_norm, self.reducer.gscale, self.ema_decay if shadow is not None else 0.0, self.first,
+                     shadow_bf16=self.teacher.flat_pb if shadow is not None else None)   # teacher mirror stays fresh
         self.first = False
         m.sync_derived_weights(self.wgrad_stream)
         m._synced_version = m.flat_p._version
@@ -185,7 +186,7 @@ class SSLStep:
     def teacher_probs(self, images_t):
         """Eval-mode forward of the EMA teacher (Encoder.py:152-155 on the shadow weights)."""
         t = self.teacher
-        t.refresh_from_master()
+        t.refresh_from_master(mirror_is_fresh=True)       # make_teacher() and every sgd_step keep flat_pb current
         t.eval()
         x1, x2, _ = t._forward_plan(images_t.contiguous().float(), None)
         return ops.teacher_probs(x1, x2, tuple(images_t.shape[-2:]))

@@ -397,6 +397,7 @@ def test_optimizer_kernels(ops):
     sh = p.clone()
     pd, gd, vd, sd = p.cuda(), gr.cuda(), v.cuda(), sh.cuda()
     pb = torch.empty(n, dtype=BF, device='cuda')
+    sb = torch.empty(n, dtype=BF, device='cuda')
     gn, ws = torch.empty(1, device='cuda'), torch.empty(1024, device='cuda')
     lr = torch.tensor([0.01], device='cuda')
     pr = torch.nn.Parameter(p.clone())
@@ -404,7 +405,7 @@ def test_optimizer_kernels(ops):
     for step in range(2):
         ops.sumsq(gd, gn, ws)
         assert gn.item() == pytest.approx((gr.double() ** 2).sum().item(), rel=1e-5)
-        ops.sgd_step(pd, gd, vd, sd, pb, gn, lr, 0.9, 5e-4, 32.0, 1.0, 0.99, step == 0)
+        ops.sgd_step(pd, gd, vd, sd, pb, gn, lr, 0.9, 5e-4, 32.0, 1.0, 0.99, step == 0, shadow_bf16=sb)
         pr.grad = gr.clone()
         torch.nn.utils.clip_grad_norm_([pr], 32.0)
         opt.step()
@@ -412,6 +413,7 @@ def test_optimizer_kernels(ops):
     torch.testing.assert_close(pd.cpu(), pr.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(sd.cpu(), sh, rtol=1e-5, atol=1e-6)
     assert torch.equal(pb.cpu(), pd.cpu().to(BF))
+    assert torch.equal(sb.cpu(), sd.cpu().to(BF))          # the EMA teacher's mirror, written in the same pass
     w = torch.randn(40, 9, 24, generator=g)
     wt = torch.empty(24, 9, 40, dtype=BF, device='cuda')
     ops.weight_transpose_bf16(w.cuda(), wt, 40, 9, 24)

@@ -5,6 +5,7 @@
 #   <tag>_kernel_stats.txt             rocprofv3 --kernel-trace --stats of bench.py --serial (one stream: the
 #                                      per-kernel averages the roofline probe's HIP events must agree with)
 #   <tag>_kernel_stats_overlapped.txt  the same for the default two-stream step
+#   <tag>_kernel_one_step.txt          kernel time of ONE serial step by kernel name (no model initialisation)
 #   <tag>_pmc_hbm_traffic.txt + pmc_traffic.json   FETCH_SIZE / WRITE_SIZE passes
 tag=$1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -12,6 +13,7 @@ bash scripts/pmc_traffic.sh > /dev/null 2>&1
 cp gpurun_out/pmc_traffic.txt gpurun_out/${tag}_pmc_hbm_traffic.txt
 mkdir -p profiles; cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json      # the bench line below reads it
 bash scripts/gpu_prof.sh ${tag}s > /dev/null 2>&1; cp gpurun_out/prof_${tag}s.txt gpurun_out/${tag}_kernel_stats.txt
+bash scripts/kstep_all.sh > /dev/null 2>&1; cp gpurun_out/ks_all.txt gpurun_out/${tag}_kernel_one_step.txt
 rm -rf gpurun_out/prof_o
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_o -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_o.log 2>&1
 python scripts/prof_summary.py gpurun_out/prof_o/r_results.db 5 > gpurun_out/${tag}_kernel_stats_overlapped.txt

@@ -77,10 +77,159 @@ static __device__ __forceinline__ void src_coord(int mode, int base, int t, int 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// ---- epilogue shared by the convolution kernels: accumulators -> bf16 C tile [pixel][cout] in LDS (`smem`, BP * CSTR
+// bytes + the reduction scratch behind it) -> 16-byte rows to memory, with the fused residual / inference BatchNorm /
+// BatchNorm statistics / BatchNorm-backward sums.  s, q: the per-channel sums of this thread's channel vector,
+// carried by the caller; flush: reduce them over the workgroup and add them to statistics replica `replica`.
+template <int BC, int BP, int WC, int WP>
+static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BC / WC / 32][BP / WP / 32],
+                                                     unsigned char* smem, int m0, int c0, float (&s)[8], float (&q)[8],
+                                                     bool flush, int replica) {
+    constexpr int NW = WC * WP, NT = 64 * NW;
+    constexpr int FI = BC / WC / 32, FJ = BP / WP / 32;
+    constexpr int CSTR = BC * 2 + 16;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WC, wp = wave / WC;
+    const int lrow = lane & 31, lk = lane >> 5;
+    // ---- epilogue: accumulators -> bf16 C tile [pixel][cout] in LDS
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            int px = wp * (BP / WP) + j * 32 + lrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int co = wc * (BC / WC) + i * 32 + 8 * g + 4 * lk;
+                uint2 pk;
+                pk.x = pack2bf(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]);
+                pk.y = pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                *(uint2*)(smem + px * CSTR + co * 2) = pk;
+            }
+        }
+    __syncthreads();
+    constexpr int VPR = BC / 8;              // 16-byte vectors per C row
+    constexpr int RPP = NT / VPR;            // rows per pass
+    const int cv = t % VPR, rr = t / VPR;
+    const int co = c0 + cv * 8;
+    const bool cok = co < a.Cout;
+    float bmean[8], bistd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bmean[e] = 0.f; bistd[e] = 0.f; }
+    if (a.bn_x && cok) {
+        const float* mi = a.bn_mi + (size_t)(m0 / a.rows_per_group) * 2 * a.Cout;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bmean[e] = mi[co + e]; bistd[e] = mi[a.Cout + co + e]; }
+    }
+    if (a.ev_rm && cok) {       // reuse the two register arrays: bistd = scale, bmean = shift
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float sc = a.ev_gamma[co + e] / sqrtf(a.ev_rv[co + e] + a.ev_eps);
+            bistd[e] = sc;
+            bmean[e] = a.ev_beta[co + e] - a.ev_rm[co + e] * sc;
+        }
+    }
+#pragma unroll 2
+    for (int p = 0; p < BP / RPP; ++p) {
+        int row = rr + p * RPP;
+        int m = m0 + row;
+        if (m < a.M && cok) {
+            u16x8 val = *(const u16x8*)(smem + row * CSTR + cv * 16);
+            if (a.ev_rm) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bf2f(val[e]) * bistd[e] + bmean[e];
+                if (a.res) {
+                    u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += bf2f(rv[e]);
+                }
+                if (a.ev_relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    unsigned pk = pack2bf(f[e], f[e + 1]);
+                    val[e] = (bf16_t)(pk & 0xffffu);
+                    val[e + 1] = (bf16_t)(pk >> 16);
+                }
+            } else if (a.res) {
+                u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
+                if (a.res_mask) {       // residual = upstream gradient gated by the ReLU of the layer it passed through
+                    const unsigned mb = a.res_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] = ((mb >> e) & 1u) ? rv[e] : (bf16_t)0;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    unsigned pk = pack2bf(bf2f(val[e]) + bf2f(rv[e]), bf2f(val[e + 1]) + bf2f(rv[e + 1]));
+                    val[e] = (bf16_t)(pk & 0xffffu);
+                    val[e + 1] = (bf16_t)(pk >> 16);
+                }
+            }
+            if (a.bn_x) {
+                u16x8 xv = *(const u16x8*)(a.bn_x + (size_t)m * a.bn_ldx + co);
+                float gf[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gf[e] = bf2f(val[e]);
+                if (a.bn_relu) {
+                    if (a.bn_mask) {
+                        const unsigned mb = a.bn_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gf[e] = ((mb >> e) & 1u) ? gf[e] : 0.f;
+                    } else {
+                        u16x8 yv = *(const u16x8*)(a.bn_y + (size_t)m * a.bn_ldy + co);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gf[e] = (bf2f(yv[e]) > 0.f) ? gf[e] : 0.f;
+                    }
+                }
+                if (a.bn_nscale) {
+                    const float* ns = a.bn_nscale + (size_t)(m / a.bn_rpi) * a.Cout + co;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += gf[e]; q[e] += gf[e] * ((bf2f(xv[e]) - bmean[e]) * bistd[e]); }
+            } else if (a.stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float f = bf2f(val[e]); s[e] += f; q[e] += f * f; }
+            }
+            *(u16x8*)(a.y + (size_t)m * a.ldy + co) = val;
+        }
+    }
+    if (a.stats && flush) {
+        // lanes with equal cv inside a wave: strides VPR, 2*VPR, ... < 64
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (VPR <= 8) { s[e] = xor_add<8>(s[e]); q[e] = xor_add<8>(q[e]); }
+            if constexpr (VPR <= 16) { s[e] = xor_add<16>(s[e]); q[e] = xor_add<16>(q[e]); }
+            if constexpr (VPR <= 32) { s[e] = xor_add<32>(s[e]); q[e] = xor_add<32>(q[e]); }
+        }
+        float* red = (float*)(smem + BP * CSTR);     // [NW waves][2][BC]
+        if (lane < VPR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 2 + 0) * BC + cv * 8 + e] = s[e];
+                red[(wave * 2 + 1) * BC + cv * 8 + e] = q[e];
+            }
+        }
+        __syncthreads();
+        if (t < 2 * BC) {
+            int which = t / BC, c = t % BC;
+            float tot = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) tot += red[(wv * 2 + which) * BC + c];
+            if (c0 + c < a.Cout)
+                atomicAdd(&a.stats[(((size_t)(m0 / a.rows_per_group) * NREP + replica) * 2 + which) * a.Cout + c0 + c], tot);
+        }
+    }
+}
+
 template <int BC, int BP, int STAGES = 3, int WC = 2, int WP = 2, bool PIPE = false>
 __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only
-    constexpr int NW = WC * WP, NT = 64 * NW;            // waves / threads per workgroup
+    constexpr int NW = WC * WP;                         // waves per workgroup
     constexpr int FI = BC / WC / 32, FJ = BP / WP / 32;  // 32x32 accumulators per wave
     constexpr int WL = BC / (NW * 8), XL = BP / (NW * 8);   // LDS-DMA instructions per wave per tile (1 KiB each)
     constexpr int LD = WL + XL;
@@ -297,138 +446,10 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
     __syncthreads();
     if (a.dbg) tq2 = __builtin_readcyclecounter();
 
-    // ---- epilogue: accumulators -> bf16 C tile [pixel][cout] in LDS
+    float s[8], q[8];
 #pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-            int px = wp * (BP / WP) + j * 32 + lrow;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int co = wc * (BC / WC) + i * 32 + 8 * g + 4 * lk;
-                uint2 pk;
-                pk.x = pack2bf(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1]);
-                pk.y = pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                *(uint2*)(smem + px * CSTR + co * 2) = pk;
-            }
-        }
-    __syncthreads();
-    constexpr int VPR = BC / 8;              // 16-byte vectors per C row
-    constexpr int RPP = NT / VPR;            // rows per pass
-    const int cv = t % VPR, rr = t / VPR;
-    const int co = c0 + cv * 8;
-    const bool cok = co < a.Cout;
-    float s[8], q[8], bmean[8], bistd[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; bmean[e] = 0.f; bistd[e] = 0.f; }
-    if (a.bn_x && cok) {
-        const float* mi = a.bn_mi + (size_t)(m0 / a.rows_per_group) * 2 * a.Cout;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { bmean[e] = mi[co + e]; bistd[e] = mi[a.Cout + co + e]; }
-    }
-    if (a.ev_rm && cok) {       // reuse the two register arrays: bistd = scale, bmean = shift
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float sc = a.ev_gamma[co + e] / sqrtf(a.ev_rv[co + e] + a.ev_eps);
-            bistd[e] = sc;
-            bmean[e] = a.ev_beta[co + e] - a.ev_rm[co + e] * sc;
-        }
-    }
-#pragma unroll 2
-    for (int p = 0; p < BP / RPP; ++p) {
-        int row = rr + p * RPP;
-        int m = m0 + row;
-        if (m < a.M && cok) {
-            u16x8 val = *(const u16x8*)(smem + row * CSTR + cv * 16);
-            if (a.ev_rm) {
-                float f[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = bf2f(val[e]) * bistd[e] + bmean[e];
-                if (a.res) {
-                    u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += bf2f(rv[e]);
-                }
-                if (a.ev_relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    unsigned pk = pack2bf(f[e], f[e + 1]);
-                    val[e] = (bf16_t)(pk & 0xffffu);
-                    val[e + 1] = (bf16_t)(pk >> 16);
-                }
-            } else if (a.res) {
-                u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
-                if (a.res_mask) {       // residual = upstream gradient gated by the ReLU of the layer it passed through
-                    const unsigned mb = a.res_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rv[e] = ((mb >> e) & 1u) ? rv[e] : (bf16_t)0;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    unsigned pk = pack2bf(bf2f(val[e]) + bf2f(rv[e]), bf2f(val[e + 1]) + bf2f(rv[e + 1]));
-                    val[e] = (bf16_t)(pk & 0xffffu);
-                    val[e + 1] = (bf16_t)(pk >> 16);
-                }
-            }
-            if (a.bn_x) {
-                u16x8 xv = *(const u16x8*)(a.bn_x + (size_t)m * a.bn_ldx + co);
-                float gf[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gf[e] = bf2f(val[e]);
-                if (a.bn_relu) {
-                    if (a.bn_mask) {
-                        const unsigned mb = a.bn_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) gf[e] = ((mb >> e) & 1u) ? gf[e] : 0.f;
-                    } else {
-                        u16x8 yv = *(const u16x8*)(a.bn_y + (size_t)m * a.bn_ldy + co);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) gf[e] = (bf2f(yv[e]) > 0.f) ? gf[e] : 0.f;
-                    }
-                }
-                if (a.bn_nscale) {
-                    const float* ns = a.bn_nscale + (size_t)(m / a.bn_rpi) * a.Cout + co;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { s[e] += gf[e]; q[e] += gf[e] * ((bf2f(xv[e]) - bmean[e]) * bistd[e]); }
-            } else if (a.stats) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { float f = bf2f(val[e]); s[e] += f; q[e] += f * f; }
-            }
-            *(u16x8*)(a.y + (size_t)m * a.ldy + co) = val;
-        }
-    }
-    if (a.stats) {
-        // lanes with equal cv inside a wave: strides VPR, 2*VPR, ... < 64
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if constexpr (VPR <= 8) { s[e] = xor_add<8>(s[e]); q[e] = xor_add<8>(q[e]); }
-            if constexpr (VPR <= 16) { s[e] = xor_add<16>(s[e]); q[e] = xor_add<16>(q[e]); }
-            if constexpr (VPR <= 32) { s[e] = xor_add<32>(s[e]); q[e] = xor_add<32>(q[e]); }
-        }
-        float* red = (float*)(smem + BP * CSTR);     // [NW waves][2][BC]
-        if (lane < VPR) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                red[(wave * 2 + 0) * BC + cv * 8 + e] = s[e];
-                red[(wave * 2 + 1) * BC + cv * 8 + e] = q[e];
-            }
-        }
-        __syncthreads();
-        if (t < 2 * BC) {
-            int which = t / BC, c = t % BC;
-            float tot = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < NW; ++wv) tot += red[(wv * 2 + which) * BC + c];
-            if (c0 + c < a.Cout)
-                atomicAdd(&a.stats[(((size_t)(m0 / a.rows_per_group) * NREP + (blockIdx.x & (NREP - 1))) * 2 + which) * a.Cout + c0 + c], tot);
-        }
-    }
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    conv_epilogue<BC, BP, WC, WP>(a, acc, smem, m0, c0, s, q, true, blockIdx.x & (NREP - 1));
     if (a.dbg && t == 0) {
         unsigned long long tq3 = __builtin_readcyclecounter();
         a.dbg[blockIdx.x * 4 + 0] = tq0; a.dbg[blockIdx.x * 4 + 1] = tq1;

@@ -608,3 +608,88 @@ def test_factored_ppm_maps_equal_the_one_pass_maps_per_op():
         ref = torch.einsum('pj,npc->njc', V.cpu(), dc.float().cpu().view(N, h * w, C)).reshape(N * 9 * s * s, C)
         assert ((dz2.float().cpu() - ref).norm() / ref.norm()).item() < 4e-3, s
         assert ((dz2.float() - dz1.float()).norm() / dz1.float().norm()).item() < 5e-3, s
+
+
+# ---------------------------------------------------------------- the 1x1 layers of layer1 / layer2 at full size
+# thousands of tiles per launch, several statistics groups per workgroup wave: every fused epilogue is checked at such a
+# size against torch on the same bf16 operands.
+STREAM = [  # N, H, W, Cin, Cout
+    (4, 128, 128, 64, 256),        # layer1 conv3: one K slab, two channel tiles
+    (8, 128, 128, 256, 64),        # layer1 conv1: BC = 64, four K slabs
+    (4, 64, 64, 128, 1024),        # eight channel tiles, two K slabs
+    (6, 128, 128, 64, 128),        # tiles_p = 768: uneven tiles per workgroup
+]
+
+
+@pytest.mark.parametrize('N,H,W,Ci,Co', STREAM)
+def test_large_1x1_conv_plain_residual_and_statistics(ops, N, H, W, Ci, Co):
+    g = torch.Generator().manual_seed(Ci + Co)
+    M = N * H * W
+    x = torch.randn(M, Ci, generator=g).to(BF).cuda()
+    w = (torch.randn(Co, 1, Ci, generator=g) * 0.1).to(BF).cuda()
+    res = torch.randn(M, Co, generator=g).to(BF).cuda()
+    ref = x.float() @ w.float().view(Co, Ci).t()
+    y = torch.empty(M, Co, dtype=BF, device='cuda')
+    ops.conv2d(x, w, y, N, H, W, H, W, 1, 1, 1, 0, 1, 0)
+    assert torch.equal(y, ref.to(BF)) or relerr(y.float().cpu(), ref.cpu()) < 4e-3
+    # statistics of the STORED values, per group (2 groups = source / target batch), summed over the replicas
+    groups = 2
+    st = torch.zeros(groups, 8, 2, Co, device='cuda')
+    y2 = torch.empty_like(y)
+    ops.conv2d(x, w, y2, N, H, W, H, W, 1, 1, 1, 0, 1, 0, stats=st, stat_groups=groups)
+    assert torch.equal(y2, y)
+    yg = y.float().view(groups, M // groups, Co)
+    torch.testing.assert_close(st.sum(1)[:, 0].cpu(), yg.sum(1).cpu(), rtol=1e-4, atol=0.5)
+    torch.testing.assert_close(st.sum(1)[:, 1].cpu(), (yg * yg).sum(1).cpu(), rtol=1e-4, atol=0.5)
+    # residual added before the store
+    y3 = torch.empty_like(y)
+    ops.conv2d(x, w, y3, N, H, W, H, W, 1, 1, 1, 0, 1, 0, res, None)
+    assert relerr(y3.float().cpu(), (ref + res.float()).cpu()) < 8e-3      # the conv is rounded to bf16 before the add
+    # strided views on both sides
+    xs = torch.randn(M, Ci + 64, generator=g).to(BF).cuda()
+    ybig = torch.zeros(M, Co + 8, dtype=BF, device='cuda')
+    ops.conv2d(xs[:, 64:], w, ybig[:, :Co], N, H, W, H, W, 1, 1, 1, 0, 1, 0)
+    assert relerr(ybig[:, :Co].float().cpu(), (xs[:, 64:].float() @ w.float().view(Co, Ci).t()).cpu()) < 4e-3
+    assert float(ybig[:, Co:].abs().max()) == 0.0
+
+
+def test_large_1x1_conv_fused_bn_backward_sums_and_masks(ops):
+    """The data-gradient form at layer1 size: residual gated by a sign mask + the consumer BatchNorm's backward sums,
+    against the unfused kernels (rgda_bn_bwd_reduce on the stored gradient)."""
+    g = torch.Generator().manual_seed(77)
+    N, H, W, Cb, Cf, groups = 4, 128, 128, 64, 256, 2          # forward conv Cf -> Cb (1x1); its data gradient Cb -> Cf
+    M = N * H * W
+    dy = torch.randn(M, Cb, generator=g).to(BF).cuda()
+    wt = (torch.randn(Cf, 1, Cb, generator=g) * 0.1).to(BF).cuda()
+    res = torch.randn(M, Cf, generator=g).to(BF).cuda()
+    keep = torch.rand(M, Cf, generator=g) > 0.4
+    rmask = (keep.reshape(M, Cf // 8, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(-1).to(torch.uint8).cuda()
+    cy = torch.randn(M, Cf, generator=g).to(BF).cuda()
+    cx = torch.randn(M, Cf, generator=g).to(BF).cuda()
+    mi = torch.stack([torch.randn(groups, Cf, generator=g) * 0.1, torch.rand(groups, Cf, generator=g) + 0.5], 1).cuda().contiguous()
+    dx = torch.empty(M, Cf, dtype=BF, device='cuda')
+    sums = torch.zeros(groups, 8, 2, Cf, device='cuda')
+    ops.conv2d_bnbwd(dy, wt, dx, N, H, W, H, W, 1, 1, 1, 0, 1, 1, res, sums, groups, cy, cx, mi, True, res_mask=rmask)
+    gated = torch.where(keep.cuda(), res, torch.zeros_like(res))
+    ref = dy.float() @ wt.float().view(Cf, Cb).t() + gated.float()
+    assert relerr(dx.float().cpu(), ref.cpu()) < 8e-3
+    want = torch.zeros(groups, 8, 2, Cf, device='cuda')
+    ops.bn_bwd_reduce(dx, cy, cx, mi, want, M, Cf, True, groups=groups)
+    torch.testing.assert_close(sums.sum(1).cpu(), want.sum(1).cpu(), rtol=2e-4, atol=0.5)
+
+
+def test_large_1x1_conv_inference_batchnorm(ops):
+    """The EMA teacher's unit at layer1 size: conv + eval-mode BN + residual + ReLU in one kernel."""
+    g = torch.Generator().manual_seed(78)
+    N, H, W, Ci, Co = 4, 128, 128, 64, 256
+    M = N * H * W
+    x = torch.randn(M, Ci, generator=g).to(BF).cuda()
+    w = (torch.randn(Co, 1, Ci, generator=g) * 0.1).to(BF).cuda()
+    res = torch.randn(M, Co, generator=g).to(BF).cuda()
+    rm, rv = torch.randn(Co, generator=g).cuda() * 0.1, (torch.rand(Co, generator=g) + 0.5).cuda()
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda() * 0.1
+    y = torch.empty(M, Co, dtype=BF, device='cuda')
+    ops.conv2d_bneval(x, w, y, N, H, W, H, W, 1, 1, 1, 0, 1, rm, rv, gamma, beta, True, res)
+    c = (x.float() @ w.float().view(Co, Ci).t()).to(BF).float()         # the kernel normalises the bf16-rounded conv
+    ref = torch.relu((c - rm) / torch.sqrt(rv + 1e-5) * gamma + beta + res.float())
+    assert relerr(y.float().cpu(), ref.cpu()) < 1e-2

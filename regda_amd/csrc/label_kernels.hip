@@ -342,28 +342,61 @@ __global__ void __launch_bounds__(PX * SL) pearson_sim_kernel(const float* __res
     }
 }
 
+constexpr int REFINE_ROWS = 8;
 template <int C>
 __global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restrict__ sim, const float* __restrict__ p1,
                                                            const float* __restrict__ p2, const float* __restrict__ soft,
                                                            float* __restrict__ out, float* classmax, int h, int w,
                                                            int H, int W, float temp) {
-    const int b = blockIdx.z, Y = blockIdx.y;
+    // a workgroup walks REFINE_ROWS output rows: the per-class maxima leave as one atomic per class and workgroup
+    // (one per row-workgroup was 49 K same-address memory-side atomics, a large part of this kernel's time)
+    const int b = blockIdx.z;
     const int X = blockIdx.x * 256 + threadIdx.x;
     const int hw = h * w;
     const size_t HW = (size_t)H * W;
+    float omax[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) omax[c] = 0.f;
+    // the horizontal half of the bilinear interpolation (bilerp's `top` / `bot`) depends only on the pair of low-res
+    // rows: it is kept across the output rows that share the pair (16 of them at scale 16) -- same operations, 8x
+    // fewer gathers
+    const Lerp lx = lerp_ac(min(X, W - 1), w, W);
+    float top[3][C], bot[3][C];
+    int have_i0 = -1;
+    const int Y0 = blockIdx.y * REFINE_ROWS, Y1 = min(H, (int)(blockIdx.y + 1) * REFINE_ROWS);
+    float sv[C], sn[C];                                              // this row's soft labels, and the next row's in flight
+#pragma unroll
+    for (int c = 0; c < C; ++c) sn[c] = (X < W) ? soft[((size_t)b * C + c) * HW + (size_t)Y0 * W + X] : 0.f;
+  for (int Y = Y0; Y < Y1; ++Y) {
     float o[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = 0.f;
+    for (int c = 0; c < C; ++c) { o[c] = 0.f; sv[c] = sn[c]; }
+    if (X < W && Y + 1 < Y1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) sn[c] = soft[((size_t)b * C + c) * HW + (size_t)(Y + 1) * W + X];
+    }
     if (X < W) {
-        Lerp ly = lerp_ac(Y, h, H), lx = lerp_ac(X, w, W);
+        const Lerp ly = lerp_ac(Y, h, H);
+        if (ly.i0 != have_i0) {
+            have_i0 = ly.i0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const size_t off = ((size_t)b * C + c) * hw;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float* p = (q == 0 ? sim : (q == 1 ? p1 : p2)) + off;
+                    top[q][c] = __fadd_rn(__fmul_rn(lx.l0, p[ly.i0 * w + lx.i0]), __fmul_rn(lx.l1, p[ly.i0 * w + lx.i1]));
+                    bot[q][c] = __fadd_rn(__fmul_rn(lx.l0, p[ly.i1 * w + lx.i0]), __fmul_rn(lx.l1, p[ly.i1 * w + lx.i1]));
+                }
+            }
+        }
         float a[C], z1[C], z2[C];
         float ma = -INFINITY, m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            size_t off = ((size_t)b * C + c) * hw;
-            a[c] = bilerp(sim + off, w, ly, lx);
-            z1[c] = __fdiv_rn(bilerp(p1 + off, w, ly, lx), temp);
-            z2[c] = __fdiv_rn(bilerp(p2 + off, w, ly, lx), temp);
+            a[c] = __fadd_rn(__fmul_rn(ly.l0, top[0][c]), __fmul_rn(ly.l1, bot[0][c]));
+            z1[c] = __fdiv_rn(__fadd_rn(__fmul_rn(ly.l0, top[1][c]), __fmul_rn(ly.l1, bot[1][c])), temp);
+            z2[c] = __fdiv_rn(__fadd_rn(__fmul_rn(ly.l0, top[2][c]), __fmul_rn(ly.l1, bot[2][c])), temp);
             ma = fmaxf(ma, a[c]); m1 = fmaxf(m1, z1[c]); m2 = fmaxf(m2, z2[c]);
         }
         float sa = 0.f, s1 = 0.f, s2 = 0.f;
@@ -383,7 +416,7 @@ __global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restri
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float wgt = a[c] / (pmax + 1e-7f) + z1[c] / (lmax + 1e-7f);
-            float v = wgt * soft[((size_t)b * C + c) * HW + (size_t)Y * W + X];
+            float v = wgt * sv[c];
             o[c] = v;
             tot += v;
         }
@@ -393,11 +426,14 @@ __global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restri
             out[((size_t)b * C + c) * HW + (size_t)Y * W + X] = o[c];
         }
     }
+#pragma unroll
+    for (int c = 0; c < C; ++c) omax[c] = fmaxf(omax[c], o[c]);
+  }
     if (classmax) {
         __shared__ float red[4][C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            float m = wave_max(o[c]);
+            float m = wave_max(omax[c]);
             if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = m;
         }
         __syncthreads();
@@ -451,7 +487,7 @@ extern "C" int rgda_label_refine(const float* feat, const float* protos, const f
         return RGDA_ERR_LAUNCH;
     pearson_sim_kernel<6, PX, SL><<<g1, PX * SL, lds, st>>>(feat, pc, pstd, sim, k, hw);
     RGDA_CHECK_LAUNCH();
-    dim3 g2(cdiv(W, 256), H, b);
+    dim3 g2(cdiv(W, 256), cdiv(H, REFINE_ROWS), b);
     refine_apply_kernel<6><<<g2, 256, 0, st>>>(sim, p1, p2, soft, out, classmax, h, w, H, W, temp);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
@@ -495,6 +531,69 @@ __global__ void __launch_bounds__(256) downscale_label_kernel(const int64_t* __r
         label_ds[cell] = o;
         if (o != ignore_label) atomicAdd(&cnt[(int)o], 1.0f);
     }
+}
+
+// Fast form for scale 16 and C <= 6 (the RegDA configuration: 512 -> 32, six classes + ignore): one workgroup per ROW of
+// low-res cells.  A thread owns two label columns of the 16-row band (16-byte loads, fully coalesced 4 KB rows) and
+// counts its 32 labels in seven 9-bit fields of one 64-bit word; the eight threads of a cell add their words with DPP
+// row shifts (no LDS, no atomics), the first of them picks the class.  (The one-workgroup-per-cell kernel above spends
+// 94 us on 8192 tiny workgroups with LDS atomics and a single-thread tail; this is ~8 us for the same 17 MB.)
+__global__ void __launch_bounds__(256) downscale_label16_kernel(const int64_t* __restrict__ label, int64_t* label_ds,
+                                                                float* cnt, int* flag, int h, int w, int C,
+                                                                int ignore_label, float min_ratio) {
+    const int W = w * 16;
+    const int b = blockIdx.y / h, y = blockIdx.y % h;
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 2;           // first of this thread's two columns
+    unsigned long long packed = 0;
+    int bad = 0;
+    if (col < W) {
+        const int64_t* src = label + ((size_t)b * h * 16 + (size_t)y * 16) * W + col;
+        longlong2 rows[16];                                          // the whole band in flight at once
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rows[r] = *(const longlong2*)(src + (size_t)r * W);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const longlong2 v = rows[r];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                long long l = k ? v.y : v.x;
+                if (l == ignore_label) l = C;
+                if (l < 0 || l > C) bad = 1;
+                else packed += 1ull << (9 * (int)l);
+            }
+        }
+    }
+    if (bad) atomicOr(flag, 2);
+    // sum over the 8 threads (16 columns) of a cell: lanes 8k .. 8k+7 of a wave
+    unsigned lo = (unsigned)packed, hi = (unsigned)(packed >> 32);
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        unsigned long long other = ((unsigned long long)(unsigned)__shfl_xor((int)hi, o, 64) << 32) | (unsigned)__shfl_xor((int)lo, o, 64);
+        packed += other;
+        lo = (unsigned)packed; hi = (unsigned)(packed >> 32);
+    }
+    __shared__ int wg_cnt[8];                                        // cells of this workgroup per class
+    if (threadIdx.x < 8) wg_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if ((threadIdx.x & 7) == 0 && col < W) {
+        const int x = col / 16;
+        // avg_pool2d of the one-hot: count / 256 in fp32; torch.max keeps the first maximum
+        float best = __fdiv_rn((float)(packed & 511u), 256.f);
+        int arg = 0;
+        for (int c = 1; c <= C; ++c) {
+            float r = __fdiv_rn((float)((packed >> (9 * c)) & 511u), 256.f);
+            if (r > best) { best = r; arg = c; }
+        }
+        long long o = arg;
+        if (arg == C) o = ignore_label;
+        if (best < min_ratio) o = ignore_label;
+        label_ds[((size_t)b * h + y) * w + x] = o;
+        if (o != ignore_label) atomicAdd(&wg_cnt[(int)o], 1);
+    }
+    // one global add per class and workgroup (whole numbers: exact in fp32 in any order); per-cell adds on six words
+    // were 8192 serialised memory-side atomics, most of this kernel's time
+    __syncthreads();
+    if (threadIdx.x < C && wg_cnt[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (float)wg_cnt[threadIdx.x]);
 }
 
 // one wavefront per (image, channel) row of hw features; per-class sums, one atomic per class
@@ -550,7 +649,10 @@ extern "C" int rgda_proto_update(const float* feat, const int64_t* label, float*
     float* cnt = sums + (size_t)c * k;
     int* flag = (int*)(cnt + c);
     if (hipMemsetAsync(ws, 0, rgda_proto_update_workspace(c, k), st) != hipSuccess) return RGDA_ERR_LAUNCH;
-    downscale_label_kernel<<<b * h * w, 256, 0, st>>>(label, label_ds, cnt, flag, h, w, scale, c, ignore_label, min_ratio);
+    if (scale == 16 && c <= 6 && !(w & 1))
+        downscale_label16_kernel<<<dim3(cdiv(w * 8, 256), b * h), 256, 0, st>>>(label, label_ds, cnt, flag, h, w, c, ignore_label, min_ratio);
+    else
+        downscale_label_kernel<<<b * h * w, 256, 0, st>>>(label, label_ds, cnt, flag, h, w, scale, c, ignore_label, min_ratio);
     RGDA_CHECK_LAUNCH();
     int rows = b * k;
     proto_accum_kernel<6><<<cdiv(rows, 4), 256, 0, st>>>(feat, label_ds, sums, k, h * w, rows);

@@ -648,11 +648,19 @@ __global__ void __launch_bounds__(256) instnorm_fwd_kernel(const bf16_t* __restr
     const bf16_t* xb = x + (size_t)n * HW * ldx;
     float s[8] = {0}, q[8] = {0};
     if (cok)
-        for (int p = rl; p < HW; p += 32) {
-            float f[8];
-            load8(xb + (size_t)p * ldx + cg, f);
+        for (int pb = rl; pb < HW; pb += 32 * ROW_BATCH) {           // ROW_BATCH loads in flight per thread
+            u16x8 v[ROW_BATCH];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            for (int u = 0; u < ROW_BATCH; ++u)
+                if (pb + u * 32 < HW) v[u] = *(const u16x8*)(xb + (size_t)(pb + u * 32) * ldx + cg);
+#pragma unroll
+            for (int u = 0; u < ROW_BATCH; ++u) {
+                if (pb + u * 32 >= HW) break;
+                float f[8];
+                cvt8(v[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
         }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -696,9 +704,14 @@ __global__ void __launch_bounds__(256) instnorm_fwd_kernel(const bf16_t* __restr
             int ch = threadIdx.x >> 2, part = threadIdx.x & 3;
             if (c0 + ch < C) {
                 float* dst = feat + ((size_t)n * C + c0 + ch) * HW + pb + part * 8;
+                if (pb + part * 8 + 8 <= HW && !(HW & 3)) {          // two 16-byte stores
+                    *(float4*)dst = make_float4(tile[ch][part * 8 + 0], tile[ch][part * 8 + 1], tile[ch][part * 8 + 2], tile[ch][part * 8 + 3]);
+                    *(float4*)(dst + 4) = make_float4(tile[ch][part * 8 + 4], tile[ch][part * 8 + 5], tile[ch][part * 8 + 6], tile[ch][part * 8 + 7]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (pb + part * 8 + e < HW) dst[e] = tile[ch][part * 8 + e];
+                    for (int e = 0; e < 8; ++e)
+                        if (pb + part * 8 + e < HW) dst[e] = tile[ch][part * 8 + e];
+                }
             }
         }
     }
@@ -729,29 +742,48 @@ __global__ void __launch_bounds__(256) instnorm_bwd_kernel(const bf16_t* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mean[e] = mi[((size_t)n * 2) * C + cg + e]; istd[e] = mi[((size_t)n * 2 + 1) * C + cg + e]; }
     }
-    auto gload = [&](int p, float (&g)[8]) {
-        size_t row = (size_t)n * HW + p;
+    // both passes: all loads of a batch of rows (up to four tensors each) are issued before the first use
+    constexpr int IB = 2;
+    auto fetch = [&](int pb, u16x8 (&va)[IB], u16x8 (&vb)[IB], u16x8 (&vc)[IB], u16x8 (&vx)[IB]) {
+#pragma unroll
+        for (int u = 0; u < IB; ++u) {
+            const int p = pb + u * 32;
+            if (p >= HW) break;
+            const size_t row = (size_t)n * HW + p;
+            if (ga) va[u] = *(const u16x8*)(ga + row * ldg + cg);
+            if (gb) vb[u] = *(const u16x8*)(gb + row * ldg + cg);
+            if (gc) vc[u] = *(const u16x8*)(gc + row * ldgc + cg);
+            vx[u] = *(const u16x8*)(x + row * ldx + cg);
+        }
+    };
+    auto gsum = [&](const u16x8& a8, const u16x8& b8, const u16x8& c8, float (&g)[8]) {
+        float t8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = 0.f;
-        float t8[8];
-        if (ga) { load8(ga + row * ldg + cg, t8);
+        if (ga) { cvt8(a8, t8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] += t8[e]; }
-        if (gb) { load8(gb + row * ldg + cg, t8);
+        if (gb) { cvt8(b8, t8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] += t8[e]; }
-        if (gc) { load8(gc + row * ldgc + cg, t8);
+        if (gc) { cvt8(c8, t8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] += t8[e]; }
     };
     float s[8] = {0}, q[8] = {0};
     if (cok)
-        for (int p = rl; p < HW; p += 32) {
-            float g[8], f[8];
-            gload(p, g);
-            load8(x + ((size_t)n * HW + p) * ldx + cg, f);
+        for (int pb = rl; pb < HW; pb += 32 * IB) {
+            u16x8 va[IB], vb[IB], vc[IB], vx[IB];
+            fetch(pb, va, vb, vc, vx);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += g[e]; q[e] += g[e] * ((f[e] - mean[e]) * istd[e]); }
+            for (int u = 0; u < IB; ++u) {
+                if (pb + u * 32 >= HW) break;
+                float g[8], f[8];
+                gsum(va[u], vb[u], vc[u], g);
+                cvt8(vx[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += g[e]; q[e] += g[e] * ((f[e] - mean[e]) * istd[e]); }
+            }
         }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -768,13 +800,20 @@ __global__ void __launch_bounds__(256) instnorm_bwd_kernel(const bf16_t* __restr
         k2[e] = b / (float)HW;
     }
     if (cok)
-        for (int p = rl; p < HW; p += 32) {
-            float g[8], f[8], o[8];
-            gload(p, g);
-            load8(x + ((size_t)n * HW + p) * ldx + cg, f);
+        for (int pb = rl; pb < HW; pb += 32 * IB) {
+            u16x8 va[IB], vb[IB], vc[IB], vx[IB];
+            fetch(pb, va, vb, vc, vx);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = istd[e] * (g[e] - k1[e] - (f[e] - mean[e]) * istd[e] * k2[e]);
-            store8(dx + ((size_t)n * HW + p) * lddx + cg, o);
+            for (int u = 0; u < IB; ++u) {
+                const int p = pb + u * 32;
+                if (p >= HW) break;
+                float g[8], f[8], o[8];
+                gsum(va[u], vb[u], vc[u], g);
+                cvt8(vx[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = istd[e] * (g[e] - k1[e] - (f[e] - mean[e]) * istd[e] * k2[e]);
+                store8(dx + ((size_t)n * HW + p) * lddx + cg, o);
+            }
         }
 }
 

@@ -43,6 +43,7 @@ CASES = [
     (8, 32, 32, 256, 256, 3, 1, 1, 1),
     (1, 4, 4, 512, 512, 3, 1, 1, 1),
     (3, 1, 1, 2048, 512, 1, 1, 0, 1),
+    (4, 32, 32, 1024, 256, 1, 1, 0, 1),    # layer-3 1x1 at a quarter of its size: several K splits
     # tap-fused 3x3 weight-gradient geometries: 64-pixel K tiles of R rows x WT columns
     (2, 64, 64, 128, 256, 3, 1, 1, 1),     # WT=64, R=1
     (1, 8, 128, 256, 128, 3, 1, 1, 1),     # WT=64, two tiles per image row

@@ -141,18 +141,30 @@ __global__ void __launch_bounds__(256) lrh_hist_kernel(const int64_t* __restrict
     int beg = blockIdx.x * chunk, end = min(hw, beg + chunk);
     int bad = 0;
     // the loop bound is wave-uniform so the shuffles/ballots in lrh_add see full waves
-    for (int i0 = beg; i0 < end; i0 += 256) {
-        int i = i0 + threadIdx.x;
-        bool in = i < end;
-        long long l = in ? lab[i] : (long long)ignore_label;
-        long long r = in ? reg[i] : 0;
-        bool rok = (r >= 0) && (r < R);
-        bool lok = (l >= 0) && (l < C);
-        if (in && !rok) bad |= 1;
-        if (in && !lok && l != ignore_label) bad |= 2;
-        bool valid = in && rok && lok;
-        int key = valid ? ((int)r * C + (int)l) : -1;
-        lrh_add(key, valid, lds_hist, lds_bins, gh);
+    constexpr int LB = 4;                                          // 256-pixel slabs whose loads are issued together
+    for (int i0 = beg; i0 < end; i0 += 256 * LB) {
+        long long lv[LB], rv[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int i = i0 + u * 256 + threadIdx.x;
+            const bool in = i < end;
+            lv[u] = in ? lab[i] : (long long)ignore_label;
+            rv[u] = in ? reg[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            if (i0 + u * 256 >= end) break;                         // wave-uniform
+            const int i = i0 + u * 256 + threadIdx.x;
+            const bool in = i < end;
+            const long long l = lv[u], r = rv[u];
+            bool rok = (r >= 0) && (r < R);
+            bool lok = (l >= 0) && (l < C);
+            if (in && !rok) bad |= 1;
+            if (in && !lok && l != ignore_label) bad |= 2;
+            bool valid = in && rok && lok;
+            int key = valid ? ((int)r * C + (int)l) : -1;
+            lrh_add(key, valid, lds_hist, lds_bins, gh);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < lds_bins; i += 256) {
@@ -216,7 +228,10 @@ extern "C" int rgda_lrh(const int64_t* labels, const int64_t* regions, int64_t* 
     if (hipMemsetAsync(hist, 0, hist_bytes, st) != hipSuccess) return RGDA_ERR_LAUNCH;
     if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
     int lds_regions = min(R, (48 * 1024) / (C * 4));
+    // pixels per workgroup: enough workgroups to fill the chip (a 16 K chunk left half of the CUs idle and made every
+    // workgroup a chain of 64 dependent load round trips), few enough that the LDS flush stays small
     int chunk = 16384;
+    while (chunk > 2048 && (long long)cdiv(hw, chunk) * b < 512) chunk >>= 1;
     dim3 g1(cdiv(hw, chunk), b);
     lrh_hist_kernel<<<g1, 256, (size_t)lds_regions * C * 4, st>>>(labels, regions, hist, flag, hw, chunk, C,
                                                                     ignore_label, R, lds_regions);

@@ -44,6 +44,11 @@ CASES = [
     (1, 4, 4, 512, 512, 3, 1, 1, 1),
     (3, 1, 1, 2048, 512, 1, 1, 0, 1),
     (4, 32, 32, 1024, 256, 1, 1, 0, 1),    # layer-3 1x1 at a quarter of its size: several K splits
+    # full-batch 32-wide 3x3 layers (layer3 / layer4 / head geometry at reduced channel counts), dilation 2, odd batch
+    (16, 32, 32, 256, 256, 3, 1, 1, 1),
+    (16, 32, 32, 128, 512, 3, 1, 1, 1),
+    (8, 32, 32, 128, 512, 3, 1, 2, 2),
+    (7, 16, 32, 192, 1024, 3, 1, 1, 1),
     # tap-fused 3x3 weight-gradient geometries: 64-pixel K tiles of R rows x WT columns
     (2, 64, 64, 128, 256, 3, 1, 1, 1),     # WT=64, R=1
     (1, 8, 128, 256, 128, 3, 1, 1, 1),     # WT=64, two tiles per image row

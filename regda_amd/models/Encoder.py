@@ -15,6 +15,7 @@ nn.Parameter objects are zero-copy views with the reference's logical [Cout,Cin,
 bf16 mirror for the forward pass, a transposed bf16 copy for the data-gradient pass and ONE flat fp32
 gradient buffer (what the RCCL all-reduce and the fused SGD kernel work on).
 """
+import contextlib
 import math
 
 import os
@@ -281,6 +282,8 @@ class Deeplabv2(nn.Module):
         # PPM heads: apply the tap-shifted bilinear maps in their separable form (csrc/mix_kernels.hip); False = the
         # one-pass sparse maps (rgda_spatial_mix / rgda_spatial_mix_multi), kept as the cross-check
         self.factored_ppm = True
+        self.parallel_heads = True       # training forward: the second head on its own stream
+        self._head_stream = None
         self._mat_cache = {}
         self._synced_version = -1
         self.sync_weights()
@@ -963,23 +966,36 @@ class Deeplabv2(nn.Module):
         else:
             for s, pooled in zip(POOL_SCALES, pooled_all):
                 ops.spatial_mix(xn, mats[s][0], pooled, N, s * s, HW, 2048)
+        # The two heads are independent: in training the second one runs on its own stream, so that its dozen small
+        # launches (PPM branches, Z convs, mixes) overlap the first head's 280 us convolution instead of queueing
+        # behind it.
+        hs = None
+        if T is not None and self.parallel_heads:
+            if self._head_stream is None:
+                self._head_stream = torch.cuda.Stream(device=dev)
+            hs = self._head_stream
+            caller = torch.cuda.current_stream()
+            hs.wait_event(caller.record_event())
         for hi, head in enumerate(('layer5', 'layer6')):
-            qs = []
-            for i, s in enumerate(POOL_SCALES):
-                q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
-                                        pooled_all[i], N, s, s, True)
-                qs.append(q)
+            with (ops.use_stream(hs) if (hs is not None and hi == 1) else contextlib.nullcontext()):
+                qs = []
+                for i, s in enumerate(POOL_SCALES):
+                    q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
+                                            pooled_all[i], N, s, s, True)
+                    qs.append(q)
+                    if dbg is not None:
+                        dbg[f'{head}.q{i}'] = q.float().reshape(N, s, s, -1).permute(0, 3, 1, 2)
+                hid = self._head_last_fwd(T, head, xn, qs, N, h, w, masks[hi])
                 if dbg is not None:
-                    dbg[f'{head}.q{i}'] = q.float().reshape(N, s, s, -1).permute(0, 3, 1, 2)
-            hid = self._head_last_fwd(T, head, xn, qs, N, h, w, masks[hi])
-            if dbg is not None:
-                dbg[head + '.hidden'] = hid.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
-            cl = C[f'{head}.conv_last.4']
-            lg = torch.empty(N, self.num_classes, h, w, device=dev)
-            ops.classifier_fwd(hid, cl.w.view(cl.co, cl.ci), cl.bias, lg, N, HW, 512, self.num_classes)
-            if T is not None:
-                T[f'{head}.cls'] = (hid, (N, h, w))
-            logits.append(lg)
+                    dbg[head + '.hidden'] = hid.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
+                cl = C[f'{head}.conv_last.4']
+                lg = torch.empty(N, self.num_classes, h, w, device=dev)
+                ops.classifier_fwd(hid, cl.w.view(cl.co, cl.ci), cl.bias, lg, N, HW, 512, self.num_classes)
+                if T is not None:
+                    T[f'{head}.cls'] = (hid, (N, h, w))
+                logits.append(lg)
+        if hs is not None:
+            caller.wait_event(hs.record_event())
         return logits[0], logits[1], feat
 
     # ------------------------------------------------------------------ backward plan

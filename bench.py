@@ -226,8 +226,6 @@ def main():
         for head in ('layer5', 'layer6'):
             model.convs[f'{head}.conv_last.4'].w.mul_(40.0)
     model.sync_weights()
-    if os.environ.get('RGDA_SERIAL_HEADS'):       # A/B switch for the two-stream head forward (development)
-        model.parallel_heads = False
     if world > 1:       # identical initial weights on every rank
         dist.broadcast(model.flat_p, 0)
         dist.broadcast(model.flat_buf, 0)

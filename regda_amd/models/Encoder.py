@@ -283,6 +283,7 @@ class Deeplabv2(nn.Module):
         # one-pass sparse maps (rgda_spatial_mix / rgda_spatial_mix_multi), kept as the cross-check
         self.factored_ppm = True
         self.parallel_heads = True       # training forward: the second head on its own stream
+        self.early_last_flush = True     # layer1's weight gradients start before the stem's backward
         self._head_stream = None
         self._mat_cache = {}
         self._synced_version = -1
@@ -1074,6 +1075,10 @@ class Deeplabv2(nn.Module):
             else:
                 g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm, consumer=below)
             self._progress(T, self._offset_of(p + '.conv1'))
+        # layer1's queued weight gradients go to the second stream NOW, next to the stem's backward (max-pool, BN, its
+        # own weight gradient: ~0.4 ms on this stream) -- flushed after it they were a tail the optimizer waited for
+        if self.early_last_flush:
+            self._flush_wgrads(T)
         idx, (N, H1, W1, H2, W2) = T['pool']
         ga0 = torch.empty(N * H1 * W1, 64, dtype=BF, device=dev)
         ops.maxpool_bwd(g, idx, ga0, N, H1, W1, 64, H2, W2)

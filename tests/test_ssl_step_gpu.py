@@ -96,3 +96,25 @@ def test_online_ema_teacher_and_reference_style_loop():
     assert torch.isfinite(total) and not torch.equal(before, m.flat_p)
     x1b, _, _ = m(g['images_s'])          # weights were re-synced automatically (bf16 mirror / transposed copies)
     assert not torch.equal(x1, x1b)
+
+
+@pytest.mark.parametrize('rt,b,size', [('resnet50', 2, 256), ('resnet101', 3, 384)])
+def test_step_runs_at_other_batch_and_tile_sizes(rt, b, size):
+    """Odd batch sizes and feature maps that are not 32 wide (16x16, 24x24: the generic weight-gradient and tile
+    paths): two full steps with the online teacher, finite losses, valid labels, no LRH range flag."""
+    from regda_amd.models.Encoder import Deeplabv2
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    m = Deeplabv2(dict(backbone=dict(resnet_type=rt, output_stride=16, pretrained=False), multi_layer=True,
+                       cascade=False, use_ppm=True, ppm=dict(num_classes=6, use_aux=False, fc_dim=2048),
+                       inchannels=2048, num_classes=6, is_ins_norm=True))
+    bt = make_batch(b=b, size=size, seed=5)
+    st = SSLStep(m, torch.randn(6, 2048), ema_decay=0.99)
+    p0 = m.flat_p.clone()
+    for _ in range(2):
+        ls, lt, gn = st.step(bt['images_s'], bt['label_s'], bt['images_t'], None, bt['regs_t'], lr=1e-3)
+    torch.cuda.synchronize()
+    assert np.isfinite(ls.item()) and np.isfinite(lt.item()) and np.isfinite(gn.item()) and gn.item() > 0
+    hard = st.last_hard
+    assert hard.shape == (b, size, size) and int(hard.min()) >= -1 and int(hard.max()) < 6
+    assert st.lrh_flag() == 0 and not torch.equal(p0, m.flat_p)

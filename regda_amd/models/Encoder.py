@@ -284,6 +284,7 @@ class Deeplabv2(nn.Module):
         self.factored_ppm = True
         self.parallel_heads = True       # training forward: the second head on its own stream
         self.early_last_flush = True     # layer1's weight gradients start before the stem's backward
+        self.parallel_ds = True          # downsample branches on the head stream
         self._head_stream = None
         self._mat_cache = {}
         self._synced_version = -1
@@ -924,13 +925,28 @@ class Deeplabv2(nn.Module):
             dbg['stem'] = a0.float().reshape(N, H1, W1, -1).permute(0, 3, 1, 2)
             dbg['pool'] = y.float().reshape(N, H2, W2, -1).permute(0, 3, 1, 2)
         h, w = H2, W2
+        # a downsample branch (first block of a layer) only meets the main branch in bn3's residual add: in training it
+        # runs on the head stream next to conv1 .. conv3
+        bs = None
+        if T is not None and self.parallel_heads and self.parallel_ds:
+            if self._head_stream is None:
+                self._head_stream = torch.cuda.Stream(device=dev)
+            bs = self._head_stream
         for p, inpl, planes, stride, dil, ds in self.blocks:
+            idt = y
+            joined = None
+            if ds:
+                if bs is not None:
+                    bs.wait_event(torch.cuda.current_stream().record_event())
+                with (ops.use_stream(bs) if bs is not None else contextlib.nullcontext()):
+                    idt, _, _ = self._cbr_fwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], y, N, h, w,
+                                              False)
+                    if bs is not None:
+                        joined = bs.record_event()
             a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True)
             a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True)
-            idt = y
-            if ds:
-                idt, _, _ = self._cbr_fwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], y, N, h, w,
-                                          False)
+            if joined is not None:
+                torch.cuda.current_stream().wait_event(joined)
             y, _, _ = self._cbr_fwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], a2, N, h2, w2, True, res=idt)
             h, w = h2, w2
             if dbg is not None:

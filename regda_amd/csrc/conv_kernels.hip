@@ -31,6 +31,7 @@ struct ConvArgs {
     int tiles_c, tiles_p;
     int rows_per_group;   // BatchNorm statistics are kept per group of rows (src / tgt batch)
     unsigned long long* dbg;   // optional per-workgroup phase timestamps (tuning builds only)
+    int tpw;                   // conv3x3_c64_kernel: image rows per workgroup
     int skip;                  // tuning only: 1 = no DMA inside the K loop, 2 = no LDS reads / MFMA
     // optional fused BatchNorm-backward reduction of the CONSUMER of this (data-gradient) output: with g = the stored
     // result, g' = g * [bn_y > 0] * nscale, xhat = (bn_x - mean) * invstd, `stats` receives sum(g'), sum(g' * xhat)
@@ -459,6 +460,112 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// layer1's 3x3 convolutions: 64 -> 64 channels, stride 1, on 128-wide maps (forward, data gradient, teacher).
+// With K = 576 and a 64 x 64 tile the implicit-GEMM kernel above spends its time loading operands: 4096 workgroups
+// each pull all 72 KB of weights plus nine shifted copies of their pixels from L2 (600 MB into LDS for 67 MB of
+// activations; tests/dev_conv_skip.py: 40 us with the loads, 27 us without).  Here a persistent workgroup (one per
+// CU) keeps ALL weights in LDS, owns a strip of consecutive image rows and rolls a three-row input window through LDS:
+// per 128-pixel output row it loads ONE new input row (16.6 KB) while the previous row's epilogue runs.
+//   LDS: [9 taps x 64 x 128 B weights][3 row slots x 136 x 128 B][epilogue image]  = 147 KB
+// Requires: Cin = Cout = 64, W = 128, pad = dil = 1, H % a.tpw == 0 (rows per workgroup), whole images per group.
+template <int TW>
+__global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BC = 64, BP = TW, WC = 2, WP = 4, NW = 8;
+    constexpr int HP = TW + 2;                             // halo pixels of one input row
+    constexpr int RI = (HP + 7) / 8;                       // DMA instructions per input row (8 pixels each): 17
+    constexpr int SLOT = RI * 1024;                        // bytes of one row slot
+    constexpr int WBYTES = 9 * BC * 128;
+    constexpr int CSTR = BC * 2 + 16;
+    constexpr int EPI = BP * CSTR + NW * BC * 2 * 4;
+    constexpr int SC = BP / (64 * NW / (BC / 8));          // epilogue stores per thread and tile
+    __shared__ __attribute__((aligned(256))) unsigned char smem[WBYTES + 3 * SLOT + EPI];
+    unsigned char* sw = smem;
+    unsigned char* sr = smem + WBYTES;
+    unsigned char* se = sr + 3 * SLOT;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WC, wp = wave / WC;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int lrow8 = lane >> 3, lslot = lane & 7;
+    const int rpw = a.tpw;                                  // image rows per workgroup
+    const int strip = blockIdx.x;                           // strips never straddle an image: H % rpw == 0
+    const int row0 = strip * rpw;                           // global row index n * H + y
+    const int n = row0 / a.H, y0 = row0 % a.H;
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 64 * 9 * 64 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2), 0x00020000);
+    // weights: LDS row j*8 + lrow8 = (tap, co); memory row (co, tap) is 128 contiguous bytes
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int r = (j * NW + wave) * 8 + lrow8;          // 0 .. 575
+        const int tap = r / BC, co = r % BC;
+        const int vo = (co * 9 + tap) * 128 + (lslot ^ ((r >> 1) & 7)) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sw + (j * NW + wave) * 1024), 16, vo, 0, 0, 0);
+    }
+    // one input row -> slot: halo pixel hp = column hp - 1
+    int rvo[(RI + NW - 1) / NW];
+#pragma unroll
+    for (int i = 0; i < (RI + NW - 1) / NW; ++i) {
+        const int q = i * NW + wave;                        // instruction index inside the row
+        const int hp = q * 8 + lrow8, ix = hp - 1;
+        rvo[i] = (q < RI && hp < HP && ix >= 0 && ix < a.W) ? (ix * a.ldx * 2 + (lslot ^ ((hp >> 1) & 7)) * 16) : OOB;
+    }
+    auto issue_row = [&](int y) {                           // image row y (may be outside: zeros) -> slot (y + 1) % 3
+        const bool inside = y >= 0 && y < a.H;
+        const int so = inside ? ((n * a.H + y) * a.W) * a.ldx * 2 : 0;
+        unsigned char* rb = sr + ((y + 1) % 3) * SLOT;
+#pragma unroll
+        for (int i = 0; i < (RI + NW - 1) / NW; ++i) {
+            const int q = i * NW + wave;
+            if (q < RI)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(rb + q * 1024), 16, inside ? rvo[i] : OOB, so, 0, 0);
+        }
+    };
+    issue_row(y0 - 1);
+    issue_row(y0);
+    issue_row(y0 + 1);
+    float s[8], q8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q8[e] = 0.f; }
+    bool after_epilogue = false;
+    for (int ty = 0; ty < rpw; ++ty) {
+        const int y = y0 + ty;
+        // the newest row of this tile's window was issued before the previous tile's epilogue: every operation of
+        // that epilogue is younger, and it issues at least SC stores per thread (vmcnt retires in order)
+        if (after_epilogue) WAIT_VMCNT(SC); else WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+        const int px = wp * 32 + lrow;
+        const int ra = wc * 32 + lrow;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const int dy = (a.mode == 0) ? kh - 1 : 1 - kh, dx = (a.mode == 0) ? kw : 2 - kw;
+            const unsigned char* rb = sr + ((y + dy + 1) % 3) * SLOT;
+            const int hp = px + dx;
+            const unsigned char* wb = sw + tap * (BC * 128);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 fa = *(const bf16x8*)(wb + ra * 128 + (((kk * 2 + lk) ^ ((ra >> 1) & 7)) << 4));
+                const bf16x8 fb = *(const bf16x8*)(rb + hp * 128 + (((kk * 2 + lk) ^ ((hp >> 1) & 7)) << 4));
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[0][0], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                       // every wave is done with row y - 1: its slot takes row y + 2
+        if (ty + 1 < rpw) issue_row(y + 2);
+        const int m0 = (row0 + ty) * BP;
+        conv_epilogue<BC, BP, WC, WP>(a, acc, se, m0, 0, s, q8, ty + 1 == rpw, blockIdx.x & (NREP - 1));
+        after_epilogue = true;
+    }
+#endif
+}
+
 // tile choice (measured on MI355X, tests/dev_conv_bench.py): the L2 -> LDS path sustains <= ~80 GB/s per CU, so the
 // long-K head convolutions want the largest tile that still gives every CU a workgroup (128 x 256, 85 FLOP per
 // byte, 8 waves); large-M layers run 128 x 128 tiles with 8 waves and a 2-stage ring (64 KiB: two workgroups =
@@ -535,6 +642,24 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
     a.dbg = nullptr; a.skip = 0;
     if (const char* e = TUNE_ENV("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
     if (const char* e = TUNE_ENV("RGDA_CONV_SKIP")) a.skip = atoi(e);                                      // tuning only
+    // layer1's 64 -> 64 3x3 on 128-wide maps: weights-resident rolling-window kernel, one workgroup per CU
+    {
+        int c64_on = 1;
+        if (const char* e = TUNE_ENV("RGDA_C64")) c64_on = atoi(e);                         // tuning experiments only
+        if (c64_on && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && Cin == 64 && Cout == 64 && W == 128 &&
+            Wo == W && Ho == H && !(a.rows_per_group % (H * W))) {
+            int rpw = (int)((long long)N * H / 256);
+            while (rpw > 1 && (H % rpw)) --rpw;
+            if (rpw >= 2) {
+                a.tpw = rpw;
+                a.tiles_c = 1;
+                a.tiles_p = N * H;
+                conv3x3_c64_kernel<128><<<N * H / rpw, 512, 0, st>>>(a);
+                RGDA_CHECK_LAUNCH();
+                return RGDA_OK;
+            }
+        }
+    }
     int bc, bp, stages;
     if (pick_tile(M, Cout, (long long)kh * kw * Cin, (stats && stat_groups > 1) ? a.rows_per_group : 0, bc, bp, stages))
         return RGDA_ERR_UNSUPPORTED;

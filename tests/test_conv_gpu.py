@@ -49,6 +49,9 @@ CASES = [
     (16, 32, 32, 128, 512, 3, 1, 1, 1),
     (8, 32, 32, 128, 512, 3, 1, 2, 2),
     (7, 16, 32, 192, 1024, 3, 1, 1, 1),
+    # layer1 geometry (64 -> 64 on 128-wide maps): the weights-resident rolling-window kernel, 2 and 5 rows per workgroup
+    (4, 128, 128, 64, 64, 3, 1, 1, 1),
+    (10, 128, 128, 64, 64, 3, 1, 1, 1),
     # tap-fused 3x3 weight-gradient geometries: 64-pixel K tiles of R rows x WT columns
     (2, 64, 64, 128, 256, 3, 1, 1, 1),     # WT=64, R=1
     (1, 8, 128, 256, 128, 3, 1, 1, 1),     # WT=64, two tiles per image row

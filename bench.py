@@ -70,6 +70,8 @@ def conv_flops_probe(step_fn, park_ms=150.0):
         st3 = stg % 80 if stg >= 80 else stg
         piped = 'true' if (st3 == 3 and bc == 128 and bp in (64, 128, 256) and (stg >= 80 or bp == 64)) else 'false'
         name = 'conv_igemm_kernel<%d, %d, %d, %s, %s>' % (bc, bp, st3, '2, 4' if stg >= 80 else '2, 2', piped)
+        if kh == 3 and kw == 3 and stride == 1 and dil == 1 and co == 64 and ci == 64 and Wo == 128 and N * Ho >= 512:
+            name = 'conv3x3_c64_kernel<128>'        # layer1's 3x3: the weights-resident rolling-window kernel
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()

@@ -534,8 +534,8 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
     bool after_epilogue = false;
     for (int ty = 0; ty < rpw; ++ty) {
         const int y = y0 + ty;
-        // the newest row of this tile's window was issued before the previous tile's epilogue: every operation of
-        // that epilogue is younger, and it issues at least SC stores per thread (vmcnt retires in order)
+        // the newest row of this tile's window was issued in the middle of the previous tile: every operation of that
+        // tile's epilogue is younger, and it issues at least SC stores per thread (vmcnt retires in order)
         if (after_epilogue) WAIT_VMCNT(SC); else WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();
         f32x16 acc[1][1];
@@ -543,22 +543,28 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
         const int px = wp * 32 + lrow;
         const int ra = wc * 32 + lrow;
+        // window rows oldest first: once the three taps that read row y - 1 are done (every wave: one barrier), that
+        // row's slot takes row y + 2, whose load then has the other six taps and the epilogue to land
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap % 3;
-            const int dy = (a.mode == 0) ? kh - 1 : 1 - kh, dx = (a.mode == 0) ? kw : 2 - kw;
-            const unsigned char* rb = sr + ((y + dy + 1) % 3) * SLOT;
-            const int hp = px + dx;
-            const unsigned char* wb = sw + tap * (BC * 128);
+        for (int wr = 0; wr < 3; ++wr) {
+            const unsigned char* rb = sr + ((y + wr) % 3) * SLOT;         // slot of image row y - 1 + wr
+            const int kh = (a.mode == 0) ? wr : 2 - wr;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 fa = *(const bf16x8*)(wb + ra * 128 + (((kk * 2 + lk) ^ ((ra >> 1) & 7)) << 4));
-                const bf16x8 fb = *(const bf16x8*)(rb + hp * 128 + (((kk * 2 + lk) ^ ((hp >> 1) & 7)) << 4));
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[0][0], 0, 0, 0);
+            for (int kw = 0; kw < 3; ++kw) {
+                const int hp = px + ((a.mode == 0) ? kw : 2 - kw);
+                const unsigned char* wb = sw + (kh * 3 + kw) * (BC * 128);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bf16x8 fa = *(const bf16x8*)(wb + ra * 128 + (((kk * 2 + lk) ^ ((ra >> 1) & 7)) << 4));
+                    const bf16x8 fb = *(const bf16x8*)(rb + hp * 128 + (((kk * 2 + lk) ^ ((hp >> 1) & 7)) << 4));
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[0][0], 0, 0, 0);
+                }
+            }
+            if (wr == 0) {
+                __builtin_amdgcn_s_barrier();
+                if (ty + 1 < rpw) issue_row(y + 2);
             }
         }
-        __builtin_amdgcn_s_barrier();                       // every wave is done with row y - 1: its slot takes row y + 2
-        if (ty + 1 < rpw) issue_row(y + 2);
         const int m0 = (row0 + ty) * BP;
         conv_epilogue<BC, BP, WC, WP>(a, acc, se, m0, 0, s, q8, ty + 1 == rpw, blockIdx.x & (NREP - 1));
         after_epilogue = true;

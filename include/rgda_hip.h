@@ -262,12 +262,15 @@ int rgda_spatial_mix_multi(int nsrc, const void* const* ins, const int* ldins, c
                            const int* Js, void* out, int ldout, int N, int I, int C, rgda_stream_t stream);
 
 /* 1x1 classifier with bias (regda/models/Encoder.py:40): hidden [M][ldh] bf16 ->
- * logits NCHW f32 (N,ncls,HW); backward gives dhidden (bf16), dW f32[ncls][C] +=, db += */
+ * logits NCHW f32 (N,ncls,HW); backward gives dhidden (bf16), dW f32[ncls][C] +=, db +=.
+ * ws (optional, rgda_classifier_bwd_workspace bytes): per-workgroup partial sums + a deterministic reduction instead of
+ * atomics (NULL: atomics). */
 int rgda_classifier_fwd(const void* hidden, int ldh, const float* w, const float* bias,
                         float* logits, int N, int HW, int C, int ncls, rgda_stream_t stream);
+size_t rgda_classifier_bwd_workspace(int64_t M, int C, int ncls);
 int rgda_classifier_bwd(const void* hidden, int ldh, const float* w, const float* glogits,
                         void* dhidden, int lddh, float* dw, float* db, int N, int HW, int C,
-                        int ncls, rgda_stream_t stream);
+                        int ncls, void* ws, size_t ws_bytes, rgda_stream_t stream);
 
 /* ------------------------------------------------------------- optimizer   */
 

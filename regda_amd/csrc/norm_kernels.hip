@@ -1091,7 +1091,7 @@ template <int NC>
 __global__ void __launch_bounds__(256) classifier_bwd_kernel(const bf16_t* __restrict__ hid, int ldh,
                                                              const float* __restrict__ w, const float* __restrict__ gl,
                                                              bf16_t* __restrict__ dhid, int lddh, float* dw, float* db,
-                                                             int N, int HW, int C, int rows_per_block) {
+                                                             int N, int HW, int C, int rows_per_block, float* part) {
     // block: channel vectors x row lanes, like the BN passes
     extern __shared__ float lds[];       // [rpb][vpb*8][NC]
     const int vpr = C / 8;
@@ -1154,13 +1154,63 @@ __global__ void __launch_bounds__(256) classifier_bwd_kernel(const bf16_t* __res
             for (int e = 0; e < 8; ++e) {
                 float a = 0.f;
                 for (int r = 0; r < rpb; ++r) a += lds[((r * vpb + cvl) * 8 + e) * NC + c];
-                atomicAdd(dw + c * C + cg + e, a);
+                if (part) part[(size_t)blockIdx.x * (NC * C + 64) + c * C + cg + e] = a;   // per-workgroup partial, no atomics
+                else atomicAdd(dw + c * C + cg + e, a);
             }
     }
     if (blockIdx.y == 0 && cvl == 0) {
         // every row lane of channel-vector 0 saw a disjoint set of rows
+        if (!part) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) atomicAdd(db + c, dbacc[c]);
+            for (int c = 0; c < NC; ++c) atomicAdd(db + c, dbacc[c]);
+        }
+    }
+    if (part && blockIdx.y == 0) {
+        __shared__ float dbl2[64][NC];
+        if (cvl == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dbl2[rl][c] = dbacc[c];
+        }
+        __syncthreads();
+        if (threadIdx.x < NC) {
+            float a = 0.f;
+            for (int r = 0; r < rpb; ++r) a += dbl2[r][threadIdx.x];
+            part[(size_t)blockIdx.x * (NC * C + 64) + NC * C + threadIdx.x] = a;
+        }
+    }
+}
+
+// dW[c][k] += sum over the workgroups' partials (rows of NC*C + 64 floats: dW then db).  Workgroup = 32 outputs x
+// 8 slices of the partial rows (eight loads in flight per thread), slices summed through LDS in a fixed order.
+template <int NC>
+__global__ void __launch_bounds__(256) classifier_bwd_reduce_kernel(const float* __restrict__ part, int blocks, float* dw,
+                                                                    float* db, int C) {
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    const int stride = NC * C + 64;
+    const bool ok = i < NC * C + NC;
+    float a = 0.f;
+    if (ok) {
+        const int per = (blocks + 7) / 8;
+        const int b0 = sl * per, b1 = min(blocks, b0 + per);
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; b < b1; ++b) a += part[(size_t)b * stride + i];
+    }
+    red[sl][o] = a;
+    __syncthreads();
+    if (sl == 0 && ok) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][o];
+        if (i < NC * C) dw[i] += t; else db[i - NC * C] += t;
     }
 }
 
@@ -1174,23 +1224,41 @@ extern "C" int rgda_classifier_fwd(const void* hidden, int ldh, const float* w, 
     return RGDA_OK;
 }
 
+extern "C" size_t rgda_classifier_bwd_workspace(int64_t M, int C, int ncls) {
+    return (size_t)cdiv(M, 64) * ((size_t)ncls * C + 64) * 4;
+}
+
 extern "C" int rgda_classifier_bwd(const void* hidden, int ldh, const float* w, const float* glogits, void* dhidden,
-                                   int lddh, float* dw, float* db, int N, int HW, int C, int ncls,
-                                   rgda_stream_t stream) {
+                                   int lddh, float* dw, float* db, int N, int HW, int C, int ncls, void* ws,
+                                   size_t ws_bytes, rgda_stream_t stream) {
     if (!hidden || !w || !glogits || !dhidden || !dw || !db || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || (ldh & 7) ||
         (lddh & 7))
         return RGDA_ERR_ARG;
     if (ncls != 6) return RGDA_ERR_UNSUPPORTED;
     long long M = (long long)N * HW;
     RowLayout L = row_layout(C);
-    // every workgroup ends with ncls*C fp32 atomics onto the SAME addresses (cross-XCD same-address atomics are slow):
-    // few, long workgroups
+    hipStream_t st = to_stream(stream);
+    if (ws) {
+        // 64 rows per workgroup (the whole chip), per-workgroup partial dW / db in the workspace, then one small
+        // deterministic reduction: ncls*C atomics per workgroup onto the SAME addresses forced few, long workgroups
+        // (64 of them at M = 16384: a quarter of the CUs, 70 us)
+        if (ws_bytes < rgda_classifier_bwd_workspace(M, C, ncls)) return RGDA_ERR_WORKSPACE;
+        const int blocks = cdiv(M, 64);
+        dim3 grid(blocks, cdiv(L.vpr, L.vpb));
+        classifier_bwd_kernel<6><<<grid, 256, (size_t)256 * 8 * 6 * 4, st>>>(
+            (const bf16_t*)hidden, ldh, w, glogits, (bf16_t*)dhidden, lddh, dw, db, N, HW, C, 64, (float*)ws);
+        RGDA_CHECK_LAUNCH();
+        classifier_bwd_reduce_kernel<6><<<cdiv(6 * C + 6, 32), 256, 0, st>>>((const float*)ws, blocks, dw, db, C);
+        RGDA_CHECK_LAUNCH();
+        return RGDA_OK;
+    }
+    // without a workspace: atomics, few long workgroups
     int rows_per_block = 256;
     if (const char* e = TUNE_ENV("RGDA_CLS_ROWS")) rows_per_block = atoi(e);     // tuning experiments only
     while ((long long)cdiv(M, rows_per_block) * cdiv(L.vpr, L.vpb) > 1024) rows_per_block *= 2;
     dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
-    classifier_bwd_kernel<6><<<grid, 256, (size_t)256 * 8 * 6 * 4, to_stream(stream)>>>(
-        (const bf16_t*)hidden, ldh, w, glogits, (bf16_t*)dhidden, lddh, dw, db, N, HW, C, rows_per_block);
+    classifier_bwd_kernel<6><<<grid, 256, (size_t)256 * 8 * 6 * 4, st>>>(
+        (const bf16_t*)hidden, ldh, w, glogits, (bf16_t*)dhidden, lddh, dw, db, N, HW, C, rows_per_block, nullptr);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -363,8 +363,11 @@ def classifier_fwd(hidden, w, bias, logits, N, HW, C, ncls):
 
 
 def classifier_bwd(hidden, w, glogits, dhidden, dw, db, N, HW, C, ncls):
-    lib().call('rgda_classifier_bwd', hidden.data_ptr(), _ld(hidden), w.data_ptr(), glogits.data_ptr(),
-               dhidden.data_ptr(), _ld(dhidden), dw.data_ptr(), db.data_ptr(), N, HW, C, ncls, _stream())
+    L = lib()
+    ws = _ws(L.size('rgda_classifier_bwd_workspace', N * HW, C, ncls), hidden.device)
+    L.call('rgda_classifier_bwd', hidden.data_ptr(), _ld(hidden), w.data_ptr(), glogits.data_ptr(),
+           dhidden.data_ptr(), _ld(dhidden), dw.data_ptr(), db.data_ptr(), N, HW, C, ncls, ws.data_ptr(), ws.numel(),
+           _stream())
 
 
 def sumsq(g, out, ws):

@@ -19,9 +19,13 @@ _EVAL_AUG = [('Normalize', dict(mean=MEAN, std=STD, max_pixel_value=1)), ('ToTen
 
 SOURCE_DATA_CONFIG = dict(image_dir=source_dir['image_dir'], mask_dir=source_dir['mask_dir'], transforms=_TRAIN_AUG,
                           CV=dict(k=10, i=-1), training=True, batch_size=8, num_workers=4)
+_TARGET_AUG = [('RandomCrop', (512, 512)), ('OneOf', ('HorizontalFlip', 'VerticalFlip', 'RandomRotate90'), 0.75),
+               ('Normalize', dict(mean=MEAN, std=STD, max_pixel_value=1)), ('ToTensor',)]
+TARGET_DATA_CONFIG = dict(image_dir=target_dir['image_dir'], mask_dir=target_dir['mask_dir'], transforms=_TARGET_AUG,
+                          CV=dict(k=10, i=-1), training=True, batch_size=8, num_workers=4)
 PSEUDO_DATA_CONFIG = dict(image_dir=target_dir['image_dir'], mask_dir=target_dir['mask_dir'], transforms=_EVAL_AUG,
-                          CV=dict(k=10, i=-1), training=False, batch_size=1, num_workers=4)
+                          CV=dict(k=10, i=-1), training=False, batch_size=1, num_workers=1)
 EVAL_DATA_CONFIG = dict(image_dir=val_dir['image_dir'], mask_dir=val_dir['mask_dir'], transforms=_EVAL_AUG,
-                        CV=dict(k=10, i=-1), training=False, batch_size=1, num_workers=4)
+                        CV=dict(k=10, i=-1), training=False, batch_size=1, num_workers=1)
 TEST_DATA_CONFIG = dict(image_dir=test_dir['image_dir'], mask_dir=test_dir['mask_dir'], transforms=_EVAL_AUG,
-                        CV=dict(k=10, i=-1), training=False, batch_size=1, num_workers=4)
+                        CV=dict(k=10, i=-1), training=False, batch_size=1, num_workers=1)

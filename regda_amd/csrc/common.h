@@ -36,7 +36,7 @@ static __device__ __forceinline__ float wave_sum(float v) {
 }
 // v + v[lane ^ O] for O = 8 / 16 / 32 without the LDS crossbar: DPP row rotate (rows are 16 lanes) and the gfx950
 // half / row-pair exchanges.  `__shfl_xor` is a ds_bpermute_b32: 32 of them per wave in a conv epilogue, from all eight
-// waves of the workgroup at once, cost ~3000 cycles on the shared LDS pipe (tests/dev_conv_phases2.py).
+// waves of the workgroup at once, cost ~3000 cycles on the shared LDS pipe (scripts/dev/dev_conv_phases2.py).
 template <int O>
 static __device__ __forceinline__ float xor_add(float v) {
     static_assert(O == 8 || O == 16 || O == 32, "xor_add: 8, 16 or 32");
@@ -61,7 +61,7 @@ static __device__ __forceinline__ float wave_max(float v) {
 #define NREP RGDA_STAT_REPLICAS
 
 // Tuning hooks (tile overrides, per-workgroup timestamps, ablation switches) read environment variables.  They exist
-// only in a tuning build (`make TUNING=1`, what tests/dev_*.py expect); the product library never looks at the
+// only in a tuning build (`make TUNING=1`, what scripts/dev/dev_*.py expect); the product library never looks at the
 // environment.
 #include <stdlib.h>
 #ifdef RGDA_TUNING

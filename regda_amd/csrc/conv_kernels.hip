@@ -3,15 +3,16 @@
 //   forward / data-gradient : D[co][pixel] = sum_{tap,ci} W[co][tap][ci] * X[src(pixel,tap)][ci]
 //   weight-gradient         : dW[co][tap][ci] += sum_pixel dY[pixel][co] * X[src(pixel,tap)][ci]
 //
-// v_mfma_f32_32x32x16_bf16, fp32 accumulate.  256-thread workgroups = 2x2 wavefronts, every
-// wavefront owns a (BC/2)x(BP/2) block of 32x32 accumulators.  Operand tiles are staged
-// HBM -> registers -> LDS (issue-early / write-late, double buffered, one barrier per K tile):
-// the gathered, zero-padded pixel rows of an implicit GEMM cannot be expressed as the
-// lane-linear image global_load_lds wants without a second pass.
-//   * forward: both operands are K(channel)-contiguous -> 128-byte LDS rows with a 16-byte-slot
-//     XOR swizzle (slot ^= (row>>1)&7): conflict-free for the 16-lane groups of ds_read_b128.
-//   * wgrad:   both operands are K(pixel)-STRIDED -> rows of pixels with a +64 B pad and
-//     ds_read_b64_tr_b16 transposing reads (4 k-rows x 16 columns per 16-lane group).
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate.  Workgroups of WC x WP wavefronts (4 or 8), every wavefront owns a
+// (BC/WC)x(BP/WP) block of 32x32 accumulators.  Operand tiles (64 channels of one filter tap) go HBM/L2 -> LDS by
+// LDS-DMA (`buffer_load_dwordx4 ... lds`) into a 2- or 3-stage ring, ordered by counted `s_waitcnt vmcnt(N)` and one
+// raw `s_barrier` per K tile; padding / out-of-range rows carry an out-of-range buffer offset and the hardware
+// deposits zeros, so the gathered, zero-padded pixel rows of the implicit GEMM need no second pass.
+//   * forward / data gradient: both operands are K(channel)-contiguous -> 128-byte LDS rows; the 16-byte-slot XOR
+//     swizzle (slot ^= (row>>1)&7) is applied on the SOURCE address (the DMA image is lane-linear) and again on the
+//     read: conflict-free for the 16-lane groups of ds_read_b128.
+//   * weight gradient: both operands are K(pixel)-STRIDED -> rows of pixels as they lie in memory, 64-byte granules
+//     XOR-swizzled with the row index, ds_read_b64_tr_b16 transposing reads (4 k-rows x 16 columns per 16-lane group).
 // Epilogue (forward): accumulators -> bf16 -> LDS -> 16-byte coalesced row stores, with the
 // optional residual add and the per-channel sum / sum-of-squares of BatchNorm folded in.
 #include <stdio.h>
@@ -464,7 +465,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 // layer1's 3x3 convolutions: 64 -> 64 channels, stride 1, on 128-wide maps (forward, data gradient, teacher).
 // With K = 576 and a 64 x 64 tile the implicit-GEMM kernel above spends its time loading operands: 4096 workgroups
 // each pull all 72 KB of weights plus nine shifted copies of their pixels from L2 (600 MB into LDS for 67 MB of
-// activations; tests/dev_conv_skip.py: 40 us with the loads, 27 us without).  Here a persistent workgroup (one per
+// activations; scripts/dev/dev_conv_skip.py: 40 us with the loads, 27 us without).  Here a persistent workgroup (one per
 // CU) keeps ALL weights in LDS, owns a strip of consecutive image rows and rolls a three-row input window through LDS:
 // per 128-pixel output row it loads ONE new input row (16.6 KB) while the previous row's epilogue runs.
 //   LDS: [9 taps x 64 x 128 B weights][3 row slots x 136 x 128 B][epilogue image]  = 147 KB
@@ -572,7 +573,7 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
 #endif
 }
 
-// tile choice (measured on MI355X, tests/dev_conv_bench.py): the L2 -> LDS path sustains <= ~80 GB/s per CU, so the
+// tile choice (measured on MI355X, scripts/dev/dev_conv_bench.py): the L2 -> LDS path sustains <= ~80 GB/s per CU, so the
 // long-K head convolutions want the largest tile that still gives every CU a workgroup (128 x 256, 85 FLOP per
 // byte, 8 waves); large-M layers run 128 x 128 tiles with 8 waves and a 2-stage ring (64 KiB: two workgroups =
 // 16 waves per CU); everything else 128 x 64 tiles with 4 waves, two workgroups per CU.  `stages` 82 / 83 mean

@@ -563,16 +563,23 @@ class Deeplabv2(nn.Module):
         return (self.convs[conv_name].w.data_ptr() - self.flat_p.data_ptr()) // 4
 
     def make_teacher(self):
-        """EMA teacher (regda/utils/ema.py:41-58): its own (shadow) parameters, the STUDENT's BN buffers."""
+        """EMA teacher (regda/utils/ema.py:41-58): its own (shadow) parameters.  ema.py averages parameters only, so
+        the BatchNorm buffers are the student's -- taken as a SNAPSHOT (`adopt_buffers`) at a defined point of the
+        step, never aliased: the teacher's eval forward may run on another stream next to the student's training
+        forward, which rewrites those buffers."""
         t = Deeplabv2(self.config)
         with torch.no_grad():
             t.flat_p.copy_(self.flat_p)                       # ema.register(): shadow = param.clone()
-        for name, b in t.bns.items():
-            src = self.bns[name]
-            b.rm, b.rv, b.nbt = src.rm, src.rv, src.nbt
+        t.adopt_buffers(self)
         t.refresh_from_master()
         t.eval()
         return t
+
+    def adopt_buffers(self, other):
+        """Copy `other`'s BatchNorm running statistics (one flat buffer each) on the current stream."""
+        with torch.no_grad():
+            self.flat_buf.copy_(other.flat_buf)
+            self.flat_nbt.copy_(other.flat_nbt)
 
     def refresh_from_master(self, mirror_is_fresh=False):
         """bf16 mirror + padded stem weights only (a forward-only model needs no transposed copies).
@@ -963,6 +970,8 @@ class Deeplabv2(nn.Module):
             T['inorm'] = (y, imi, (N, h, w))
         if self.head_kind == 'aspp':
             x1, x2 = self._aspp_fwd(T, xn, N, h, w)
+            if T is not None:
+                T['out_shape'] = tuple(x1.shape)
             return x1, x2, feat
         mats = self._mats(h, w)
         if T is not None:
@@ -1013,6 +1022,8 @@ class Deeplabv2(nn.Module):
                 logits.append(lg)
         if hs is not None:
             caller.wait_event(hs.record_event())
+        if T is not None:
+            T['out_shape'] = tuple(logits[0].shape)
         return logits[0], logits[1], feat
 
     # ------------------------------------------------------------------ backward plan
@@ -1146,18 +1157,29 @@ class _StatsPool:
 
 
 class _ModelFn(torch.autograd.Function):
+    """The drop-in nn.Module surface: (x1, x2, feat) = model(x) with all three outputs differentiable, like the
+    reference's (Encoder.py:146-151) -- the stage-2 losses act on `feat`."""
+
     @staticmethod
     def forward(ctx, x, anchor, model):
         T = model.new_tape()
         x1, x2, feat = model._forward_plan(x, T)
         ctx.model, ctx.tape = model, T
-        ctx.mark_non_differentiable(feat)
+        ctx.set_materialize_grads(False)
         return x1, x2, feat
 
     @staticmethod
-    def backward(ctx, g1, g2, _gfeat):
+    def backward(ctx, g1, g2, gfeat):
         model, T = ctx.model, ctx.tape
         model._prepare_grads()
-        model._backward_plan(T, g1, g2)
+        x1shape = T['out_shape']
+        if g1 is None:
+            g1 = torch.zeros(x1shape, device=model.device)
+        if g2 is None:
+            g2 = torch.zeros(x1shape, device=model.device)
+        gf = None
+        if gfeat is not None:       # NCHW fp32 -> pixel-major bf16 rows, the layout the InstanceNorm backward consumes
+            gf = gfeat.permute(0, 2, 3, 1).reshape(-1, gfeat.shape[1]).to(BF).contiguous()
+        model._backward_plan(T, g1.contiguous().float(), g2.contiguous().float(), gfeat=gf)
         T.clear()
         return None, None, None

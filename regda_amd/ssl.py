@@ -45,6 +45,8 @@ class SSLStep:
         self._graph = None
         self.marks = None           # set to [] to collect (name, event) phase marks of the next step (bench --phases)
         self.overlap_comm = overlap_comm
+        self.keep_debug = False     # tests: keep the step's target logits / features / refined soft labels (`self.debug`)
+        self.debug = None
         self.world = self.reducer.world
         self.group = process_group
 
@@ -106,12 +108,18 @@ class SSLStep:
         nb = images_s.shape[0]
         T = m.new_tape(groups=2)
         main = torch.cuda.current_stream()
-        teacher_on_side = soft_t is None and self.wgrad_stream is not None
+        online = soft_t is None
+        teacher_on_side = online and self.wgrad_stream is not None
+        if online:
+            # the teacher sees the BatchNorm running statistics as they stand at the START of the step (a snapshot on
+            # the main stream, before the student's forward rewrites them) -- the same view whether its forward then
+            # runs next to the student's on the second stream or after it
+            self.teacher.adopt_buffers(m)
         if teacher_on_side:
             # the EMA teacher's forward is independent of the student's: it runs on the second stream, next to it
             self.wgrad_stream.wait_stream(main)
             with ops.use_stream(self.wgrad_stream):
-                soft_t = self.teacher_probs(images_t)
+                soft_t = self.teacher_probs(images_t, snapshot=False)
                 self._mark('teacher forward done (side)', self.wgrad_stream)
         x1, x2, feat = m._forward_plan([images_s.contiguous().float(), images_t.contiguous().float()], T)
         self._mark('student forward done')
@@ -119,15 +127,20 @@ class SSLStep:
         feat_s, feat_t = feat[:nb], feat[nb:]
         if teacher_on_side:
             main.wait_stream(self.wgrad_stream)
-        elif soft_t is None:
-            soft_t = self.teacher_probs(images_t)
+        elif online:
+            soft_t = self.teacher_probs(images_t, snapshot=False)
+        self.last_soft_t = soft_t
         self._mark('joined teacher')
         # ---- label path (a5-a8)
         if self.refine_label:
             soft, cm = ops.label_refine(feat_t, self.prototypes, t1, t2, soft_t, self.temp, return_ws=True)
             hard = ops.pseudo_select(soft, self.top, self.low, self.ig, classmax_ws=cm, check=False)
         else:
+            soft = soft_t
             hard = ops.pseudo_select(soft_t, self.top, self.low, self.ig, check=False)
+        if self.keep_debug:
+            self.debug = dict(t1=t1, t2=t2, s1=s1, s2=s2, feat_t=feat_t, feat_s=feat_s, soft_in=soft_t, soft=soft,
+                              hard_selected=hard)
         if self.sam_refine:
             regs = regs_t.squeeze(1) if regs_t.dim() == 4 else regs_t
             self._lrh_flag_off = (regs.shape[0] * self.max_regions * (self.C + 1)) * 4
@@ -183,9 +196,12 @@ class SSLStep:
         self._mark('optimizer + weight mirrors done')
 
     @torch.no_grad()
-    def teacher_probs(self, images_t):
-        """Eval-mode forward of the EMA teacher (Encoder.py:152-155 on the shadow weights)."""
+    def teacher_probs(self, images_t, snapshot=True):
+        """Eval-mode forward of the EMA teacher (Encoder.py:152-155 on the shadow weights; BatchNorm buffers = the
+        student's, copied now unless the caller already took the snapshot)."""
         t = self.teacher
+        if snapshot:
+            t.adopt_buffers(self.model)
         t.refresh_from_master(mirror_is_fresh=True)       # make_teacher() and every sgd_step keep flat_pb current
         t.eval()
         x1, x2, _ = t._forward_plan(images_t.contiguous().float(), None)

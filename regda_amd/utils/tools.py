@@ -12,35 +12,43 @@ from .. import ops
 
 
 def import_config(config_name, prefix='configs', copy=True, create=True, postfix=''):
-    """UPPER_CASE python-module configs addressed by dotted name, e.g. 'st.regda.2potsdam'
-    (tools.py:173-181)."""
-    cfg_path = '{}.{}'.format(prefix, config_name)
-    m = importlib.import_module(name=cfg_path)
-    m.SNAPSHOT_DIR += postfix
+    """Load the UPPER_CASE config module `<prefix>.<config_name>` (e.g. 'st.regda.2potsdam'), append `postfix` to its
+    SNAPSHOT_DIR, optionally create that directory and drop a copy of the module there as config.py
+    (same contract as tools.py:173-181)."""
+    module = importlib.import_module(f'{prefix}.{config_name}')
+    module.SNAPSHOT_DIR = module.SNAPSHOT_DIR + postfix
     if create:
-        os.makedirs(m.SNAPSHOT_DIR, exist_ok=True)
+        os.makedirs(module.SNAPSHOT_DIR, exist_ok=True)
     if copy:
-        src = os.path.abspath(m.__file__)
-        shutil.copy(src, os.path.join(m.SNAPSHOT_DIR, 'config.py'))
-    return m
+        shutil.copy(os.path.abspath(module.__file__), os.path.join(module.SNAPSHOT_DIR, 'config.py'))
+    return module
+
+
+def learning_rate_at(i_iter, base_lr, warmup_iter, max_iter, power):
+    """The one schedule of the st.regda.* runs (tools.py:184-207): linear warm-up from 0 over `warmup_iter`
+    iterations, then polynomial decay base * (1 - it / max_iter) ** power.  Plain Python floats, like the reference."""
+    it = float(i_iter)
+    if i_iter < warmup_iter:
+        return base_lr * (it / warmup_iter)
+    return base_lr * (1 - it / max_iter) ** power
 
 
 def lr_poly(base_lr, i_iter, max_iter, power):
-    return base_lr * ((1 - float(i_iter) / max_iter) ** power)
+    """Decay branch alone (tools.py:184-185)."""
+    return learning_rate_at(i_iter, base_lr, 0, max_iter, power)
 
 
 def lr_warmup(base_lr, i_iter, warmup_iter):
+    """Warm-up branch alone (tools.py:188-189); not clamped past `warmup_iter`, like the reference."""
     return base_lr * (float(i_iter) / warmup_iter)
 
 
 def adjust_learning_rate(optimizer, i_iter, cfg):
-    if i_iter < cfg.PREHEAT_STEPS:
-        lr = lr_warmup(cfg.LEARNING_RATE, i_iter, cfg.PREHEAT_STEPS)
-    else:
-        lr = lr_poly(cfg.LEARNING_RATE, i_iter, cfg.NUM_STEPS, cfg.POWER)
-    optimizer.param_groups[0]['lr'] = lr
-    if len(optimizer.param_groups) > 1:
-        optimizer.param_groups[1]['lr'] = lr * 10
+    """Set the lr of `optimizer` for iteration `i_iter` from cfg.{LEARNING_RATE, PREHEAT_STEPS, NUM_STEPS, POWER};
+    a second parameter group, when present, runs at ten times the rate (tools.py:191-207).  Returns the lr."""
+    lr = learning_rate_at(i_iter, cfg.LEARNING_RATE, cfg.PREHEAT_STEPS, cfg.NUM_STEPS, cfg.POWER)
+    for group, mult in zip(optimizer.param_groups[:2], (1, 10)):
+        group['lr'] = lr * mult
     return lr
 
 

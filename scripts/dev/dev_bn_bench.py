@@ -1,6 +1,6 @@
 """dev: BN apply / backward-apply bandwidth on rotating (cache-cold) buffers."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from regda_amd import ops
 BF = torch.bfloat16

@@ -1,6 +1,6 @@
 """dev: isolated conv timings with (a) BN statistics in the epilogue, (b) rotating buffers (cold L2 / MALL)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from regda_amd import ops
 BF = torch.bfloat16

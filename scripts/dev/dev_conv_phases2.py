@@ -1,6 +1,6 @@
 """Per-workgroup phase timestamps of the HBM-bound small-K convolutions (tuning build only: make TUNING=1)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from regda_amd import ops
 BF = torch.bfloat16

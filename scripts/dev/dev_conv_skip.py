@@ -1,6 +1,6 @@
 """dev: kernel time with the K loop's DMA and/or compute removed (RGDA_CONV_SKIP), no timestamps inside."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from regda_amd import ops
 BF = torch.bfloat16

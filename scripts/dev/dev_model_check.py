@@ -1,6 +1,6 @@
 """Developer script (not a test): prints error metrics of the HIP model vs the CPU oracle on the small case."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from oracle import model as omodel, labelpath as opath

@@ -702,3 +702,120 @@ def test_large_1x1_conv_inference_batchnorm(ops):
     c = (x.float() @ w.float().view(Co, Ci).t()).to(BF).float()         # the kernel normalises the bf16-rounded conv
     ref = torch.relu((c - rm) / torch.sqrt(rv + 1e-5) * gamma + beta + res.float())
     assert relerr(y.float().cpu(), ref.cpu()) < 1e-2
+
+
+# ---------------------------------------------------------------- the production 128 x 256 tile (8 waves, 3-stage ring, pipelined K loop)
+# conv_igemm_kernel<128, 256, 3, 2, 4, true> is selected only for K >= 4096 with >= 240 tiles of 128 x 256: the head's
+# 3x3 2048 -> 512 and layer4's 3x3 512 -> 512 at the full 8 + 8 batch of 32 x 32 maps (forward and data gradient).  Every
+# epilogue the step runs on that tile is checked here at exactly those geometries, against fp32 torch on the same bf16
+# operands (im2col + matmul on the GPU: 16384 x 18432 x 512 is too slow for the CPU suite).
+BIG = [  # N, H, W, Cin, Cout, k, pad, dil          what it is in the step
+    (16, 32, 32, 2048, 512, 3, 1, 1),              # head conv, feature half: forward (+ PPM residual, statistics)
+    (16, 32, 32, 512, 512, 3, 2, 2),               # layer4.{1,2}.conv2: forward, atrous
+    (16, 32, 32, 512, 512, 3, 1, 1),               # layer4.0.conv2
+]
+
+
+def _big_tile_code(M, Cout, k, Cin, rows_per_group=0):
+    from regda_amd._lib import lib
+    code = lib().raw('rgda_conv2d_tile')(M, Cout, k, k, Cin, rows_per_group)
+    return code & 1023, (code >> 10) & 1023, code >> 20
+
+
+def _ref_conv_gpu(x_pxc, w, N, H, W, k, pad, dil):
+    """fp32 reference of a stride-1 'same' conv on pixel-major bf16 operands: unfold + matmul in fp32 on the GPU.
+    x_pxc [N*H*W, Cin] bf16, w [Cout, k*k, Cin] bf16 -> [N*H*W, Cout] f32."""
+    Cin, Cout = x_pxc.shape[1], w.shape[0]
+    x = x_pxc.float().view(N, H, W, Cin).permute(0, 3, 1, 2)
+    cols = F.unfold(x, k, dil, pad, 1)                                   # (N, Cin*k*k, H*W), row = ci*k*k + tap
+    cols = cols.view(N, Cin, k * k, H * W).permute(0, 3, 2, 1).reshape(N * H * W, k * k * Cin)
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        return cols @ w.float().view(Cout, k * k * Cin).t()
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize('N,H,W,Ci,Co,k,pad,dil', BIG)
+def test_big_tile_forward_statistics_residual(ops, N, H, W, Ci, Co, k, pad, dil):
+    M, groups = N * H * W, 2
+    assert _big_tile_code(M, Co, k, Ci, M // groups) == (128, 256, 83), 'the 8-wave 128 x 256 tile must be selected'
+    g = torch.Generator().manual_seed(Ci + dil)
+    x = torch.randn(M, Ci, generator=g).to(BF).cuda()
+    w = (torch.randn(Co, k * k, Ci, generator=g) * (2.0 / (Ci * k * k)) ** 0.5).to(BF).cuda()
+    res = torch.randn(M, Co, generator=g).to(BF).cuda()
+    ref = _ref_conv_gpu(x, w, N, H, W, k, pad, dil)
+    y = torch.empty(M, Co, dtype=BF, device='cuda')
+    ops.conv2d(x, w, y, N, H, W, H, W, k, k, 1, pad, dil, 0)
+    assert relerr(y.float(), ref) < 6e-3 and rel_l2(y, ref) < 3e-3          # one bf16 rounding of the output
+    # residual added before the store + per-group statistics of the STORED values (the head conv's epilogue)
+    st = torch.zeros(groups, 8, 2, Co, device='cuda')
+    y2 = torch.empty_like(y)
+    ops.conv2d(x, w, y2, N, H, W, H, W, k, k, 1, pad, dil, 0, res, st, groups)
+    assert rel_l2(y2, ref + res.float()) < 4e-3
+    yg = y2.float().view(groups, M // groups, Co)
+    torch.testing.assert_close(st.sum(1)[:, 0], yg.sum(1), rtol=1e-4, atol=0.5)
+    torch.testing.assert_close(st.sum(1)[:, 1], (yg * yg).sum(1), rtol=1e-4, atol=0.5)
+
+
+def test_big_tile_inference_batchnorm_epilogue(ops):
+    """conv + eval-mode BN + residual + ReLU on the 128 x 256 tile (an eval forward of 16 images, e.g. two TTA batches)."""
+    N, H, W, Ci, Co, k = 16, 32, 32, 2048, 512, 3
+    M = N * H * W
+    assert _big_tile_code(M, Co, k, Ci) == (128, 256, 83)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, Ci, generator=g).to(BF).cuda()
+    w = (torch.randn(Co, k * k, Ci, generator=g) * (2.0 / (Ci * k * k)) ** 0.5).to(BF).cuda()
+    res = torch.randn(M, Co, generator=g).to(BF).cuda()
+    rm, rv = torch.randn(Co, generator=g).cuda() * 0.1, (torch.rand(Co, generator=g) + 0.5).cuda()
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda() * 0.1
+    y = torch.empty(M, Co, dtype=BF, device='cuda')
+    ops.conv2d_bneval(x, w, y, N, H, W, H, W, k, k, 1, 1, 1, rm, rv, gamma, beta, True, res)
+    c = _ref_conv_gpu(x, w, N, H, W, k, 1, 1).to(BF).float()                # the kernel normalises the bf16-rounded conv
+    ref = torch.relu((c - rm) / torch.sqrt(rv + 1e-5) * gamma + beta + res.float())
+    # a conv output one bf16 ulp off moves the normalised value by ~1 %: compare in norm, bound the worst element
+    assert rel_l2(y, ref) < 6e-3 and relerr(y.float(), ref) < 3e-2
+
+
+@pytest.mark.parametrize('Cf,Cb,k,pad,dil', [(2048, 512, 3, 1, 1), (512, 512, 3, 2, 2)])
+def test_big_tile_data_gradient_with_fused_bn_backward(ops, Cf, Cb, k, pad, dil):
+    """The data gradient of the head conv (512 -> 2048, residual = the other head's feature gradient) and of layer4's
+    atrous conv2 (residual-free in the step; here with one) on the 128 x 256 tile: plain, and with the consumer
+    BatchNorm's backward sums + ReLU sign mask folded into the epilogue (what _cbr_bwd launches for layer4)."""
+    N, H, W, groups = 16, 32, 32, 2
+    M = N * H * W
+    assert _big_tile_code(M, Cf, k, Cb, M // groups) == (128, 256, 83)
+    g = torch.Generator().manual_seed(Cf + dil)
+    dy = torch.randn(M, Cb, generator=g).to(BF).cuda()
+    w = (torch.randn(Cb, k * k, Cf, generator=g) * (2.0 / (Cf * k * k)) ** 0.5).to(BF).cuda()     # forward weights [Cout][tap][Cin]
+    wt = w.permute(2, 1, 0).contiguous()                                                        # [Cin][tap][Cout]
+    res = torch.randn(M, Cf, generator=g).to(BF).cuda()
+    # reference: autograd through the fp32 im2col matmul
+    xr = torch.zeros(M, Cf, device='cuda', requires_grad=True)
+    cols = F.unfold(xr.view(N, H, W, Cf).permute(0, 3, 1, 2), k, dil, pad, 1)
+    cols = cols.view(N, Cf, k * k, H * W).permute(0, 3, 2, 1).reshape(M, k * k * Cf)
+    (cols @ w.float().view(Cb, k * k * Cf).t()).backward(dy.float())
+    ref = xr.grad + res.float()
+    dx = torch.empty(M, Cf, dtype=BF, device='cuda')
+    ops.conv2d(dy, wt, dx, N, H, W, H, W, k, k, 1, pad, dil, 1, res, None)
+    assert rel_l2(dx, ref) < 4e-3 and relerr(dx.float(), ref) < 1.5e-2
+    # fused BatchNorm-backward reduction of the consumer (y sign from a mask, per-group statistics)
+    cy = torch.randn(M, Cf, generator=g).to(BF).cuda()
+    cx = torch.randn(M, Cf, generator=g).to(BF).cuda()
+    keep = (cy.float() > 0).cpu()
+    mask = (keep.reshape(M, Cf // 8, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(-1).to(torch.uint8).cuda()
+    mi = torch.stack([torch.randn(groups, Cf, generator=g) * 0.1, torch.rand(groups, Cf, generator=g) + 0.5], 1).cuda().contiguous()
+    for use_mask in (False, True):
+        dx2 = torch.empty_like(dx)
+        sums = torch.zeros(groups, 8, 2, Cf, device='cuda')
+        ops.conv2d_bnbwd(dy, wt, dx2, N, H, W, H, W, k, k, 1, pad, dil, 1, res, sums, groups,
+                         None if use_mask else cy, cx, mi, True, relu_mask=mask if use_mask else None)
+        assert torch.equal(dx2, dx)
+        want = torch.zeros(groups, 8, 2, Cf, device='cuda')
+        ops.bn_bwd_reduce(dx2, cy, cx, mi, want, M, Cf, True, groups=groups)
+        torch.testing.assert_close(sums.sum(1), want.sum(1), rtol=3e-4, atol=0.5)

@@ -55,6 +55,11 @@ def _worker(rank, world, port, q):
     red.reset()
     red.finish()
     ok = ok and torch.allclose(flat, expect, rtol=1e-6, atol=1e-6)
+    # ClassBalance: per-class counts are summed over the ranks before the frequency EMA (regda_amd/gast/balance.py)
+    from regda_amd.gast.balance import sync_class_counts
+    cnt = torch.tensor([1.0, 2.0, 3.0]) * (rank + 1)
+    sync_class_counts(cnt)
+    ok = ok and torch.equal(cnt, torch.tensor([1.0, 2.0, 3.0]) * sum(r + 1 for r in range(world)))
     q.put((rank, bool(ok), len(red.buckets)))
     dist.destroy_process_group()
 
@@ -80,3 +85,6 @@ def test_single_process_reducer_is_a_noop():
     red.ready_down_to(5)
     red.finish()
     assert torch.equal(flat, torch.arange(10.0)) and red.gscale == 1.0
+    from regda_amd.gast.balance import sync_class_counts
+    cnt = torch.tensor([4.0, 5.0])
+    assert sync_class_counts(cnt) is cnt and torch.equal(cnt, torch.tensor([4.0, 5.0]))

@@ -1,0 +1,93 @@
+"""GPU: the RCCL path of the data-parallel step on ONE GPU.  `torch.distributed` backend "nccl" (= RCCL) is initialised
+at world size 1 and RGDA_FORCE_DDP=1 makes the step issue its bucketed, stream-overlapped all-reduces exactly as it
+does at world size N (regda_amd/ddp.py, regda_amd/ssl.py): with one rank every all-reduce is the identity, so the
+step must reproduce the plain step.  (The N > 1 exchange itself is covered by tests/test_ddp_cpu.py with gloo; an 8-GPU
+run is the driver's.)"""
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import model as omodel
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture()
+def nccl_world1(monkeypatch):
+    monkeypatch.setenv('RGDA_FORCE_DDP', '1')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', torch.cuda.current_device()))
+    yield
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+
+
+def _run(steps, bucket_elems, overlap_comm=True, class_balance=False):
+    from regda_amd.models.Encoder import Deeplabv2
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    m = Deeplabv2(dict(backbone=dict(resnet_type=rt, output_stride=16, pretrained=False), multi_layer=True,
+                       cascade=False, use_ppm=True, ppm=dict(num_classes=6, use_aux=False, fc_dim=2048),
+                       inchannels=2048, num_classes=6, is_ins_norm=True))
+    m.load_state_dict(omodel.init_state_dict(rt, 6, seed=2), strict=True)
+    ones = torch.ones(4, 512)
+    m.set_drop_masks(ones, ones)
+    b = make_batch(b=2, size=128, seed=13)
+    st = SSLStep(m, torch.randn(6, 2048, generator=torch.Generator().manual_seed(3)), bucket_elems=bucket_elems,
+                 overlap_comm=overlap_comm)
+    out = None
+    for i in range(steps):
+        out = st.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], lr=1e-3)
+    torch.cuda.synchronize()
+    return m, st, [float(x.item()) for x in out]
+
+
+def test_forced_rccl_step_equals_plain_step(nccl_world1):
+    from regda_amd.ddp import FlatGradReducer
+    m1, st1, out1 = _run(2, bucket_elems=1 << 20)                   # small buckets: several all-reduces per step
+    assert st1.reducer.force and st1.world == 1 and len(st1.reducer.buckets) >= 3
+    assert st1.reducer._next == len(st1.reducer.buckets)            # every bucket was issued
+    m2, st2, out2 = _run(2, bucket_elems=1 << 20, overlap_comm=False)   # one exchange after backward
+    # reference: the same step with the reducer switched off
+    force = FlatGradReducer.__init__
+
+    def no_force(self, *a, **k):
+        force(self, *a, **k)
+        self.force = False
+    FlatGradReducer.__init__ = no_force
+    try:
+        m0, st0, out0 = _run(2, bucket_elems=1 << 20)
+    finally:
+        FlatGradReducer.__init__ = force
+    assert not st0.reducer.force
+    for got in (out1, out2):
+        # weight gradients are fp32 atomics: run-to-run summation order only
+        assert got[0] == pytest.approx(out0[0], rel=1e-4) and got[1] == pytest.approx(out0[1], rel=1e-3, abs=1e-4)
+        assert got[2] == pytest.approx(out0[2], rel=1e-3)
+    for mm in (m1, m2):
+        d = (mm.flat_p - m0.flat_p).norm() / (m0.flat_p.norm())
+        assert d.item() < 1e-5
+        torch.testing.assert_close(mm.flat_g, m0.flat_g, rtol=1e-3, atol=1e-5 * float(m0.flat_g.abs().max()))
+    torch.testing.assert_close(st1.prototypes, st0.prototypes, rtol=1e-5, atol=1e-6)
+
+
+def test_class_balance_counts_go_through_the_process_group(nccl_world1):
+    from regda_amd.gast.balance import ClassBalance
+    lab = torch.randint(-1, 6, (2, 64, 64), device='cuda')
+    cb = ClassBalance(class_num=6, ignore_label=-1)
+    w = cb.next_class_weight(lab)
+    cnt = torch.stack([(lab == c).sum() for c in range(6)]).float()
+    freq = 0.01 * cnt / (cnt.sum() + 1e-7) + 0.99 * torch.ones(6, device='cuda') / 6
+    torch.testing.assert_close(cb.freq, freq, rtol=1e-6, atol=1e-7)
+    assert w.shape == (6,) and float(w.max()) <= 1.0

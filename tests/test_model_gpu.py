@@ -299,3 +299,48 @@ def test_factored_ppm_maps_match_the_one_pass_maps():
     assert l2(a1, b1) < 2e-2 and l2(a2, b2) < 2e-2
     cos = (ga @ gb / (ga.norm() * gb.norm())).item()
     assert cos > 0.99 and ga.norm().item() == pytest.approx(gb.norm().item(), rel=3e-2)       # the mask test's bound
+
+
+def test_feature_output_is_differentiable_through_the_module_api():
+    """d(loss on feat)/dW through `model(x)` + torch.autograd (the stage-2 losses of tools/train_align_reg.py act on
+    the third output): against autograd on the bf16-emulating oracle, and against the logits-only gradient (must
+    differ).  The reference's `feat` is an ordinary differentiable output (Encoder.py:146-151)."""
+    rt = 'resnet17t'
+    m = build(rt)
+    sd = omodel.init_state_dict(rt, 6, seed=5)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    gen = torch.Generator().manual_seed(17)
+    xs = torch.randn(2, 3, 64, 64, generator=gen)
+    R = torch.randn(2, 2048, 4, 4, generator=gen)
+    ones = (torch.ones(2, 512), torch.ones(2, 512))
+    m.set_drop_masks(*ones)
+    names = omodel.param_names(sd)
+    backbone = [k for k in names if k.startswith('encoder.')]
+
+    def grads(use_feat, use_logits):
+        m.zero_grad(set_to_none=True)
+        x1, x2, feat = m(xs.cuda())
+        assert feat.requires_grad
+        loss = 0
+        if use_feat:
+            loss = loss + (feat * R.cuda()).mean()
+        if use_logits:
+            loss = loss + x1.square().mean() + x2.mean()
+        loss.backward()
+        named = dict(m.named_parameters())
+        return torch.cat([named[k].grad.float().cpu().reshape(-1) for k in backbone])
+    g_feat = grads(True, False)
+    g_both = grads(True, True)
+    g_log = grads(False, True)
+    assert g_feat.norm().item() > 0
+    # linearity of the backward pass in the output gradients
+    cos = (g_both @ (g_feat + g_log) / (g_both.norm() * (g_feat + g_log).norm())).item()
+    assert cos > 0.995 and g_both.norm().item() == pytest.approx((g_feat + g_log).norm().item(), rel=0.03)
+    # oracle: autograd on the same loss
+    sdr = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    r1, r2, rf = omodel.forward(sdr, xs, True, ones, rt, {}, None, emulate_bf16=True)
+    gref = torch.autograd.grad((rf * R).mean(), [sdr[k] for k in backbone])
+    b = torch.cat([g.reshape(-1) for g in gref])
+    cos = (g_feat @ b / (g_feat.norm() * b.norm())).item()
+    assert cos > 0.97 and g_feat.norm().item() == pytest.approx(b.norm().item(), rel=0.05), (cos, g_feat.norm().item(), b.norm().item())

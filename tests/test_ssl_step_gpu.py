@@ -118,3 +118,161 @@ def test_step_runs_at_other_batch_and_tile_sizes(rt, b, size):
     hard = st.last_hard
     assert hard.shape == (b, size, size) and int(hard.min()) >= -1 and int(hard.max()) < 6
     assert st.lrh_flag() == 0 and not torch.equal(p0, m.flat_p)
+
+
+def test_resnet101_step_vs_reference_minted_step(gold, capsys):
+    """The HIP SSLStep on ResNet-101 against the REFERENCE's own composed step (tests/golden/model_small.npz: minted by
+    make_goldens.gold_model from tools/train_ssl_reg.py:198-241 on the imported reference model, fp32).  Stated
+    tolerances (bf16 storage / fp32 accumulation through 101 layers): losses 3 %, gradient norm
+    6 %, refined soft labels 2e-2 mean-abs, end-to-end pseudo-label mismatch rate < 6 % (reported), prototypes 3e-3,
+    selected gradients by cosine."""
+    from regda_amd.ssl import SSLStep
+    g = gold('model_small.npz')
+    sd = omodel.init_state_dict('resnet101', 6, seed=1)
+    m = build('resnet101')
+    m.load_state_dict(sd, strict=True)
+    m5 = torch.from_numpy(np.concatenate([g['m5'][0], g['m5'][1]]))       # Dropout2d keep masks: source pass, target pass
+    m6 = torch.from_numpy(np.concatenate([g['m6'][0], g['m6'][1]]))
+    m.set_drop_masks(m5, m6)
+    st = SSLStep(m, torch.from_numpy(g['protos']))
+    st.keep_debug = True
+    xs, xt = torch.from_numpy(g['xs']).cuda(), torch.from_numpy(g['xt']).cuda()
+    lab = torch.from_numpy(g['lab_s'].astype(np.int64)).cuda()
+    soft_t = torch.from_numpy(g['soft_t']).cuda()
+    regs = torch.from_numpy(g['regs'].astype(np.int64)).cuda()
+    ls, lt, gn = st.step(xs, lab, xt, soft_t, regs, lr=1e-2)
+    torch.cuda.synchronize()
+    rep = {}
+    rep['loss_s'] = (ls.item(), float(g['loss_s']))
+    rep['loss_t'] = (lt.item(), float(g['loss_t']))
+    rep['grad_norm'] = (gn.sqrt().item(), float(g['grad_norm']))
+    soft = st.debug['soft'].cpu()
+    rep['soft2_mean_abs'] = (soft - torch.from_numpy(g['soft2'])).abs().mean().item()
+    hard = st.last_hard.cpu().numpy()
+    rep['hard2_mismatch'] = float((hard != g['hard2'].astype(np.int64)).mean())
+    rep['hard_selected_mismatch'] = float((st.debug['hard_selected'].cpu().numpy() != g['hard'].astype(np.int64)).mean())
+    pn = torch.from_numpy(g['protos_new'])
+    rep['protos_rel'] = ((st.prototypes.cpu() - pn).norm() / pn.norm()).item()
+    named = {k: v for k, v in m._gviews.items()}
+    cos = {}
+    for key in g.files:
+        if not key.startswith('grad:'):
+            continue
+        name = key[5:]
+        ref = torch.from_numpy(g[key]).float()
+        if name.endswith('[:2]'):
+            got = named['encoder.resnet.' + name[:-4]][:2]
+        elif name.endswith('[:1,:64]'):
+            got = named[name[:-8]][:1, :64]
+        else:
+            got = named[name]
+        got = got.detach().float().cpu().reshape(ref.shape)
+        cos[name] = ((got.flatten() @ ref.flatten()) / (got.norm() * ref.norm() + 1e-30)).item(), got.norm().item() / (ref.norm().item() + 1e-30)
+    rep['grad_cos_and_norm_ratio'] = cos
+    with capsys.disabled():
+        print('\n[resnet101 step vs reference golden]', rep)
+    # the integer chain is exact given the HIP path's own soft labels
+    mine = olab.homogenize(olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1), g['regs'].astype(np.int64).squeeze(1), 0.5, 6, -1)
+    assert np.array_equal(mine, hard)
+    assert rep['loss_s'][0] == pytest.approx(rep['loss_s'][1], rel=0.03)
+    assert rep['loss_t'][0] == pytest.approx(rep['loss_t'][1], rel=0.06, abs=0.02)
+    assert rep['grad_norm'][0] == pytest.approx(rep['grad_norm'][1], rel=0.06)
+    assert rep['soft2_mean_abs'] < 2e-2
+    assert rep['hard2_mismatch'] < 0.06 and rep['hard_selected_mismatch'] < 0.06
+    assert rep['protos_rel'] < 3e-3
+    for name, (c, r) in cos.items():
+        if 'ppm.0.' in name:            # the degenerate scale-1 branch: rounding noise in the reference itself
+            continue
+        assert c > 0.85 and 0.8 < r < 1.25, (name, c, r)
+    assert st.lrh_flag() == 0
+    assert int(m.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == 2
+
+
+def test_full_size_config1_step_properties_and_label_chain(capsys):
+    """ONE full BASELINE config[1] step: ResNet-101, 8 + 8 images of 512 x 512, online EMA teacher, both streams --
+    the workload bench.py times.  Checked through size-independent properties, and the whole label path is
+    recomputed by the oracle from the HIP model's own target logits / features / teacher probabilities:
+    label_refine within 5e-4, then pseudo_selection + LRH BIT-EXACT on the HIP path's own refined soft labels."""
+    from oracle import labelpath as opath
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    m = build('resnet101')
+    with torch.no_grad():
+        for head in ('layer5', 'layer6'):           # confident classifiers, like bench.py: some pixels pass the threshold
+            m.convs[f'{head}.conv_last.4'].w.mul_(40.0)
+    m.sync_weights()
+    b = make_batch(b=8, size=512, seed=2333, with_soft=False)
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
+    st = SSLStep(m, protos, ema_decay=0.999)
+    p0 = m.flat_p.clone()
+    st.step(b['images_s'], b['label_s'], b['images_t'], None, b['regs_t'], lr=1e-3)      # warm-up (momentum init variant)
+    st.keep_debug = True
+    p1 = m.flat_p.clone()
+    sh1 = st.teacher.flat_p.clone()
+    protos1 = st.prototypes.clone()
+    nbt0 = int(m.state_dict()['encoder.resnet.bn1.num_batches_tracked'])
+    ls, lt, gn = st.step(b['images_s'], b['label_s'], b['images_t'], None, b['regs_t'], lr=1e-3)
+    torch.cuda.synchronize()
+    d = st.debug
+    assert np.isfinite(ls.item()) and np.isfinite(lt.item()) and np.isfinite(gn.item()) and gn.item() > 0
+    assert ls.item() > 0 and lt.item() >= 0
+    assert d['t1'].shape == (8, 6, 32, 32) and d['feat_t'].shape == (8, 2048, 32, 32)
+    # instance-normalised features: zero mean / unit variance per (image, channel)
+    f = d['feat_t']
+    assert float(f.mean((2, 3)).abs().max()) < 1e-3 and float((f.var((2, 3), unbiased=False) - 1).abs().max()) < 1e-2
+    # teacher output: a probability map
+    si = d['soft_in']
+    assert si.shape == (8, 6, 512, 512) and float(si.min()) >= 0
+    torch.testing.assert_close(si.sum(1), torch.ones(8, 512, 512, device='cuda'), rtol=1e-5, atol=1e-5)
+    # BN buffers: updated twice (source, target); weights moved; EMA shadow = 0.999 * old + 0.001 * new weights
+    assert int(m.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == nbt0 + 2
+    assert not torch.equal(p1, m.flat_p) and not torch.equal(p0, p1)
+    torch.testing.assert_close(st.teacher.flat_p, 0.999 * sh1 + 0.001 * m.flat_p, rtol=1e-5, atol=1e-7)
+    assert torch.equal(m.flat_pb, m.flat_p.to(torch.bfloat16))
+    # gradient norm reported = norm of the flat gradient buffer
+    assert gn.item() == pytest.approx(float((m.flat_g.double() ** 2).sum()), rel=1e-4)
+    # ---- label path recomputed by the oracle from the HIP model's own tensors
+    soft_ref = opath.label_refine(d['feat_t'].cpu(), protos1.cpu(), [d['t1'].cpu(), d['t2'].cpu()], si.cpu(), True, 'all', 2.0)
+    soft = d['soft'].cpu()
+    torch.testing.assert_close(soft, soft_ref, rtol=5e-4, atol=1e-6)
+    hard_sel = olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1)
+    assert np.array_equal(hard_sel, d['hard_selected'].cpu().numpy())
+    regs = b['regs_t'].squeeze(1).cpu().numpy()
+    hard = st.last_hard.cpu().numpy()
+    assert np.array_equal(olab.homogenize(hard_sel, regs, 0.5, 6, -1), hard)
+    labelled = float((hard >= 0).mean())
+    # end-to-end thresholding sensitivity: the oracle's refine output selects (almost) the same pixels
+    flips = float((olab.pseudo_selection(soft_ref.numpy(), 0.8, 0.6, -1) != hard_sel).mean())
+    with capsys.disabled():
+        print('\n[full-size step] loss_s %.4f loss_t %.4f |g| %.3f labelled %.3f refine-rounding flips %.2e' %
+              (ls.item(), lt.item(), gn.sqrt().item(), labelled, flips))
+    assert 0.0 < labelled < 1.0 and flips < 1e-3
+    assert st.lrh_flag() == 0
+    # prototypes: EMA of the per-class masked feature means of the SOURCE batch (oracle on the HIP features)
+    pref, _ = opath.update_prototype(d['feat_s'].cpu(), b['label_s'].cpu(), protos1.cpu(), 0.996, 6, -1)
+    torch.testing.assert_close(st.prototypes.cpu(), pref, rtol=1e-4, atol=1e-5)
+
+
+def test_teacher_sees_the_same_batchnorm_statistics_with_and_without_stream_overlap():
+    """The EMA teacher reads a snapshot of the student's BatchNorm buffers taken at the start of the step: its soft
+    labels are identical whether its forward overlaps the student's training forward (which rewrites the buffers) or
+    runs after it."""
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=4)
+    bt = make_batch(b=2, size=128, seed=9, with_soft=False)
+    ones = torch.ones(4, 512)
+    soft = {}
+    for overlap in (True, False):
+        m = build(rt)
+        m.load_state_dict(sd, strict=True)
+        m.set_drop_masks(ones, ones)
+        st = SSLStep(m, torch.zeros(6, 2048), ema_decay=0.9, overlap_wgrad=overlap)
+        for _ in range(2):      # the second step's teacher sees buffers one update away from their initial values
+            st.step(bt['images_s'], bt['label_s'], bt['images_t'], None, bt['regs_t'], lr=0.0)
+        torch.cuda.synchronize()
+        soft[overlap] = st.last_soft_t.clone()
+        assert st.teacher.bns['encoder.resnet.bn1'].rm.data_ptr() != m.bns['encoder.resnet.bn1'].rm.data_ptr()
+    assert torch.equal(soft[True], soft[False])

@@ -123,9 +123,11 @@ def test_step_runs_at_other_batch_and_tile_sizes(rt, b, size):
 def test_resnet101_step_vs_reference_minted_step(gold, capsys):
     """The HIP SSLStep on ResNet-101 against the REFERENCE's own composed step (tests/golden/model_small.npz: minted by
     make_goldens.gold_model from tools/train_ssl_reg.py:198-241 on the imported reference model, fp32).  Stated
-    tolerances (bf16 storage / fp32 accumulation through 101 layers): losses 3 %, gradient norm
-    6 %, refined soft labels 2e-2 mean-abs, end-to-end pseudo-label mismatch rate < 6 % (reported), prototypes 3e-3,
-    selected gradients by cosine."""
+    tolerances (bf16 storage / fp32 accumulation through 101 layers; measured on MI355X: losses
+    0.9 % / 0.1 %, gradient norm 0.2 %, soft labels 8e-4 mean-abs, 0.27 % of the pseudo labels differ end to end,
+    prototypes 1e-4, gradient cosines 0.88 .. 0.9999): losses 2.5 %, gradient norm 2.5 %, refined soft labels 4e-3
+    mean-abs, end-to-end pseudo-label mismatch rate < 1.5 % (reported), prototypes 1e-3, selected gradients by
+    cosine > 0.8 and norm ratio within 15 %."""
     from regda_amd.ssl import SSLStep
     g = gold('model_small.npz')
     sd = omodel.init_state_dict('resnet101', 6, seed=1)
@@ -174,16 +176,16 @@ def test_resnet101_step_vs_reference_minted_step(gold, capsys):
     # the integer chain is exact given the HIP path's own soft labels
     mine = olab.homogenize(olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1), g['regs'].astype(np.int64).squeeze(1), 0.5, 6, -1)
     assert np.array_equal(mine, hard)
-    assert rep['loss_s'][0] == pytest.approx(rep['loss_s'][1], rel=0.03)
-    assert rep['loss_t'][0] == pytest.approx(rep['loss_t'][1], rel=0.06, abs=0.02)
-    assert rep['grad_norm'][0] == pytest.approx(rep['grad_norm'][1], rel=0.06)
-    assert rep['soft2_mean_abs'] < 2e-2
-    assert rep['hard2_mismatch'] < 0.06 and rep['hard_selected_mismatch'] < 0.06
-    assert rep['protos_rel'] < 3e-3
+    assert rep['loss_s'][0] == pytest.approx(rep['loss_s'][1], rel=0.025)
+    assert rep['loss_t'][0] == pytest.approx(rep['loss_t'][1], rel=0.025, abs=0.01)
+    assert rep['grad_norm'][0] == pytest.approx(rep['grad_norm'][1], rel=0.025)
+    assert rep['soft2_mean_abs'] < 4e-3
+    assert rep['hard2_mismatch'] < 0.015 and rep['hard_selected_mismatch'] < 0.015
+    assert rep['protos_rel'] < 1e-3
     for name, (c, r) in cos.items():
         if 'ppm.0.' in name:            # the degenerate scale-1 branch: rounding noise in the reference itself
             continue
-        assert c > 0.85 and 0.8 < r < 1.25, (name, c, r)
+        assert c > 0.8 and 0.85 < r < 1.15, (name, c, r)
     assert st.lrh_flag() == 0
     assert int(m.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == 2
 
@@ -270,9 +272,13 @@ def test_teacher_sees_the_same_batchnorm_statistics_with_and_without_stream_over
         m.load_state_dict(sd, strict=True)
         m.set_drop_masks(ones, ones)
         st = SSLStep(m, torch.zeros(6, 2048), ema_decay=0.9, overlap_wgrad=overlap)
-        for _ in range(2):      # the second step's teacher sees buffers one update away from their initial values
-            st.step(bt['images_s'], bt['label_s'], bt['images_t'], None, bt['regs_t'], lr=0.0)
+        # eval-mode kernels have no atomics: the teacher's output on a given buffer snapshot is bit-reproducible.
+        # (Across steps it is not: the student's batch statistics are summed with atomics in a varying order.)
+        before = st.teacher_probs(bt['images_t']).clone()
+        st.step(bt['images_s'], bt['label_s'], bt['images_t'], None, bt['regs_t'], lr=0.0)
         torch.cuda.synchronize()
         soft[overlap] = st.last_soft_t.clone()
+        assert torch.equal(soft[overlap], before)       # the statistics as they stood at the start of the step
         assert st.teacher.bns['encoder.resnet.bn1'].rm.data_ptr() != m.bns['encoder.resnet.bn1'].rm.data_ptr()
+        assert not torch.equal(st.teacher.flat_buf, m.flat_buf)     # the student's forward has moved on since
     assert torch.equal(soft[True], soft[False])

@@ -31,6 +31,7 @@ struct ConvArgs {
     int M;
     int tiles_c, tiles_p;
     int rows_per_group;   // BatchNorm statistics are kept per group of rows (src / tgt batch)
+    int howo_shift, wo_shift;   // log2(Ho * Wo), log2(Wo) when those are powers of two (every map of a 512 x 512 step), else -1
     unsigned long long* dbg;   // optional per-workgroup phase timestamps (tuning builds only)
     int tpw;                   // conv3x3_c64_kernel: image rows per workgroup
     int skip;                  // tuning only: 1 = no DMA inside the K loop, 2 = no LDS reads / MFMA
@@ -268,8 +269,11 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         int m = m0 + r;
         xm[i] = m < a.M;
         int mm = xm[i] ? m : 0;
-        int n = mm / (a.Ho * a.Wo), rem = mm % (a.Ho * a.Wo);
-        int ho = rem / a.Wo, wo = rem % a.Wo;
+        int n, rem, ho, wo;       // 32-bit divisions cost ~50 instructions each: shifts where the map sizes allow
+        if (a.howo_shift >= 0) { n = mm >> a.howo_shift; rem = mm & ((1 << a.howo_shift) - 1); }
+        else { n = mm / (a.Ho * a.Wo); rem = mm % (a.Ho * a.Wo); }
+        if (a.wo_shift >= 0) { ho = rem >> a.wo_shift; wo = rem & ((1 << a.wo_shift) - 1); }
+        else { ho = rem / a.Wo; wo = rem % a.Wo; }
         xn[i] = n * a.H * a.W;
         if (a.mode == 0) { xh[i] = ho * a.stride - a.pad; xw[i] = wo * a.stride - a.pad; }
         else             { xh[i] = ho + a.pad;            xw[i] = wo + a.pad; }
@@ -603,6 +607,7 @@ extern "C" int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, in
     return bc | (bp << 10) | (stages << 20);
 }
 
+static int ilog2_exact(int v);
 struct BnBwdFuse { const void* y; int ldy; const unsigned char* mask; const void* x; int ldx; const float* mi; const float* nscale; int rpi; int relu; };
 struct BnEvalFuse { const float* rm; const float* rv; const float* gamma; const float* beta; float eps; int relu; };
 
@@ -626,6 +631,8 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
     long long M = (long long)N * Ho * Wo;
     if (M > 0x7fffffffLL) return RGDA_ERR_ARG;
     a.M = (int)M;
+    a.howo_shift = ilog2_exact(Ho * Wo);
+    a.wo_shift = ilog2_exact(Wo);
     hipStream_t st = to_stream(stream);
     // tile choice: fill 256 CUs (2 workgroups each); prefer the big tile when it still gives >= 512 groups
     if (stat_groups < 1) stat_groups = 1;

@@ -452,32 +452,45 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
                                                            int rows_per_block, int bpg) {
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
-    if (cg >= C) return;
     const int grp = blockIdx.x / bpg, chunk = blockIdx.x % bpg;     // M = rows of ONE group
     mi += (size_t)grp * 2 * C;
     sums += (size_t)grp * NREP * 2 * C;
-    float mean[8], istd[8], k0[8], k1[8], k2[8];
+    // per-channel constants of the workgroup's vpb * 8 channels: one channel per thread (coalesced across threads; the
+    // 2 * NREP replicated partial sums are 16 loads per CHANNEL, not per thread: 16 row lanes used to fetch the same 38
+    // vectors each, more load instructions than the rows a workgroup streams), shared through LDS
+    extern __shared__ __attribute__((aligned(16))) float sk_dyn[];      // [5][vpb * 8]
+    const int nch = vpb * 8;
+    float* const sk0 = sk_dyn;          // mean, istd, k0 = gamma * istd, k1 = sum(g') / M, k2 = sum(g' xhat) / M
     const float invM = 1.f / (float)M;
+    for (int c = threadIdx.x; c < vpb * 8; c += 256) {
+        const int cc = blockIdx.y * vpb * 8 + c;
+        if (cc < C) {
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        mean[e] = mi[cg + e];
-        istd[e] = mi[C + cg + e];
-        float gi = gamma[cg + e] * istd[e];
-        k0[e] = gi;
-        float t1 = 0.f, t2 = 0.f;
-        for (int r = 0; r < NREP; ++r) { t1 += sums[(size_t)(2 * r) * C + cg + e]; t2 += sums[(size_t)(2 * r + 1) * C + cg + e]; }
-        k1[e] = t1;
-        k2[e] = t2;
-    }
-    if (chunk == 0 && rl == 0 && dgamma) {      // one workgroup per group folds that group's sums into the grads
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            atomicAdd(dgamma + cg + e, k2[e]);
-            atomicAdd(dbeta + cg + e, k1[e]);
+            for (int r = 0; r < NREP; ++r) { t1 += sums[(size_t)(2 * r) * C + cc]; t2 += sums[(size_t)(2 * r + 1) * C + cc]; }
+            const float is = mi[C + cc];
+            sk0[0 * nch + c] = mi[cc];
+            sk0[1 * nch + c] = is;
+            sk0[2 * nch + c] = gamma[cc] * is;
+            sk0[3 * nch + c] = t1 * invM;
+            sk0[4 * nch + c] = t2 * invM;
+            if (chunk == 0 && dgamma) {      // one workgroup per group folds that group's sums into the grads
+                atomicAdd(dgamma + cc, t2);
+                atomicAdd(dbeta + cc, t1);
+            }
         }
     }
+    __syncthreads();
+    if (cg >= C) return;
+    float mean[8], istd[8], k0[8], k1[8], k2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { k1[e] *= invM; k2[e] *= invM; }
+    for (int e = 0; e < 8; ++e) {
+        mean[e] = sk0[0 * nch + cvl * 8 + e];
+        istd[e] = sk0[1 * nch + cvl * 8 + e];
+        k0[e] = sk0[2 * nch + cvl * 8 + e];
+        k1[e] = sk0[3 * nch + cvl * 8 + e];
+        k2[e] = sk0[4 * nch + cvl * 8 + e];
+    }
     long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
     for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
@@ -538,7 +551,7 @@ extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy,
     if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     RowLayout L; int rpbk, bpg; dim3 grid;
     elementwise_grid(M / groups, C, groups, L, rpbk, bpg, grid);
-    bn_bwd_apply_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask,
+    bn_bwd_apply_kernel<<<grid, 256, (size_t)5 * L.vpb * 8 * sizeof(float), to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask,
                                                               (const bf16_t*)x, ldx, mi, gamma, nscale, rows_per_image,
                                                               sums, (bf16_t*)dx, lddx, (bf16_t*)gmask, ldgm, dgamma,
                                                               dbeta, M / groups, C, relu, L.vpb, L.rpb, rpbk, bpg);

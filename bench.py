@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--serial', action='store_true', help='one stream only (clean per-kernel profiles)')
     ap.add_argument('--no-comm-overlap', action='store_true', help='all-reduce the whole gradient after backward instead of bucket by bucket during it')
+    ap.add_argument('--eager', action='store_true', help='one Python -> ctypes call per launch instead of the recorded launch plan (regda_amd/plan.py, the single-GPU default)')
+    ap.add_argument('--no-h2d', action='store_true', help='reuse one device-resident batch instead of staging a fresh pinned host batch per step over a copy stream')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 24.7 vs 24.1 ms)')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--phases', action='store_true', help='HIP-event phase marks of one extra step, to stderr')
@@ -238,17 +240,40 @@ def main():
     batch = make_batch(b=args.batch, size=args.size, seed=2333 + rank, with_soft=not teacher)
     soft = batch.get('soft_t')
     it = [0]
+    # input path (tools/train_ssl_reg.py:200-206 moves every batch to the GPU inside the iteration): two distinct
+    # synthetic batches in pinned host memory, copied per step by a copy stream into double-buffered device slots
+    pf = None
+    if not args.no_h2d:
+        from regda_amd.utils.prefetch import DevicePrefetcher
+        host = [{k: v.cpu() for k, v in batch.items()},
+                {k: v for k, v in make_batch(b=args.batch, size=args.size, seed=4666 + rank, with_soft=not teacher, device='cpu').items()}]
+        pf = DevicePrefetcher(host)
 
     def one():
         i = it[0]
         lr = lr_warmup(1e-2, i, 300) if i < 300 else lr_poly(1e-2, i, 9000, 0.9)   # tools.py:191-207
         it[0] += 1
-        return step.step(batch['images_s'], batch['label_s'], batch['images_t'], soft, batch['regs_t'], lr)
+        if pf is None:
+            return step.step(batch['images_s'], batch['label_s'], batch['images_t'], soft, batch['regs_t'], lr)
+        b = pf.next()
+        out = step.step(b['images_s'], b['label_s'], b['images_t'], b.get('soft_t'), b['regs_t'], lr)
+        pf.release()
+        return out
 
     for _ in range(args.warmup):
         one()
     torch.cuda.synchronize()
-    graphed = False
+    graphed = planned = False
+    if world == 1 and not args.graph and not args.eager:
+        try:        # the step is a static launch sequence: replay it below the ABI (one C loop per segment)
+            step.record_plan(batch['images_s'], batch['label_s'], batch['images_t'], soft, batch['regs_t'])
+            it[0] += 1
+            one()
+            torch.cuda.synchronize()
+            planned = True
+        except Exception as e:      # stay eager, say so
+            print('plan recording failed, running eagerly:', repr(e)[:300], file=sys.stderr)
+            step._plan = None
     if world == 1 and args.graph:
         try:        # replay the (static) step as one hipGraph: removes ~20 ms/step of host launch work
             step.capture(batch['images_s'], batch['label_s'], batch['images_t'], soft, batch['regs_t'])
@@ -275,6 +300,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = [float(x.item()) for x in out]
+    # host cost of enqueueing ONE step, measured from an idle queue (in the timed loop above the GPU is the bottleneck and
+    # the launch queue pushes back on the host, so that loop's host time mostly shows the back-pressure)
+    t_iso = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one()
+        t_iso.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
     if args.phases and rank == 0:
         one()                       # keep the GPU queue primed like in the timed loop
         step.marks = []
@@ -291,17 +325,19 @@ def main():
     res = {
         'metric': 'src+tgt 512x512 image-pairs/sec (SSL step)', 'value': value, 'unit': 'pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+        'data': 'synthetic' + ('' if pf is None else ', H2D per step (%.0f MB pinned -> device on a copy stream)' % (pf.bytes_per_batch / 1e6)),
         'config': {'workload': f'st.regda.2potsdam SSL step, {args.model} DeepLabV2(PPM), batch {args.batch}+{args.batch} '
                                f'{args.size}x{args.size} per GPU, ' + ('online EMA teacher' if teacher else 'offline soft labels'),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'gflop_per_pair': gflop_pair},
         'pairs_per_sec_per_gpu': value / world,
         'step_mfma_frac': value / world * gflop_pair / (MFMA_PEAK_TFLOPS * 1e3),
-        'loss_source': losses[0], 'loss_target': losses[1], 'hip_graph': graphed,
-        'host_enqueue_ms_per_step': t_host / args.steps * 1e3,
+        'loss_source': losses[0], 'loss_target': losses[1], 'hip_graph': graphed, 'plan_replay': planned,
+        'host_enqueue_ms_per_step': sorted(t_iso)[1] * 1e3,         # one step enqueued into an idle queue (median of 3)
+        'host_loop_ms_per_step': t_host / args.steps * 1e3,         # the timed loop's host side (includes queue back-pressure)
     }
     if rank == 0 and world == 1 and not args.no_roofline:
-        step._graph = None          # the per-launch HIP-event probe needs the eager path ...
+        step._graph = step._plan = None          # the per-launch HIP-event probe needs the eager path ...
         side, step.wgrad_stream = step.wgrad_stream, None     # ... and one stream, so a launch's events bracket only itself
         kern = conv_flops_probe(one)
         c3 = kern.pop('__conv3x3__')

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 2
+#define RGDA_ABI_VERSION 3
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the fp32 atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore f32[RGDA_STAT_REPLICAS][2][C], zeroed by the caller. */
@@ -386,6 +386,27 @@ int rgda_aspp_gather(const void* z, int ldz, const float* const* bias, float* ou
                      int w, int C, const int* dil, rgda_stream_t stream);
 int rgda_aspp_scatter(const float* g1, const float* g2, void* dz, int lddz, int zc, float* const* dbias, int N,
                       int h, int w, int C, const int* dil, rgda_stream_t stream);
+
+/* ------------------------------------------------------------------ plan replay
+ * The reference drives its step from Python, one operator call at a time (tools/train_ssl_reg.py:198-241); so does
+ * regda_amd in eager mode -- ~750 entry-point calls per SSL step.  The step's launch sequence is static (fixed shapes,
+ * fixed buffers), so the caller may RECORD it once as a table of rows {entry point, arguments packed into 64-bit
+ * slots: integers / pointers / streams by value, float and double by bit pattern} and have it replayed by one call.
+ * The table, every buffer it points to (device memory and the small host arrays some entry points take) and the
+ * streams are caller-owned; nothing is retained or allocated here.
+ *   rgda_plan_fn_id("rgda_conv2d") -> index of that entry point in the dispatch table (-1: not replayable; only
+ *     int-returning enqueue entry points are), rgda_plan_fn_count() -> table size.
+ *   rgda_plan_run: calls the rows in order; stops at the first row whose entry point returns a negative status and
+ *     returns that status (*failed_index = its row, when given).  A row with a bad id / argument count -> RGDA_ERR_ARG. */
+#define RGDA_PLAN_MAX_ARGS 36
+typedef struct rgda_plan_entry {
+    int32_t fn;
+    int32_t nargs;
+    uint64_t args[RGDA_PLAN_MAX_ARGS];
+} rgda_plan_entry;
+int rgda_plan_fn_count(void);
+int rgda_plan_fn_id(const char* name);
+int rgda_plan_run(const rgda_plan_entry* entries, int n, int* failed_index);
 
 #ifdef __cplusplus
 }

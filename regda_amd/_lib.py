@@ -77,12 +77,15 @@ class _Lib:
         if st != 0:
             msg = self._dll.rgda_strerror(st).decode()
             raise (ValueError if st in (-1, -4) else RgdaError)(f'{name}: {msg} (status {st})')
+        if _plan is not None and _plan._ACTIVE is not None:      # a step is being recorded (regda_amd/plan.py)
+            _plan._ACTIVE._call(name, args)
 
     def size(self, name, *args):
         return int(getattr(self._dll, name)(*args))
 
 
 _lib = None
+_plan = None        # set to the regda_amd.plan module when it is imported (the recorder lives there)
 
 
 def lib():

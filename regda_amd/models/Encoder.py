@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import plan
 
 BF = torch.bfloat16
 LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3),
@@ -519,19 +520,19 @@ class Deeplabv2(nn.Module):
             self._sync_head_weights(True)
             self._wt_ready = self._hw_ready = None
         else:
-            side_stream.wait_event(torch.cuda.current_stream().record_event())
+            plan.wait_event(side_stream, plan.record_event(torch.cuda.current_stream()))
             with ops.use_stream(side_stream):
                 self._sync_head_weights(True)
-                self._hw_ready = side_stream.record_event()         # needed by the next forward's heads
+                plan.host(lambda: setattr(self, '_hw_ready', side_stream.record_event()))    # needed by the next forward's heads
                 ops.weight_transpose_batched(self._wt_table, self._wt_table.shape[0], self._wt_blocks)
-            self._wt_ready = side_stream.record_event()              # needed by the next backward
+            plan.host(lambda: setattr(self, '_wt_ready', side_stream.record_event()))        # needed by the next backward
 
     def _sync_head_weights(self, with_transposes):
         """Re-slice the head convs' weights from the fp32 master (same rounding as the bf16 mirror)."""
         ops.weight_transpose_batched(self._hw_fwd_table, self._hw_fwd_table.shape[0], self._hw_fwd_blocks)
         if with_transposes:
             if self.head_kind == 'aspp':
-                self.aspp_wzt.view(2048, self.aspp_zc).copy_(self.aspp_wz.view(self.aspp_zc, 2048).t())
+                plan.host(lambda: self.aspp_wzt.view(2048, self.aspp_zc).copy_(self.aspp_wz.view(self.aspp_zc, 2048).t()))
             else:
                 ops.weight_transpose_batched(self._hw_bwd_table, self._hw_bwd_table.shape[0], self._hw_bwd_blocks)
 
@@ -577,9 +578,11 @@ class Deeplabv2(nn.Module):
 
     def adopt_buffers(self, other):
         """Copy `other`'s BatchNorm running statistics (one flat buffer each) on the current stream."""
-        with torch.no_grad():
-            self.flat_buf.copy_(other.flat_buf)
-            self.flat_nbt.copy_(other.flat_nbt)
+        def copy():
+            with torch.no_grad():
+                self.flat_buf.copy_(other.flat_buf)
+                self.flat_nbt.copy_(other.flat_nbt)
+        plan.host(copy)
 
     def refresh_from_master(self, mirror_is_fresh=False):
         """bf16 mirror + padded stem weights only (a forward-only model needs no transposed copies).
@@ -751,7 +754,7 @@ class Deeplabv2(nn.Module):
         gview = conv.g.view(512, 9, 4096)
         # weight gradients land in contiguous fp32 buffers (the kernels write [Cout][taps][Cin] densely) and are
         # added into the strided slices of the real gradient behind the grouped launch
-        hw['gfeat'].zero_()
+        plan.host(hw['gfeat'].zero_)
         T['wgrad_pending'].append((xn, dc, hw['gfeat'], N, h, w, h, w, 3, 3, 1, 1, 1))
         T['wgrad_pending_flop'] += 2.0 * M * 512 * 2048 * 9
         T['wgrad_post'].append(lambda gv=gview, t=hw['gfeat']: gv[:, :, :2048].add_(t))
@@ -773,7 +776,7 @@ class Deeplabv2(nn.Module):
             dzr = dz.view(N * s * s, 9 * 512)
             dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
             ops.conv2d(dzr, hw['wzt'][i], dq, N, s, s, s, s, 1, 1, 1, 0, 1)
-            hw['gz'][i].zero_()
+            plan.host(hw['gz'][i].zero_)
             T['wgrad_pending'].append((qs[i], dzr, hw['gz'][i], N, s, s, s, s, 1, 1, 1, 0, 1))
             T['wgrad_post'].append(lambda gv=gview, t=hw['gz'][i], i=i:
                                    gv[:, :, 2048 + 512 * i: 2048 + 512 * (i + 1)].add_(t.view(9, 512, 512).permute(1, 0, 2)))
@@ -802,15 +805,15 @@ class Deeplabv2(nn.Module):
         dev, C = self.device, self.num_classes
         xn, (N, h, w) = T['aspp']
         dz = torch.empty(N * h * w, self.aspp_zc, dtype=BF, device=dev)
-        ops.aspp_scatter(g1.contiguous().float(), g2.contiguous().float(), dz, [c.gbias for c in self.aspp_convs],
+        ops.aspp_scatter(g1, g2, dz, [c.gbias for c in self.aspp_convs],
                          N, h, w, C, ASPP_DILATIONS)
         dxn = torch.empty(N * h * w, 2048, dtype=BF, device=dev)
         ops.conv2d(dz, self.aspp_wzt, dxn, N, h, w, h, w, 1, 1, 1, 0, 1, 0)
-        self.aspp_gz.zero_()
+        plan.host(self.aspp_gz.zero_)
         ops.conv2d_wgrad(xn, dz, self.aspp_gz, N, h, w, h, w, 1, 1, 1, 0, 1)
         n = C * 9 * 2048
         for j, c in enumerate(self.aspp_convs):      # the rows of one conv are its master layout [C][3][3][2048]
-            c.g.view(-1).add_(self.aspp_gz.view(-1)[j * n:(j + 1) * n])
+            plan.host(lambda j=j, c=c: c.g.view(-1).add_(self.aspp_gz.view(-1)[j * n:(j + 1) * n]))
         return dxn
 
     def _flush_wgrads(self, T):
@@ -823,7 +826,7 @@ class Deeplabv2(nn.Module):
             if side is None:
                 ops.conv2d_wgrad_grouped(pend)
             else:
-                side.wait_event(T['main_stream'].record_event())
+                plan.wait_event(side, plan.record_event(T['main_stream']))
                 with ops.use_stream(side):
                     ops.conv2d_wgrad_grouped(pend)
                 # keep the operands alive until the streams join (no record_stream: the step must stay
@@ -833,11 +836,11 @@ class Deeplabv2(nn.Module):
             if post:        # strided adds of densely written gradients (head convs), behind the launch that made them
                 if side is None:
                     for fn in post:
-                        fn()
+                        plan.host(fn)
                 else:
                     with ops.use_stream(side):
                         for fn in post:
-                            fn()
+                            plan.host(fn)
                 T['wgrad_post'] = []
             T['wgrad_pending'] = []
             T['wgrad_pending_flop'] = 0.0
@@ -873,7 +876,7 @@ class Deeplabv2(nn.Module):
         ops.bn_bwd_apply(g, y if (relu and rmask is None) else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm,
                          bn.dgamma, bn.dbeta, nscale, Ho * Wo, groups=G, relu_mask=rmask)
         if stem:
-            self.stem_gtmp.zero_()
+            plan.host(self.stem_gtmp.zero_)
             ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
             ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
             return None, gm
@@ -909,6 +912,7 @@ class Deeplabv2(nn.Module):
         """x: one NCHW image batch, or a list of equally shaped batches that run through the network together
         as BatchNorm groups (the source and the target batch of an SSL step)."""
         dev = self.device
+        main_stream = torch.cuda.current_stream()
         xs = list(x) if isinstance(x, (list, tuple)) else [x]
         Ng, _, H, W = xs[0].shape
         N = Ng * len(xs)
@@ -944,16 +948,16 @@ class Deeplabv2(nn.Module):
             joined = None
             if ds:
                 if bs is not None:
-                    bs.wait_event(torch.cuda.current_stream().record_event())
+                    plan.wait_event(bs, plan.record_event(main_stream))
                 with (ops.use_stream(bs) if bs is not None else contextlib.nullcontext()):
                     idt, _, _ = self._cbr_fwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], y, N, h, w,
                                               False)
                     if bs is not None:
-                        joined = bs.record_event()
+                        joined = plan.record_event(bs)
             a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True)
             a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True)
             if joined is not None:
-                torch.cuda.current_stream().wait_event(joined)
+                plan.wait_event(main_stream, joined)
             y, _, _ = self._cbr_fwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], a2, N, h2, w2, True, res=idt)
             h, w = h2, w2
             if dbg is not None:
@@ -963,9 +967,11 @@ class Deeplabv2(nn.Module):
         feat = torch.empty(N, 2048, h, w, device=dev) if T is not None else None   # eval returns probabilities only
         imi = torch.empty(N, 2, 2048, device=dev)
         ops.instnorm_fwd(y, xn, None, feat, imi, N, HW, 2048)
-        if self._hw_ready is not None:                             # head weight slices rebuilt on another stream
-            torch.cuda.current_stream().wait_event(self._hw_ready)
-            self._hw_ready = None
+        def wait_head_weights():                                   # head weight slices rebuilt on another stream
+            if self._hw_ready is not None:
+                main_stream.wait_event(self._hw_ready)
+                self._hw_ready = None
+        plan.host(wait_head_weights)
         if T is not None:
             T['inorm'] = (y, imi, (N, h, w))
         if self.head_kind == 'aspp':
@@ -975,10 +981,17 @@ class Deeplabv2(nn.Module):
             return x1, x2, feat
         mats = self._mats(h, w)
         if T is not None:
-            if self._drop_override is not None:
-                masks = [m.to(dev).float().repeat(N // m.shape[0], 1) / 0.9 for m in self._drop_override]
-            else:
-                masks = [(torch.rand(N, 512, device=dev) >= 0.1).float() / 0.9 for _ in range(2)]
+            # Dropout2d(0.1) keep-masks, scaled: drawn from torch's generator at every step (a host action of a plan)
+            masks = [torch.empty(N, 512, device=dev) for _ in range(2)]
+
+            def draw():
+                for i, mk in enumerate(masks):
+                    if self._drop_override is not None:
+                        m = self._drop_override[i]
+                        mk.copy_(m.to(dev).float().repeat(N // m.shape[0], 1) / 0.9)
+                    else:
+                        mk.copy_((torch.rand(N, 512, device=dev) >= 0.1).float() / 0.9)
+            plan.host(draw)
         else:
             masks = [None, None]
         logits = []
@@ -1000,8 +1013,8 @@ class Deeplabv2(nn.Module):
             if self._head_stream is None:
                 self._head_stream = torch.cuda.Stream(device=dev)
             hs = self._head_stream
-            caller = torch.cuda.current_stream()
-            hs.wait_event(caller.record_event())
+            caller = main_stream
+            plan.wait_event(hs, plan.record_event(caller))
         for hi, head in enumerate(('layer5', 'layer6')):
             with (ops.use_stream(hs) if (hs is not None and hi == 1) else contextlib.nullcontext()):
                 qs = []
@@ -1021,7 +1034,7 @@ class Deeplabv2(nn.Module):
                     T[f'{head}.cls'] = (hid, (N, h, w))
                 logits.append(lg)
         if hs is not None:
-            caller.wait_event(hs.record_event())
+            plan.wait_event(caller, plan.record_event(hs))
         if T is not None:
             T['out_shape'] = tuple(logits[0].shape)
         return logits[0], logits[1], feat
@@ -1031,9 +1044,13 @@ class Deeplabv2(nn.Module):
         """g1, g2: d(loss)/d(logits) of the two heads (N, classes, h, w) f32.  gfeat (optional): d(loss)/d(feat) of the
         third forward output, bf16 pixel-major [N*h*w, 2048] -- the stage-2 prototype loss acts on the features."""
         dev = self.device
-        if getattr(self, '_wt_ready', None) is not None:       # transposed weights rebuilt on another stream
-            torch.cuda.current_stream().wait_event(self._wt_ready)
-            self._wt_ready = None
+        bwd_stream = torch.cuda.current_stream()
+
+        def wait_transposed_weights():                         # transposed weights rebuilt on another stream
+            if getattr(self, '_wt_ready', None) is not None:
+                bwd_stream.wait_event(self._wt_ready)
+                self._wt_ready = None
+        plan.host(wait_transposed_weights)
         T['on_progress'] = on_progress
         T['wgrad_pending'], T['wgrad_pending_flop'], T['wgrad_post'] = [], 0.0, []
         T['sums_pool'] = _StatsPool(sum(T['groups'] * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)
@@ -1054,7 +1071,7 @@ class Deeplabv2(nn.Module):
             hid, _ = T[f'{head}.cls']
             cl = C[f'{head}.conv_last.4']
             dh = torch.empty(M, 512, dtype=BF, device=dev)
-            ops.classifier_bwd(hid, cl.w.view(cl.co, cl.ci), gl.contiguous().float(), dh, cl.g.view(cl.co, cl.ci),
+            ops.classifier_bwd(hid, cl.w.view(cl.co, cl.ci), gl, dh, cl.g.view(cl.co, cl.ci),
                                cl.gbias, N, HW, 512, self.num_classes)
             # the second head's feature gradient is added onto the first head's in the conv epilogue
             dfeat, dqs = self._head_last_bwd(T, head, dh, dfeat)
@@ -1114,7 +1131,7 @@ class Deeplabv2(nn.Module):
         if T.get('mark') is not None:
             T['mark']('backward main chain done')
         if T.get('wgrad_stream') is not None:
-            T['main_stream'].wait_stream(T['wgrad_stream'])
+            plan.wait_stream(T['main_stream'], T['wgrad_stream'])
 
     # ------------------------------------------------------------------ grads <-> torch
     def attach_grads(self):
@@ -1147,7 +1164,8 @@ class _StatsPool:
     """One zero-initialised fp32 arena per forward for every BatchNorm's (sum, sumsq) accumulator."""
 
     def __init__(self, n, device):
-        self.buf = torch.zeros(n, device=device)
+        self.buf = torch.empty(n, device=device)
+        plan.host(self.buf.zero_)
         self.off = 0
 
     def take(self, n):

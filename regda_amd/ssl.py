@@ -12,6 +12,7 @@ the offline `.pt` files of the reference (BASELINE.json north_star; SURVEY.md he
 import torch
 
 from . import ops
+from . import plan
 from .ddp import FlatGradReducer
 
 
@@ -43,6 +44,7 @@ class SSLStep:
         self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
         self._graph = None
+        self._plan = None
         self.marks = None           # set to [] to collect (name, event) phase marks of the next step (bench --phases)
         self.overlap_comm = overlap_comm
         self.keep_debug = False     # tests: keep the step's target logits / features / refined soft labels (`self.debug`)
@@ -57,6 +59,8 @@ class SSLStep:
         synchronises with the host."""
         if self._graph is not None:
             return self._replay(images_s, label_s, images_t, soft_t, regs_t, lr)
+        if self._plan is not None:
+            return self._replay_plan(images_s, label_s, images_t, soft_t, regs_t, lr)
         self.lr_dev.fill_(float(lr))
         with ops.use_stream(torch.cuda.current_stream()):
             return self._step(images_s, label_s, images_t, soft_t, regs_t)
@@ -81,6 +85,40 @@ class SSLStep:
         m._hw_ready = m._wt_ready = None          # (they are events inside the graph now: nothing to wait for outside)
         self._graph = g
 
+    def record_plan(self, images_s, label_s, images_t, soft_t, regs_t):
+        """Record one whole step (all streams) as a launch plan (regda_amd/plan.py): its ~750 entry-point calls become
+        rows of a table that `rgda_plan_run` walks in C, the torch ops / stream waits between them stay host actions.
+        Later `step()` calls replay the plan on the recorded buffers (a private memory pool): same kernels, same
+        streams, same results as the eager step, a fraction of the host time.  Call after at least one eager step
+        (the first step initialises the momentum with another kernel variant).  Inputs are copied into static
+        buffers at every replay; the returned tensors (losses, `last_hard`, ...) are overwritten by the next step."""
+        assert not self.first, 'run one eager step before record_plan()'
+        assert self._graph is None and self._plan is None
+        self._static = [None if t is None else t.clone() for t in (images_s, label_s, images_t, soft_t, regs_t)]
+        torch.cuda.synchronize()
+        p = plan.Plan()
+
+        def run():
+            with ops.use_stream(torch.cuda.current_stream()):
+                return self._step(*self._static)
+        self._out = p.record(run)
+        self._plan = p
+        return p.stats()
+
+    def release_plan(self):
+        self._plan = None
+
+    def _replay_plan(self, images_s, label_s, images_t, soft_t, regs_t, lr):
+        for dst, src in zip(self._static, (images_s, label_s, images_t, soft_t, regs_t)):
+            if dst is not None and src is not dst:
+                dst.copy_(src, non_blocking=True)
+        self.lr_dev.fill_(float(lr))
+        m = self.model
+        if m.flat_p._version != m._synced_version:      # weights were changed from outside (load_state_dict, ...)
+            m.sync_weights()
+        self._plan.replay()
+        return self._out
+
     def _replay(self, images_s, label_s, images_t, soft_t, regs_t, lr):
         for dst, src in zip(self._static, (images_s, label_s, images_t, soft_t, regs_t)):
             if dst is not None and src is not dst:
@@ -101,7 +139,7 @@ class SSLStep:
             m.train()
         self._mark('step start')
         m._maybe_sync()
-        m.flat_g.zero_()
+        plan.host(m.flat_g.zero_)
         # source and target batch go through the network TOGETHER (twice the GEMM rows per launch), as two
         # BatchNorm groups: statistics, running-stat updates and gradients stay per domain like the
         # reference's two separate forward calls (train_ssl_reg.py:210-212)
@@ -117,7 +155,7 @@ class SSLStep:
             self.teacher.adopt_buffers(m)
         if teacher_on_side:
             # the EMA teacher's forward is independent of the student's: it runs on the second stream, next to it
-            self.wgrad_stream.wait_stream(main)
+            plan.wait_stream(self.wgrad_stream, main)
             with ops.use_stream(self.wgrad_stream):
                 soft_t = self.teacher_probs(images_t, snapshot=False)
                 self._mark('teacher forward done (side)', self.wgrad_stream)
@@ -126,7 +164,7 @@ class SSLStep:
         s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
         feat_s, feat_t = feat[:nb], feat[nb:]
         if teacher_on_side:
-            main.wait_stream(self.wgrad_stream)
+            plan.wait_stream(main, self.wgrad_stream)
         elif online:
             soft_t = self.teacher_probs(images_t, snapshot=False)
         self.last_soft_t = soft_t
@@ -151,13 +189,21 @@ class SSLStep:
                            ws=self.lrh_ws)
         ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
         if self.world > 1:      # keep the prototypes identical on every rank
-            torch.distributed.all_reduce(self.prototypes, group=self.group)
-            self.prototypes.div_(self.world)
+            def sync_prototypes():
+                torch.distributed.all_reduce(self.prototypes, group=self.group)
+                self.prototypes.div_(self.world)
+            plan.host(sync_prototypes)
         # ---- losses + d(loss)/d(logits)
         loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
         loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
         self._mark('label path + losses done')
-        self._backward_and_update(T, main, torch.cat([gs1, gt1]), torch.cat([gs2, gt2]))
+        g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
+
+        def gather_logit_grads():
+            torch.cat([gs1, gt1], out=g1)
+            torch.cat([gs2, gt2], out=g2)
+        plan.host(gather_logit_grads)
+        self._backward_and_update(T, main, g1, g2)
         self.last_hard = hard
         return loss_s, loss_t, self.gn
 
@@ -165,7 +211,7 @@ class SSLStep:
         """Backward (both domains in one pass; all-reduce buckets are released as it moves down the net), then clip +
         SGD (+ EMA) in one pass over the flat buffers."""
         m = self.model
-        self.reducer.reset()
+        plan.host(self.reducer.reset)
         T['wgrad_stream'] = self.wgrad_stream
         T['main_stream'] = main
         T['mark'] = self._mark if self.marks is not None else None
@@ -176,14 +222,14 @@ class SSLStep:
                     # a bucket needs the weight gradients (second stream) AND the BN gradients (main stream) of its
                     # layers: issue it from the second stream once that has caught up with this point of the main
                     # stream, so the critical path never waits for communication
-                    self.wgrad_stream.wait_event(main.record_event())
+                    plan.wait_event(self.wgrad_stream, plan.record_event(main))
                     with ops.use_stream(self.wgrad_stream):
-                        self.reducer.ready_down_to(offset)
+                        plan.host(lambda: self.reducer.ready_down_to(offset))
                 else:
-                    self.reducer.ready_down_to(offset)
+                    plan.host(lambda: self.reducer.ready_down_to(offset))
         m._backward_plan(T, g1, g2, on_progress=progress, gfeat=gfeat)
         self._mark('backward done (streams joined)')
-        self.reducer.finish()
+        plan.host(self.reducer.finish)
         # ---- clip + SGD (+ EMA) in one pass over the flat buffers
         ops.sumsq(m.flat_g, self.gn, self.gn_ws)
         shadow = self.teacher.flat_p if self.teacher is not None else None

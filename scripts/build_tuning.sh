@@ -4,6 +4,7 @@
 set -e
 cd "$(dirname "$0")/../regda_amd/csrc"
 mkdir -p tuning
+python3 gen_thunks.py ../../include/rgda_hip.h plan_thunks.inc
 for f in *.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -DRGDA_TUNING -c $f -o tuning/${f%.hip}.o &
 done

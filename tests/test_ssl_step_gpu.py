@@ -282,3 +282,73 @@ def test_teacher_sees_the_same_batchnorm_statistics_with_and_without_stream_over
         assert st.teacher.bns['encoder.resnet.bn1'].rm.data_ptr() != m.bns['encoder.resnet.bn1'].rm.data_ptr()
         assert not torch.equal(st.teacher.flat_buf, m.flat_buf)     # the student's forward has moved on since
     assert torch.equal(soft[True], soft[False])
+
+
+def test_plan_replay_matches_the_eager_step():
+    """SSLStep.record_plan(): the recorded launch table replayed by rgda_plan_run (plus its host actions) against the
+    same steps run eagerly -- same losses, BatchNorm buffers and weights up to the run-to-run noise of atomic summation
+    order, new inputs and learning rates are picked up, and the host enqueues a step several times faster."""
+    import time
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=12)
+    ones = torch.ones(4, 512)
+    b1 = make_batch(b=2, size=128, seed=21)
+    b2 = make_batch(b=2, size=128, seed=22)
+    seq = [b1, b1, b2, b1, b2]
+    lrs = [1e-3, 2e-3, 1e-3, 3e-3, 1e-3]
+
+    def run(use_plan):
+        m = build(rt)
+        m.load_state_dict(sd, strict=True)
+        m.set_drop_masks(ones, ones)
+        st = SSLStep(m, torch.randn(6, 2048, generator=torch.Generator().manual_seed(5)), ema_decay=0.9)
+        out, host = [], []
+        for i, (b, lr) in enumerate(zip(seq, lrs)):
+            if use_plan and i == 1:
+                stats = st.record_plan(b['images_s'], b['label_s'], b['images_t'], None, b['regs_t'])
+                assert stats['calls'] > 200 and stats['segments'] <= stats['host_actions'] + 1
+                # record_plan ran the step once with the learning rate of the previous step: undo nothing, just note
+                # that the recorded step IS step i (same inputs); the eager arm runs it with lrs[0] as well
+                out.append([float(x.item()) for x in st._out])
+                continue
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = st.step(b['images_s'], b['label_s'], b['images_t'], None, b['regs_t'], lr if not (i == 1) else lrs[0])
+            host.append(time.perf_counter() - t0)
+            out.append([float(x.item()) for x in o])
+        torch.cuda.synchronize()
+        return m, st, out, host
+
+    m_e, st_e, out_e, host_e = run(False)
+    m_p, st_p, out_p, host_p = run(True)
+    assert st_p._plan is not None and st_e._plan is None
+    # the source loss is a smooth function of the weights; the target loss counts thresholded pseudo labels, whose number
+    # moves by several per cent between two EAGER runs already (BatchNorm statistics are summed with atomics)
+    for oe, op in zip(out_e, out_p):
+        assert op[0] == pytest.approx(oe[0], rel=3e-2) and op[1] == pytest.approx(oe[1], rel=0.3)
+        assert op[2] == pytest.approx(oe[2], rel=0.25)
+    # a replay is a real training step: losses move from step to step and differ between the two batches
+    assert len({round(o[0], 4) for o in out_p}) == len(out_p)
+    d_e, d_p = m_e.flat_p - sd_flat(m_e, sd), m_p.flat_p - sd_flat(m_p, sd)
+    cos = (d_e @ d_p / (d_e.norm() * d_p.norm())).item()
+    assert cos > 0.95 and d_p.norm().item() == pytest.approx(d_e.norm().item(), rel=0.08)
+    assert int(m_p.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == 2 * len(seq)
+    assert (m_p.flat_buf - m_e.flat_buf).norm().item() < 2e-2 * m_e.flat_buf.norm().item()
+    sh = (st_p.teacher.flat_p - st_e.teacher.flat_p).norm() / st_e.teacher.flat_p.norm()
+    assert sh.item() < 1e-3
+    # host time of a replayed step against an eager one (both asynchronous)
+    assert min(host_p[1:]) < 0.8 * min(host_e[1:]), (host_p, host_e)       # ~270 launches here; 3x at the full-size step's 680
+
+
+def sd_flat(m, sd):
+    """The fp32 parameters of a state_dict laid out like m.flat_p (for update-direction comparisons)."""
+    ref = build_like(m)
+    ref.load_state_dict(sd, strict=True)
+    return ref.flat_p.clone()
+
+
+def build_like(m):
+    from regda_amd.models.Encoder import Deeplabv2
+    return Deeplabv2(m.config)

@@ -113,7 +113,9 @@ def conv_flops_probe(step_fn, park_ms=150.0):
         if fused:
             return 'conv_wgrad3x3_kernel<%d, %d>' % (min(W, 64), dil)
         bco, bci = (64 if co <= 64 else 128), (64 if ci <= 64 else 128)
-        wi, wj = {(128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 2)}[(bco, bci)]
+        if bci == 128 and co >= 256 and co % 256 == 0:
+            bco = 256
+        wi, wj = {(256, 128): (4, 2), (128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 2)}[(bco, bci)]
         return 'conv_wgrad_kernel<%d, %d, %d, %d, 3>' % (bco, bci, wi, wj)
 
     def wgrad_grouped(items):

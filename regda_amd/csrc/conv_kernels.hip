@@ -828,6 +828,7 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
     // LDS image: [64 pixel rows][RA bytes], lane-linear per 1 KiB instruction; the 64-byte granules of a
     // row are XOR-swizzled with the row index so that the 4 pixel rows a transposing read touches fall
     // into 4 different 64-byte bank slots (the permutation is applied to the SOURCE address).
+    //   512-byte rows: 2 rows / instruction, slot p = lane & 31, granule' = granule ^ (row & 3)
     //   256-byte rows: 4 rows / instruction, slot p = lane & 15, granule' = granule ^ (row & 3)
     //   128-byte rows: 8 rows / instruction, slot p = lane & 7,  granule' = granule ^ ((row >> 1) & 1)
     constexpr int RPA = 1024 / RA, RPB = 1024 / RB;       // rows per instruction
@@ -838,7 +839,7 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
     const i32x4 rs_a = dma_rsrc(a.dy, (unsigned)((((size_t)a.M - 1) * a.lddy + a.Cout) * 2));
     const i32x4 rs_b = dma_rsrc(a.x, (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2));
     auto swz = [](int row, int slot, int rowbytes) {
-        int f = (rowbytes == 256) ? (row & 3) : ((row >> 1) & 1);
+        int f = (rowbytes >= 256) ? (row & 3) : ((row >> 1) & 1);
         return (((slot >> 2) ^ f) << 2) | (slot & 3);
     };
     int avo[LA], brow[LB], bcolb[LB], bvo[LB];
@@ -903,7 +904,7 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
         bf16x8 af[4][FI], bfr[4][FJ];
         auto tr_pair = [&](const unsigned char* base, int rowbytes, int byte, int r0) {
             const int r1 = r0 + 4;
-            int f0 = (rowbytes == 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (rowbytes == 256) ? (r1 & 3) : ((r1 >> 1) & 1);
+            int f0 = (rowbytes >= 256) ? (r0 & 3) : ((r0 >> 1) & 1), f1 = (rowbytes >= 256) ? (r1 & 3) : ((r1 >> 1) & 1);
             const unsigned char* p0 = base + r0 * rowbytes + ((((byte >> 6) ^ f0) << 6) | (byte & 63));
             const unsigned char* p1 = base + r1 * rowbytes + ((((byte >> 6) ^ f1) << 6) | (byte & 63));
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
@@ -1159,8 +1160,8 @@ static int ilog2_exact(int v) {
     return s;
 }
 
-// kernel families: 0..3 generic <128,128> <128,64> <64,128> <64,64>; 4..9 tap-fused 3x3 <WT,D>
-enum { WK_G128_128 = 0, WK_G128_64, WK_G64_128, WK_G64_64, WK_F64_1, WK_F64_2, WK_F32_1, WK_F32_2, WK_F16_1, WK_F16_2, WK_COUNT };
+// kernel families: 0..4 generic <128,128> <128,64> <64,128> <64,64> <256,128>; 5..10 tap-fused 3x3 <WT,D>
+enum { WK_G128_128 = 0, WK_G128_64, WK_G64_128, WK_G64_64, WK_G256_128, WK_F64_1, WK_F64_2, WK_F32_1, WK_F32_2, WK_F16_1, WK_F16_2, WK_COUNT };
 
 static int wgrad_prepare(const rgda_wgrad_desc& d, WgradArgs& a) {
     if (!d.x || !d.dy || !d.dw) return RGDA_ERR_ARG;
@@ -1192,8 +1193,15 @@ static int wgrad_prepare(const rgda_wgrad_desc& d, WgradArgs& a) {
         }
     }
     int bco = (d.Cout <= 64) ? 64 : 128, bci = (d.Cin <= 64) ? 64 : 128;
+    // wide layers: 256 x 128 result tiles (8 waves of 64 x 64): 1.0 LDS fragment read per MFMA instead of 1.5 and
+    // 48 KB instead of 64 KB of operands through LDS per 4.2 MFLOP -- the 128 x 128 loop is bound by LDS cycles
+    int big = 1;
+    if (const char* e = TUNE_ENV("RGDA_WGRAD_BIG")) big = atoi(e);                        // tuning experiments only
+    // (a 2-stage 256 x 256 tile, MFMA-bound on paper, measured the same step time: 21.71 vs 21.72 ms)
+    if (big && bci == 128 && d.Cout >= 256 && (d.Cout % 256) == 0) bco = 256;
     a.tiles_co = cdiv(d.Cout, bco);
     a.tiles_ci = cdiv(d.Cin, bci);
+    if (bco == 256) return WK_G256_128;
     return (bco == 128) ? (bci == 128 ? WK_G128_128 : WK_G128_64) : (bci == 128 ? WK_G64_128 : WK_G64_64);
 }
 
@@ -1211,7 +1219,7 @@ static inline int wgrad_ktiles(const WgradArgs& a) {
 static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
     int total = 0;
     for (int l = 0; l < g.n; ++l) total += wgrad_tiles(g.a[l]);
-    const int target = (kind >= WK_F64_1) ? 256 : 512;
+    const int target = (kind >= WK_F64_1 || kind == WK_G256_128) ? 256 : 512;     // one workgroup per CU for the 144 KB tiles
     int minkt = 16;
     if (const char* e = TUNE_ENV("RGDA_WGRAD_MINKT")) minkt = atoi(e);                     // tuning experiments only
     int items = 0;
@@ -1231,13 +1239,14 @@ static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
     // keeping a layer's work items on one XCD (one L2) pays where the items of a layer re-read the same rows many
     // times (the taps of the small-channel 3x3 layers in the 64x64 kernel: 297 -> 220 us; tap-fused: 2 %); the
     // grouped 1x1 layers of the 128x128 kernel measured 9 % SLOWER with it (207 -> 225 us), so they keep b -> item b
-    g.remap = (kind != WK_G128_128);
+    g.remap = (kind != WK_G128_128 && kind != WK_G256_128);
     if (const char* e = TUNE_ENV("RGDA_WGRAD_REMAP")) g.remap = atoi(e);                   // tuning experiments only
     switch (kind) {
         case WK_G128_128: conv_wgrad_kernel<128, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
         case WK_G128_64: conv_wgrad_kernel<128, 64, 4, 2><<<items, 512, 0, st>>>(g); break;
         case WK_G64_128: conv_wgrad_kernel<64, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
         case WK_G64_64: conv_wgrad_kernel<64, 64><<<items, 256, 0, st>>>(g); break;
+        case WK_G256_128: conv_wgrad_kernel<256, 128, 4, 2><<<items, 512, 0, st>>>(g); break;
         case WK_F64_1: conv_wgrad3x3_kernel<64, 1><<<items, 256, 0, st>>>(g); break;
         case WK_F64_2: conv_wgrad3x3_kernel<64, 2><<<items, 256, 0, st>>>(g); break;
         case WK_F32_1: conv_wgrad3x3_kernel<32, 1><<<items, 256, 0, st>>>(g); break;

@@ -213,7 +213,11 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     if world > 1 or os.environ.get('RGDA_FORCE_DDP'):       # RGDA_FORCE_DDP=1: exercise the RCCL path on one GPU
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local), rank=rank, world_size=world,
+        # no `device_id=`: binding the process group to the device makes PyTorch initialise the communicator eagerly
+        # AND hook the caching allocator's segments into RCCL -- measured on MI355X at world size 1: every kernel of the
+        # step slows down, 21.2 -> 24.1 ms/step, before a single collective is issued (scripts/dev/dev_ddp_probe2.py).
+        # The lazy form (communicator created by the first collective on the current device) costs nothing.
+        dist.init_process_group('nccl', rank=rank, world_size=world,
                                 init_method=None if 'MASTER_ADDR' in os.environ else 'tcp://127.0.0.1:29533')
     from regda_amd.models.Encoder import Deeplabv2
     from regda_amd.ssl import SSLStep
@@ -286,7 +290,7 @@ def main():
             print('graph capture failed, running eagerly:', repr(e)[:200], file=sys.stderr)
             step._graph = None
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -294,7 +298,7 @@ def main():
     t_host = time.perf_counter() - t0           # host launch work only (the GPU may still be running)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -25,8 +25,8 @@ def _free_port():
 @pytest.fixture()
 def nccl_world1(monkeypatch):
     monkeypatch.setenv('RGDA_FORCE_DDP', '1')
-    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
-                            device_id=torch.device('cuda', torch.cuda.current_device()))
+    # (no device_id=: see bench.py -- the eager, device-bound form slows every kernel of the process down)
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1)
     yield
     torch.cuda.synchronize()
     dist.destroy_process_group()

@@ -202,8 +202,43 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int r = 0; r < NREP; ++r) { s0 += st[(size_t)(2 * r) * C + cc]; s1 += st[(size_t)(2 * r + 1) * C + cc]; }
                 float m = s0 * invM;
+                const float is = 1.f / sqrtf(fmaxf(s1 * invM - m * m, 0.f) + eps);
                 smean[c] = m;
-                sistd[c] = 1.f / sqrtf(fmaxf(s1 * invM - m * m, 0.f) + eps);
+                sistd[c] = is;
+                if (chunk == 0) {
+                    // the first workgroup of a group's channel block also publishes (mean, invstd) for the backward pass;
+                    // group 0's updates the running statistics, group after group (the reference runs src then tgt) --
+                    // here, one channel per thread with all loads independent, not as a serial tail of a few threads
+                    // (that tail, ~3 dependent memory round trips in one workgroup, was half the kernel on small maps)
+                    mi_out[(size_t)grp * 2 * C + cc] = m;
+                    mi_out[(size_t)grp * 2 * C + C + cc] = is;
+                    if (grp == 0 && rm) {
+                        const float unb = (M > 1) ? (float)M / (float)(M - 1) : 1.f;
+                        float gm[8], gv[8];             // groups <= 8 (checked by the host)
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            if (g < groups) {
+                                const float* sg = stats + (size_t)g * NREP * 2 * C;
+                                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                                for (int r = 0; r < NREP; ++r) { t0 += sg[(size_t)(2 * r) * C + cc]; t1 += sg[(size_t)(2 * r + 1) * C + cc]; }
+                                gm[g] = t0 * invM;
+                                gv[g] = fmaxf(t1 * invM - gm[g] * gm[g], 0.f);
+                            }
+                        }
+                        float a = rm[cc], b = rv[cc];
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            if (g < groups) {
+                                a = (1.f - mom) * a + mom * gm[g];
+                                b = (1.f - mom) * b + mom * gv[g] * unb;
+                            }
+                        }
+                        rm[cc] = a;
+                        rv[cc] = b;
+                        if (cc == 0 && nbt) *nbt += groups;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -211,36 +246,11 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
     if (cg >= C) return;
     float mean[8], sc[8], sh[8];
     if (stats) {
-        // one designated workgroup per channel block also publishes (mean, invstd) for the backward pass and
-        // updates the running statistics, group after group
-        float istd[8];
-        const float invM = 1.f / (float)M;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             mean[e] = smean[cvl * 8 + e];
-            istd[e] = sistd[cvl * 8 + e];
-            sc[e] = istd[e] * gamma[cg + e];
+            sc[e] = sistd[cvl * 8 + e] * gamma[cg + e];
             sh[e] = beta[cg + e];
-        }
-        if (chunk == 0 && rl == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                mi_out[(size_t)grp * 2 * C + cg + e] = mean[e];
-                mi_out[(size_t)grp * 2 * C + C + cg + e] = istd[e];
-            }
-            if (grp == 0 && rm) {
-                const float unb = (M > 1) ? (float)M / (float)(M - 1) : 1.f;
-                for (int g = 0; g < groups; ++g) {
-                    float m2[8], i2[8], v2[8];
-                    group_stats(stats, g, C, cg, invM, eps, m2, i2, v2);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        rm[cg + e] = (1.f - mom) * rm[cg + e] + mom * m2[e];
-                        rv[cg + e] = (1.f - mom) * rv[cg + e] + mom * v2[e] * unb;
-                    }
-                }
-                if (cg == 0 && nbt) *nbt += groups;
-            }
         }
     } else {
         mi += (size_t)grp * 2 * C;
@@ -338,7 +348,7 @@ extern "C" int rgda_bn_train_apply(const void* x, int ldx, const float* stats, f
     if (relu_mask && !relu) return RGDA_ERR_ARG;
     if (res && (ldres & 7)) return RGDA_ERR_ARG;
     if (nscale && rows_per_image <= 0) return RGDA_ERR_ARG;
-    if (groups < 1 || (M % groups) || M / groups < 2) return RGDA_ERR_ARG;
+    if (groups < 1 || groups > 8 || (M % groups) || M / groups < 2) return RGDA_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return RGDA_ERR_ARG;
     RowLayout L; int rpbk, bpg; dim3 grid;
     // fatter workgroups than the plain apply: each one first rebuilds its channels' statistics (128 loads/thread)

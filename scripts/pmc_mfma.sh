@@ -1,0 +1,34 @@
+#!/bin/bash
+# MFMA utilisation / wave-state / LDS counters per kernel over a short serial bench run: separate rocprofv3 --pmc passes
+# (kernel trace only), aggregated by kernel name.  Output: gpurun_out/pmc_mfma.txt
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
+P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"
+i=0
+for pass in "$P1" "$P2"; do
+  i=$((i+1)); rm -rf gpurun_out/pmc_m$i
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc_m$i -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --serial --eager --no-h2d > gpurun_out/pmc_m$i.log 2>&1
+done
+python - > gpurun_out/pmc_mfma.txt <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for i in (1, 2):
+    f = glob.glob('gpurun_out/pmc_m%d/**/*counter_collection.csv' % i, recursive=True)
+    seen = collections.Counter()
+    for r in csv.DictReader(open(f[0])):
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')[:52]
+        agg[k][r['Counter_Name'] + ('' if r['Counter_Name'] != 'GRBM_GUI_ACTIVE' else str(i))] += float(r['Counter_Value'])
+        if i == 1 and r['Counter_Name'] == 'SQ_WAVE_CYCLES': cnt[k] += 1
+rows = sorted(agg.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE1', 0))
+print('# MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs); wave-state shares of SQ_WAVE_CYCLES (quad-cycles);')
+print('# LDS: bank-conflict cycles / LDS-active cycles.  Counters summed over all launches of a kernel in the run (2 + 1 steps).')
+print('%-54s %6s %9s %7s %7s %7s %7s %7s %8s' % ('kernel', 'n', 'gui_act/n', 'mfma%', 'wait%', 'istall%', 'active%', 'ldsw%', 'ldsconf%'))
+for k, v in rows[:28]:
+    n = max(cnt[k], 1); ga = v.get('GRBM_GUI_ACTIVE1', 0.0); wc = max(v.get('SQ_WAVE_CYCLES', 0.0), 1.0)
+    print('%-54s %6d %9.0f %7.1f %7.1f %7.1f %7.1f %7.1f %8.1f' % (k, n, ga / n, 100.0 * v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(ga * 1024, 1),
+          100 * v.get('SQ_WAIT_ANY', 0) / wc, 100 * v.get('SQ_WAIT_INST_ANY', 0) / wc, 100 * v.get('SQ_ACTIVE_INST_ANY', 0) / wc,
+          100 * v.get('SQ_WAIT_INST_LDS', 0) / wc, 100.0 * v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 0), 1)))
+PY
+rm -rf gpurun_out/pmc_m1 gpurun_out/pmc_m2
+cat gpurun_out/pmc_mfma.txt

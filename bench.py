@@ -246,24 +246,17 @@ def main():
     batch = make_batch(b=args.batch, size=args.size, seed=2333 + rank, with_soft=not teacher)
     soft = batch.get('soft_t')
     it = [0]
-    # input path (tools/train_ssl_reg.py:200-206 moves every batch to the GPU inside the iteration): two distinct
-    # synthetic batches in pinned host memory, copied per step by a copy stream into double-buffered device slots
-    pf = None
-    if not args.no_h2d:
-        from regda_amd.utils.prefetch import DevicePrefetcher
-        host = [{k: v.cpu() for k, v in batch.items()},
-                {k: v for k, v in make_batch(b=args.batch, size=args.size, seed=4666 + rank, with_soft=not teacher, device='cpu').items()}]
-        pf = DevicePrefetcher(host)
+    pf = [None]         # the input prefetcher, created behind the warm-up (below)
 
     def one():
         i = it[0]
         lr = lr_warmup(1e-2, i, 300) if i < 300 else lr_poly(1e-2, i, 9000, 0.9)   # tools.py:191-207
         it[0] += 1
-        if pf is None:
+        if pf[0] is None:
             return step.step(batch['images_s'], batch['label_s'], batch['images_t'], soft, batch['regs_t'], lr)
-        b = pf.next()
+        b = pf[0].next()
         out = step.step(b['images_s'], b['label_s'], b['images_t'], b.get('soft_t'), b['regs_t'], lr)
-        pf.release()
+        pf[0].release(step.inputs_consumed() if pf[0].single else None)
         return out
 
     for _ in range(args.warmup):
@@ -280,6 +273,16 @@ def main():
         except Exception as e:      # stay eager, say so
             print('plan recording failed, running eagerly:', repr(e)[:300], file=sys.stderr)
             step._plan = None
+    if not args.no_h2d:
+        # input path (tools/train_ssl_reg.py:200-206 moves every batch to the GPU inside the iteration): two distinct
+        # synthetic batches in pinned host memory, copied per step by a copy stream -- straight into the recorded step's
+        # static input buffers once the running step has read them, or into double-buffered slots in eager mode
+        from regda_amd.utils.prefetch import DevicePrefetcher
+        host = [{k: v.cpu() for k, v in batch.items()},
+                make_batch(b=args.batch, size=args.size, seed=4666 + rank, with_soft=not teacher, device='cpu')]
+        pf[0] = DevicePrefetcher(host, into=step.static_inputs() if planned else None)
+        one()
+        torch.cuda.synchronize()
     if world == 1 and args.graph:
         try:        # replay the (static) step as one hipGraph: removes ~20 ms/step of host launch work
             step.capture(batch['images_s'], batch['label_s'], batch['images_t'], soft, batch['regs_t'])
@@ -332,7 +335,7 @@ def main():
         'metric': 'src+tgt 512x512 image-pairs/sec (SSL step)', 'value': value, 'unit': 'pairs/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
-        'data': 'synthetic' + ('' if pf is None else ', H2D per step (%.0f MB pinned -> device on a copy stream)' % (pf.bytes_per_batch / 1e6)),
+        'data': 'synthetic' + ('' if pf[0] is None else ', H2D per step (%.0f MB pinned -> device on a copy stream)' % (pf[0].bytes_per_batch / 1e6)),
         'config': {'workload': f'st.regda.2potsdam SSL step, {args.model} DeepLabV2(PPM), batch {args.batch}+{args.batch} '
                                f'{args.size}x{args.size} per GPU, ' + ('online EMA teacher' if teacher else 'offline soft labels'),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'gflop_per_pair': gflop_pair},

@@ -108,6 +108,17 @@ class SSLStep:
     def release_plan(self):
         self._plan = None
 
+    def static_inputs(self):
+        """The recorded step's input buffers {name: device tensor}: a loader may write the next batch straight into
+        them once `inputs_consumed()` of the running step has passed (regda_amd/utils/prefetch.py)."""
+        assert self._plan is not None or self._graph is not None
+        names = ('images_s', 'label_s', 'images_t', 'soft_t', 'regs_t')
+        return dict(zip(names, self._static))
+
+    def inputs_consumed(self):
+        """Event of the most recently enqueued step: recorded behind the last kernel that reads the step's inputs."""
+        return self._inputs_done.ev
+
     def _replay_plan(self, images_s, label_s, images_t, soft_t, regs_t, lr):
         for dst, src in zip(self._static, (images_s, label_s, images_t, soft_t, regs_t)):
             if dst is not None and src is not dst:
@@ -197,6 +208,9 @@ class SSLStep:
         loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
         loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
         self._mark('label path + losses done')
+        # from here on the step no longer reads its input tensors (images: stem im2col of student and teacher; labels,
+        # soft labels and region maps: the label path and the losses): an input prefetcher may overwrite them
+        self._inputs_done = plan.record_event(main)
         g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
 
         def gather_logit_grads():

@@ -9,13 +9,23 @@ import torch
 
 
 class DevicePrefetcher:
-    def __init__(self, host_batches, device=None, depth=2):
-        """host_batches: list of {name: CPU tensor or None} with identical shapes; cycled through in order."""
-        assert depth >= 2 and host_batches
+    def __init__(self, host_batches, device=None, depth=2, into=None):
+        """host_batches: list of {name: CPU tensor or None} with identical shapes; cycled through in order.
+        into: {name: device tensor} -- stage every batch straight into THESE tensors (one slot: the static input
+        buffers of a recorded step, SSLStep.static_inputs()); `release()` must then be given the event after which the
+        step no longer reads its inputs (SSLStep.inputs_consumed)."""
+        assert host_batches and (into is not None or depth >= 2)
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.host = [{k: (None if v is None else v.contiguous().pin_memory()) for k, v in b.items()} for b in host_batches]
-        self.slots = [{k: (None if v is None else torch.empty_like(v, device=self.device)) for k, v in self.host[0].items()}
-                      for _ in range(depth)]
+        if into is not None:
+            depth = 1
+            self.slots = [{k: into.get(k) for k in self.host[0]}]
+            for k, v in self.host[0].items():
+                assert (v is None) == (self.slots[0][k] is None) and (v is None or (v.shape == self.slots[0][k].shape and v.dtype == self.slots[0][k].dtype)), k
+        else:
+            self.slots = [{k: (None if v is None else torch.empty_like(v, device=self.device)) for k, v in self.host[0].items()}
+                          for _ in range(depth)]
+        self.single = into is not None
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.copied = [None] * depth        # event: the slot holds its batch
         self.consumed = [None] * depth      # event: the step that read the slot has been enqueued and finished with it
@@ -40,10 +50,15 @@ class DevicePrefetcher:
         slot = self.i % len(self.slots)
         torch.cuda.current_stream().wait_event(self.copied[slot])
         self._cur = slot
-        self._stage(self.i + 1)
+        if not self.single:
+            self._stage(self.i + 1)
         self.i += 1
         return self.slots[slot]
 
-    def release(self):
-        """The step consuming the current batch has been enqueued on the current stream."""
-        self.consumed[self._cur] = torch.cuda.current_stream().record_event()
+    def release(self, consumed=None):
+        """The step consuming the current batch has been enqueued on the current stream.  consumed: an event recorded
+        where the step is done READING its inputs (default: the end of everything enqueued so far).  With a single slot
+        the copy of the next batch is started here, behind that event."""
+        self.consumed[self._cur] = consumed if consumed is not None else torch.cuda.current_stream().record_event()
+        if self.single:
+            self._stage(self.i)

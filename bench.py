@@ -319,12 +319,14 @@ def main():
         t_iso.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     if args.phases and rank == 0:
+        saved, step._plan = step._plan, None        # the phase marks are recorded by the eager step
         one()                       # keep the GPU queue primed like in the timed loop
         step.marks = []
         one()
         marks, step.marks = step.marks, None
         one()
         torch.cuda.synchronize()
+        step._plan = saved
         base = marks[0][1]
         for name, ev in marks:
             print('  %+9.3f ms  %s' % (base.elapsed_time(ev), name), file=sys.stderr)
@@ -340,7 +342,11 @@ def main():
                                f'{args.size}x{args.size} per GPU, ' + ('online EMA teacher' if teacher else 'offline soft labels'),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'gflop_per_pair': gflop_pair},
         'pairs_per_sec_per_gpu': value / world,
+        # whole-step MFMA fraction on the REFERENCE's convolution FLOPs (1268 GFLOP/pair with the teacher forward): an
+        # "effective" figure -- the step executes fewer (the head conv is re-associated); the executed-FLOP
+        # fraction is roofline.step_executed_mfma_frac
         'step_mfma_frac': value / world * gflop_pair / (MFMA_PEAK_TFLOPS * 1e3),
+        'step_mfma_frac_basis': 'reference conv FLOPs (BASELINE.md section 2), label path / BN / optimizer time included',
         'loss_source': losses[0], 'loss_target': losses[1], 'hip_graph': graphed, 'plan_replay': planned,
         'host_enqueue_ms_per_step': sorted(t_iso)[1] * 1e3,         # one step enqueued into an idle queue (median of 3)
         'host_loop_ms_per_step': t_host / args.steps * 1e3,         # the timed loop's host side (includes queue back-pressure)
@@ -376,6 +382,8 @@ def main():
                            'algorithmic_mb_per_launch': d['algorithmic_mb'] / d['launches'],
                            'all_conv_kernels': {'achieved': gf / ms, 'frac': gf / ms / MFMA_PEAK_TFLOPS,
                                                 'gflop_per_step': gf, 'ms_per_step': ms},
+                           # conv FLOPs the step actually executes / step time / peak
+                           'step_executed_mfma_frac': gf / (dt / args.steps * 1e3) / MFMA_PEAK_TFLOPS,
                            # BASELINE.json's MFMA target is stated on the 3x3 convolutions (forward + both gradients)
                            'conv3x3': {'achieved': c3['tflops'], 'frac': c3['tflops'] / MFMA_PEAK_TFLOPS,
                                        'unit': 'TFLOP/s', 'gflop_per_step': c3['gflop'], 'ms_per_step': c3['ms']},

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 ctr=$1; shift
 rm -rf gpurun_out/pmc
-rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc -o p -- "$@" > gpurun_out/pmc.log 2>&1
+timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc -o p -- "$@" > gpurun_out/pmc.log 2>&1
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob('gpurun_out/pmc/**/*counter_collection.csv', recursive=True)

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$ctr
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --serial > gpurun_out/pmc_$ctr.log 2>&1
+  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --serial --eager --no-h2d > gpurun_out/pmc_$ctr.log 2>&1
 done
 python - > gpurun_out/pmc_traffic.txt <<'PY'
 import csv, glob, collections

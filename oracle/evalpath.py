@@ -5,8 +5,10 @@ regda/gast/metrics.py:19-65 (`PixelMetricIgnore.summary_all`: per-class IoU / F1
 
 Third-party arithmetic: `ever.api.metric.pixel.PixelMetric` (package `ever`, un-vendored, not installed) -- its
 confusion matrix (scipy coo_matrix of (y_true, y_pred) pairs, rows = truth) and the textbook per-class formulas are
-restated here; PARITY OF precision/recall/F1 ORIENTATION IS UNPINNED (IoU and mIoU, which is all the training driver
-consumes -- train_ssl_reg.py:256-259 -- are symmetric in the two axes).
+restated here; PARITY WITH `ever` ITSELF IS UNPINNED (no source, no vector).  What is pinned: the restatement equals
+scikit-learn's confusion_matrix / jaccard / precision / recall / f1 on random labels with rows = truth
+(tests/test_oracle_golden.py::test_eval_metrics_against_scikit_learn_definitions); IoU and mIoU, which is all the
+training driver consumes (train_ssl_reg.py:256-259), are symmetric in the two axes anyway.
 """
 import numpy as np
 

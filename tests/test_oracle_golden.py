@@ -274,3 +274,30 @@ def test_aspp_model_matches_reference(gold):
     with torch.no_grad():
         probs = model.forward(sd_eval, xs, False, None, 'resnet101')
     np.testing.assert_allclose(probs.numpy(), g['probs'], rtol=1e-3, atol=1e-4)
+
+
+def test_eval_metrics_against_scikit_learn_definitions():
+    """`ever`'s PixelMetric (the base class of PixelMetricIgnore, regda/gast/metrics.py:19-45) is un-vendored and not
+    installed, so no vector of the reference itself exists for the evaluation row.  What CAN be pinned is that the
+    restated confusion matrix and per-class IoU / precision / recall / F1 are the standard definitions with rows =
+    truth: an independent implementation (scikit-learn) on random labels, ignored pixels (label -1) excluded like
+    eval.py:45-48, including a class that never occurs."""
+    from sklearn import metrics as skm
+    from oracle import evalpath
+    rng = np.random.default_rng(11)
+    C = 6
+    y_true = rng.integers(-1, C - 1, size=20000)             # class C-1 never occurs in the truth
+    y_pred = np.where(rng.random(20000) < 0.7, np.maximum(y_true, 0), rng.integers(0, C - 1, size=20000))
+    cm = evalpath.confusion_matrix(y_true, y_pred, C)
+    keep = y_true >= 0
+    ref_cm = skm.confusion_matrix(y_true[keep], y_pred[keep], labels=list(range(C)))
+    assert np.array_equal(cm, ref_cm)
+    iou, f1, prec, rec = evalpath.per_class(cm)
+    labels = list(range(C - 1))
+    np.testing.assert_allclose(iou[:-1], skm.jaccard_score(y_true[keep], y_pred[keep], labels=labels, average=None), rtol=1e-12)
+    np.testing.assert_allclose(prec[:-1], skm.precision_score(y_true[keep], y_pred[keep], labels=labels, average=None), rtol=1e-12)
+    np.testing.assert_allclose(rec[:-1], skm.recall_score(y_true[keep], y_pred[keep], labels=labels, average=None), rtol=1e-12)
+    np.testing.assert_allclose(f1[:-1], skm.f1_score(y_true[keep], y_pred[keep], labels=labels, average=None), rtol=1e-12)
+    assert np.isnan(iou[-1])                                  # 0 / 0 for the absent class, like numpy does in `ever`
+    s = evalpath.summary(cm[:-1, :-1], ignore_labels=[0])
+    assert s['miou'] == np.round(np.mean(np.round(iou[1:-1], 5)), 5)

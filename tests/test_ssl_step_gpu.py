@@ -353,3 +353,44 @@ def sd_flat(m, sd):
 def build_like(m):
     from regda_amd.models.Encoder import Deeplabv2
     return Deeplabv2(m.config)
+
+
+def test_device_prefetcher_delivers_the_host_batches_in_order():
+    """regda_amd/utils/prefetch.py: pinned host batches reach the device unchanged and in order -- through two device slots
+    (eager step) and straight into the recorded step's static input buffers behind its inputs-consumed event."""
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    from regda_amd.utils.prefetch import DevicePrefetcher
+    host = [make_batch(b=2, size=64, seed=s, with_soft=False, device='cpu') for s in (31, 32, 33)]
+    pf = DevicePrefetcher(host, depth=2)
+    assert not pf.single and pf.bytes_per_batch == sum(v.numel() * v.element_size() for v in host[0].values())
+    for i in range(7):
+        b = pf.next()
+        torch.cuda.synchronize()
+        for k, v in host[i % 3].items():
+            assert b[k].dtype == v.dtype and torch.equal(b[k].cpu(), v), (i, k)
+        pf.release()
+    # single-slot mode on a recorded step
+    rt = 'resnet17t'
+    m = build(rt)
+    m.load_state_dict(omodel.init_state_dict(rt, 6, seed=3), strict=True)
+    m.set_drop_masks(torch.ones(4, 512), torch.ones(4, 512))        # no Dropout2d noise in the loss comparison below
+    st = SSLStep(m, torch.zeros(6, 2048), ema_decay=0.9)
+    g0 = {k: v.cuda() for k, v in host[0].items()}
+    st.step(g0['images_s'], g0['label_s'], g0['images_t'], None, g0['regs_t'], 1e-3)
+    st.record_plan(g0['images_s'], g0['label_s'], g0['images_t'], None, g0['regs_t'])
+    pf = DevicePrefetcher(host, into=st.static_inputs())
+    assert pf.single
+    losses = []
+    for i in range(6):
+        b = pf.next()
+        assert b['images_s'] is st.static_inputs()['images_s']
+        out = st.step(b['images_s'], b['label_s'], b['images_t'], None, b['regs_t'], 0.0)      # lr 0: weights stay
+        torch.cuda.synchronize()
+        for k, v in host[i % 3].items():        # the step consumed exactly this batch
+            assert torch.equal(b[k].cpu(), v), (i, k)
+        pf.release(st.inputs_consumed())
+        losses.append(out[0].item())
+    # same weights (lr = 0), same batch -> same source loss up to atomics noise; different batches differ
+    assert losses[0] == pytest.approx(losses[3], rel=2e-2) and losses[1] == pytest.approx(losses[4], rel=2e-2)
+    assert abs(losses[0] - losses[1]) > 1e-3 * abs(losses[0])

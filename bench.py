@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--eager', action='store_true', help='one Python -> ctypes call per launch instead of the recorded launch plan (regda_amd/plan.py, the single-GPU default)')
     ap.add_argument('--no-h2d', action='store_true', help='reuse one device-resident batch instead of staging a fresh pinned host batch per step over a copy stream')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 24.7 vs 24.1 ms)')
+    ap.add_argument('--relu-mask', type=int, default=None, help='tuning: keep ReLU sign bits for units with at least this many channels (model default: all units)')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--phases', action='store_true', help='HIP-event phase marks of one extra step, to stderr')
     ap.add_argument('--align-steps', type=int, default=0, help='also time this many stage-2 ("align", SURVEY 8f.2) '
@@ -235,6 +236,8 @@ def main():
     with torch.no_grad():
         for head in ('layer5', 'layer6'):
             model.convs[f'{head}.conv_last.4'].w.mul_(40.0)
+    if args.relu_mask is not None:
+        model.relu_sign_mask = args.relu_mask
     model.sync_weights()
     if world > 1:       # identical initial weights on every rank
         dist.broadcast(model.flat_p, 0)

@@ -277,9 +277,10 @@ class Deeplabv2(nn.Module):
         # is pending; 0 = one launch per layer
         self.wgrad_group_gflop = 250.0
         # keep ReLU sign bits (1/16 of y) for the backward pass instead of re-reading y, for units with at least this
-        # many channels (0 / False = never, True = always).  Pays only where y is big: the 1024-channel bn3 outputs,
-        # whose BN-backward operands make the fused data-gradient epilogue HBM-bound (-0.1 ms/step)
-        self.relu_sign_mask = 1024
+        # many channels (0 / False = never, 1 / True = always).  Round 1 kept them for the 1024-channel units only; with
+        # the leaner BatchNorm kernels of round 2 every unit pays (A/B on one box: threshold 1024 -> 21.83, 512 -> 21.77,
+        # 256 -> 21.79, all units -> 21.73 ms/step)
+        self.relu_sign_mask = 1
         # PPM heads: apply the tap-shifted bilinear maps in their separable form (csrc/mix_kernels.hip); False = the
         # one-pass sparse maps (rgda_spatial_mix / rgda_spatial_mix_multi), kept as the cross-check
         self.factored_ppm = True

@@ -45,6 +45,7 @@ class SSLStep:
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
         self._graph = None
         self._plan = None
+        self._proto_ready = None
         self.marks = None           # set to [] to collect (name, event) phase marks of the next step (bench --phases)
         self.overlap_comm = overlap_comm
         self.keep_debug = False     # tests: keep the step's target logits / features / refined soft labels (`self.debug`)
@@ -181,6 +182,11 @@ class SSLStep:
         self.last_soft_t = soft_t
         self._mark('joined teacher')
         # ---- label path (a5-a8)
+        def wait_prototypes():           # the previous step's cross-rank average of the prototypes (second stream)
+            if self._proto_ready is not None:
+                main.wait_event(self._proto_ready)
+                self._proto_ready = None
+        plan.host(wait_prototypes)
         if self.refine_label:
             soft, cm = ops.label_refine(feat_t, self.prototypes, t1, t2, soft_t, self.temp, return_ws=True)
             hard = ops.pseudo_select(soft, self.top, self.low, self.ig, classmax_ws=cm, check=False)
@@ -199,11 +205,20 @@ class SSLStep:
             hard = ops.lrh(hard, regs.contiguous(), self.percent, self.C, self.ig, self.max_regions, check=False,
                            ws=self.lrh_ws)
         ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
-        if self.world > 1:      # keep the prototypes identical on every rank
+        if self.world > 1 or self.reducer.force:
+            # keep the prototypes identical on every rank: averaged over the ranks.  Nothing of THIS step
+            # reads them any more (label_refine is done), so the 48 KB all-reduce -- pure latency -- runs on the second
+            # stream next to backward and the next step's label path waits for it
+            side = self.wgrad_stream if self.wgrad_stream is not None else main
+            if side is not main:
+                plan.wait_event(side, plan.record_event(main))
+
             def sync_prototypes():
                 torch.distributed.all_reduce(self.prototypes, group=self.group)
                 self.prototypes.div_(self.world)
-            plan.host(sync_prototypes)
+            with ops.use_stream(side):
+                plan.host(sync_prototypes)
+                plan.host(lambda: setattr(self, '_proto_ready', side.record_event() if side is not main else None))
         # ---- losses + d(loss)/d(logits)
         loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
         loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)

@@ -344,3 +344,53 @@ def test_feature_output_is_differentiable_through_the_module_api():
     b = torch.cat([g.reshape(-1) for g in gref])
     cos = (g_feat @ b / (g_feat.norm() * b.norm())).item()
     assert cos > 0.97 and g_feat.norm().item() == pytest.approx(b.norm().item(), rel=0.05), (cos, g_feat.norm().item(), b.norm().item())
+
+
+def test_resnet101_layerwise_forward_bound():
+    """Every conv + BatchNorm(+ ReLU) unit of ResNet-101 (train mode, 2 BatchNorm groups like the SSL step): the raw
+    conv output `c` and the normalised activation `y` the HIP path stored on its tape, recomputed by torch in fp32
+    from the unit's OWN stored input -- one layer of bf16 rounding each, so the bound is tight where the whole-network
+    comparisons (chaotic over 101 layers) cannot be: relative L2 < 4e-3 for c, < 1e-2 for y."""
+    rt = 'resnet101'
+    m = build(rt)
+    m.load_state_dict(omodel.init_state_dict(rt, 6, seed=7), strict=True)
+    m.train()
+    gen = torch.Generator().manual_seed(23)
+    xs = [torch.randn(2, 3, 128, 128, generator=gen).cuda(), (torch.randn(2, 3, 128, 128, generator=gen) * 1.5).cuda()]
+    T = m.new_tape(groups=2)
+    with torch.no_grad():
+        m._forward_plan(xs, T)
+    torch.cuda.synchronize()
+    worst_c, worst_y, n = (0.0, ''), (0.0, ''), 0
+    for p, inpl, planes, stride, dil, ds in m.blocks:
+        units = [('.1', '.conv1', '.bn1', True), ('.2', '.conv2', '.bn2', True)]
+        if ds:
+            units.append(('.d', '.downsample.0', '.downsample.1', False))
+        for tag, cname, bname, relu in units:
+            conv, bn = m.convs[p + cname], m.bns[p + bname]
+            x, c, y, mi, (N, H, W, Ho, Wo), nscale, rmask = T[p + tag]
+            xt = x[:, :conv.ci].float().reshape(N, H, W, conv.ci).permute(0, 3, 1, 2).cpu()
+            wt = conv.wb.float().reshape(conv.co, conv.k, conv.k, conv.ci).permute(0, 3, 1, 2).cpu()
+            ref_c = F.conv2d(xt, wt, None, conv.stride, conv.pad, conv.dil)
+            got_c = c.float().reshape(N, Ho, Wo, conv.co).permute(0, 3, 1, 2)
+            ec = l2(got_c, ref_c)
+            # BatchNorm per group (source / target halves of the batch) on the STORED conv output
+            cs = got_c.cpu()
+            ref_y = torch.cat([F.batch_norm(cs[g * N // 2:(g + 1) * N // 2], None, None, bn.gamma.cpu(), bn.beta.cpu(), True, 0.1, 1e-5)
+                               for g in range(2)])
+            if relu:
+                ref_y = ref_y.relu()
+            ey = l2(y.float().reshape(N, Ho, Wo, conv.co).permute(0, 3, 1, 2), ref_y)
+            worst_c = max(worst_c, (ec, p + tag))
+            worst_y = max(worst_y, (ey, p + tag))
+            n += 1
+            if rmask is not None and relu:
+                assert torch.equal(unpack_bits(rmask, conv.co), (y.float() > 0).cpu()), p + tag
+    assert n >= 66 + 4
+    assert worst_c[0] < 4e-3, worst_c
+    assert worst_y[0] < 1e-2, worst_y
+
+
+def unpack_bits(mask, C):
+    bits = (mask.cpu().unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1
+    return bits.reshape(mask.shape[0], C).bool()

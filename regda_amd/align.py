@@ -35,6 +35,10 @@ class AlignStep(SSLStep):
     def capture(self, *a, **k):
         raise NotImplementedError('whole-step graph capture is provided for the SSL step only')
 
+    def record_plan(self, *a, **k):
+        raise NotImplementedError('plan replay is provided for the SSL step only (the stage-2 step has host actions that '
+                                  'are not marked for recording)')
+
     def _step(self, images_s, label_s, images_t, soft_t, regs_t):
         m = self.model
         if not m.training:

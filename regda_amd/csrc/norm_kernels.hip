@@ -27,6 +27,7 @@ static RowLayout row_layout(int C) {
 static int reduce_rows_per_block(long long M, const RowLayout& L) {
     int ny = cdiv(L.vpr, L.vpb);
     long long want = 512 / ny;
+    if (const char* e = TUNE_ENV("RGDA_RED_WANT")) want = atoi(e) / ny;     // tuning experiments only
     if (want < 1) want = 1;
     long long rows = (M + want - 1) / want;
     long long minrows = (long long)L.rpb * 4;
@@ -110,6 +111,7 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict_
 extern "C" int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, int C, rgda_stream_t stream) {
     if (!x || !stats || M <= 0 || C <= 0 || (C & 7) || (ldx & 7)) return RGDA_ERR_ARG;
     RowLayout L = row_layout(C);
+    if (L.vpb > 16) { L.vpb = 16; L.rpb = 16; }          // fewer closing atomics per workgroup, see rgda_bn_bwd_reduce
     int rows_per_block = reduce_rows_per_block(M, L);
     dim3 grid(cdiv(M, rows_per_block), cdiv(L.vpr, L.vpb));
     bn_stats_kernel<<<grid, 256, 0, to_stream(stream)>>>((const bf16_t*)x, ldx, stats, M, C, L.vpb, L.rpb, rows_per_block);
@@ -439,6 +441,11 @@ extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy
     if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     hipStream_t st = to_stream(stream);
     RowLayout L = row_layout(C);
+    // 128 channels x 16 row lanes per workgroup: the atomics that end a workgroup are (workgroups x channels each), so
+    // a workgroup that spans a whole 2048-channel row issues 8 x as many as sixteen that split it.  Measured
+    // (scripts/dev/dev_bnred.py, M = 16384, C = 2048): full rows 74 us, 64-vector cap 41, 16-vector cap 30 us
+    if (L.vpb > 16) { L.vpb = 16; L.rpb = 16; }
+    if (const char* e = TUNE_ENV("RGDA_RED_VPB")) { int v = atoi(e); if (v < L.vpb) { L.vpb = v; L.rpb = 256 / v; } }   // tuning only
     const long long Mg = M / groups;
     int rows_per_block = reduce_rows_per_block(Mg * groups, L);
     if (rows_per_block > Mg) rows_per_block = (int)((Mg + L.rpb - 1) / L.rpb * L.rpb);

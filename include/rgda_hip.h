@@ -84,6 +84,14 @@ size_t rgda_label_refine_classmax_offset(int b, int c, int h, int w);
 int rgda_label_refine(const float* feat, const float* protos, const float* p1, const float* p2,
                       const float* soft, float* out, int b, int k, int c, int h, int w, int H,
                       int W, float temp, void* ws, size_t ws_bytes, rgda_stream_t stream);
+/* The other `mode`s of label_refine with label_t_sup=None (alignment.py:199,212-236): `views` bit 0 = prototype view
+ * ('p'), bit 1 = prediction view ('l'), 3 = 'all' (= rgda_label_refine).  A view that is not asked for needs no
+ * inputs: feat / protos may be NULL for views == 2, p1 / p2 for views == 1.  A single prediction tensor
+ * (alignment.py:232-234) is passed as p1 == p2: (s + s) * 0.5 is s exactly. */
+int rgda_label_refine_views(const float* feat, const float* protos, const float* p1, const float* p2,
+                            const float* soft, float* out, int b, int k, int c, int h, int w, int H,
+                            int W, float temp, int views, void* ws, size_t ws_bytes,
+                            rgda_stream_t stream);
 
 /* Aligner.update_prototype(feat, label)  regda/gast/alignment.py:86-90,300-327,456-481.
  * feat NCHW f32 (b,k,h,w); label (b,H,W) int64 with H = 16h, W = 16w;

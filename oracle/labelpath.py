@@ -53,11 +53,16 @@ def label_refine(feat_t, prototypes, preds_t, label_t_soft, refine=True, mode='a
         pw = pw / (pw.max(dim=1, keepdim=True)[0] + 1e-7)                # :222
         weight = weight + pw
     if mode in ('all', 'l'):
-        x1 = F.interpolate(preds_t[0], (H, W), mode='bilinear', align_corners=True)
-        x2 = F.interpolate(preds_t[1], (H, W), mode='bilinear', align_corners=True)
-        lw = (softmax_T(x1, temp, 1) + softmax_T(x2, temp, 1)) * 0.5     # :230-231
+        if isinstance(preds_t, (list, tuple)):
+            x1 = F.interpolate(preds_t[0], (H, W), mode='bilinear', align_corners=True)
+            x2 = F.interpolate(preds_t[1], (H, W), mode='bilinear', align_corners=True)
+            lw = (softmax_T(x1, temp, 1) + softmax_T(x2, temp, 1)) * 0.5     # :230-231
+        else:
+            lw = softmax_T(F.interpolate(preds_t, (H, W), mode='bilinear', align_corners=True), temp, 1)   # :233-234
         lw = lw / (lw.max(dim=1, keepdim=True)[0] + 1e-7)                # :235
         weight = weight + lw
+    if isinstance(weight, int):
+        return label_t_soft                                              # modes 's' / 'n' without superpixels, :260-261
     soft = weight * label_t_soft                                         # :263
     return soft / (soft.sum(dim=1, keepdim=True) + EPS)                  # :288-298
 

@@ -362,7 +362,7 @@ template <int C>
 __global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restrict__ sim, const float* __restrict__ p1,
                                                            const float* __restrict__ p2, const float* __restrict__ soft,
                                                            float* __restrict__ out, float* classmax, int h, int w,
-                                                           int H, int W, float temp) {
+                                                           int H, int W, float temp, int views) {
     // a workgroup walks REFINE_ROWS output rows: the per-class maxima leave as one atomic per class and workgroup
     // (one per row-workgroup was 49 K same-address memory-side atomics, a large part of this kernel's time)
     const int b = blockIdx.z;
@@ -399,6 +399,7 @@ __global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restri
                 const size_t off = ((size_t)b * C + c) * hw;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
+                    if (!(views & (q == 0 ? 1 : 2))) { top[q][c] = bot[q][c] = 0.f; continue; }   // view not asked for
                     const float* p = (q == 0 ? sim : (q == 1 ? p1 : p2)) + off;
                     top[q][c] = __fadd_rn(__fmul_rn(lx.l0, p[ly.i0 * w + lx.i0]), __fmul_rn(lx.l1, p[ly.i0 * w + lx.i1]));
                     bot[q][c] = __fadd_rn(__fmul_rn(lx.l0, p[ly.i1 * w + lx.i0]), __fmul_rn(lx.l1, p[ly.i1 * w + lx.i1]));
@@ -430,7 +431,9 @@ __global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restri
         float tot = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            float wgt = a[c] / (pmax + 1e-7f) + z1[c] / (lmax + 1e-7f);
+            // mode 'all': both views; 'p' / 'l': `weight = 0 + view` (alignment.py:212,223,236)
+            float wgt = (views == 3) ? a[c] / (pmax + 1e-7f) + z1[c] / (lmax + 1e-7f)
+                                     : ((views & 1) ? a[c] / (pmax + 1e-7f) : z1[c] / (lmax + 1e-7f));
             float v = wgt * sv[c];
             o[c] = v;
             tot += v;
@@ -475,9 +478,17 @@ extern "C" size_t rgda_label_refine_workspace(int b, int c, int h, int w) {
 extern "C" int rgda_label_refine(const float* feat, const float* protos, const float* p1, const float* p2,
                                  const float* soft, float* out, int b, int k, int c, int h, int w, int H, int W,
                                  float temp, void* ws, size_t ws_bytes, rgda_stream_t stream) {
-    if (!feat || !protos || !p1 || !p2 || !soft || !out || !ws) return RGDA_ERR_ARG;
+    return rgda_label_refine_views(feat, protos, p1, p2, soft, out, b, k, c, h, w, H, W, temp, 3, ws, ws_bytes, stream);
+}
+
+extern "C" int rgda_label_refine_views(const float* feat, const float* protos, const float* p1, const float* p2,
+                                       const float* soft, float* out, int b, int k, int c, int h, int w, int H, int W,
+                                       float temp, int views, void* ws, size_t ws_bytes, rgda_stream_t stream) {
+    if (views < 1 || views > 3 || !soft || !out || !ws) return RGDA_ERR_ARG;
+    const bool pview = views & 1, lview = views & 2;
+    if ((pview && (!feat || !protos)) || (lview && (!p1 || !p2))) return RGDA_ERR_ARG;
     if (c != 6) return RGDA_ERR_UNSUPPORTED;   // ISPRS: 6 classes (regda/datasets/isprsda.py:18-26)
-    if (b <= 0 || k < 2 || k > 4096 || (k & 3) || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(temp > 0.f))
+    if (b <= 0 || (pview && (k < 2 || k > 4096 || (k & 3))) || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(temp > 0.f))
         return RGDA_ERR_ARG;
     if (ws_bytes < rgda_label_refine_workspace(b, c, h, w)) return RGDA_ERR_WORKSPACE;
     hipStream_t st = to_stream(stream);
@@ -490,9 +501,10 @@ extern "C" int rgda_label_refine(const float* feat, const float* protos, const f
     off += align256((size_t)c * 4);
     float* pc = (float*)(base + off);
     if (hipMemsetAsync(classmax, 0, (size_t)b * c * 4 + 16, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    const int hw = h * w;
+    if (pview) {
     proto_center_kernel<<<c, 256, 0, st>>>(protos, pc, pstd, k);
     RGDA_CHECK_LAUNCH();
-    const int hw = h * w;
     constexpr int PX = 32, SL = 16;
     size_t lds = ((size_t)6 * k + SL * PX * 7) * 4;
     dim3 g1(cdiv(hw, PX), b);
@@ -502,8 +514,9 @@ extern "C" int rgda_label_refine(const float* feat, const float* protos, const f
         return RGDA_ERR_LAUNCH;
     pearson_sim_kernel<6, PX, SL><<<g1, PX * SL, lds, st>>>(feat, pc, pstd, sim, k, hw);
     RGDA_CHECK_LAUNCH();
+    }
     dim3 g2(cdiv(W, 256), cdiv(H, REFINE_ROWS), b);
-    refine_apply_kernel<6><<<g2, 256, 0, st>>>(sim, p1, p2, soft, out, classmax, h, w, H, W, temp);
+    refine_apply_kernel<6><<<g2, 256, 0, st>>>(sim, p1, p2, soft, out, classmax, h, w, H, W, temp, views);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -1,6 +1,6 @@
 """Aligner (prototype EMA + online soft-label re-weighting) -- mirror of the parts of
 regda/gast/alignment.py that sit on the SSL path: label_refine (:194-265, with
-label_t_sup=None as tools/train_ssl_reg.py:214 calls it), update_prototype (:86-90),
+label_t_sup=None as tools/train_ssl_reg.py:214 calls it; every `mode`), update_prototype (:86-90),
 DownscaleLabel (:456-481).  Stage-2 alignment losses are out of scope.
 """
 import torch
@@ -49,14 +49,24 @@ class Aligner:
         return ops.proto_update(feat.detach(), label, self.prototypes, 16, self.ignore_label, 0.75, self.decay)
 
     def label_refine(self, label_t_sup, feat_t, preds_t, label_t_soft, refine=True, mode='all', temp=2.0):
+        """alignment.py:194-265.  Built: every `mode` with label_t_sup=None (the SSL path passes None,
+        tools/train_ssl_reg.py:214) and one or two prediction tensors.  The superpixel view (label_t_sup given, modes
+        'all' / 's') is not."""
         assert mode in ['all', 's', 'p', 'n', 'l']
         if not refine:
             return label_t_soft
-        if label_t_sup is not None or mode != 'all' or not isinstance(preds_t, (list, tuple)):
-            raise NotImplementedError('only the SSL-path call (label_t_sup=None, mode="all", two heads) is built; '
+        if label_t_sup is not None and mode in ('all', 's'):
+            raise NotImplementedError('the superpixel view of label_refine (label_t_sup given) is not built; '
                                       'see DESIGN.md "out of scope"')
-        assert len(preds_t) == 2
-        out, cm = ops.label_refine(feat_t.detach(), self.prototypes, preds_t[0].detach(), preds_t[1].detach(),
-                                   label_t_soft, temp, return_ws=True)
+        if mode in ('s', 'n'):
+            return label_t_soft                  # no view contributes: `weight` stays the int 0 (alignment.py:260-261)
+        if isinstance(preds_t, (list, tuple)):
+            assert len(preds_t) == 2
+            p1, p2 = preds_t
+        else:
+            p1 = p2 = preds_t                    # (s + s) * 0.5 == s: the single-tensor branch, alignment.py:232-234
+        views = {'all': 3, 'p': 1, 'l': 2}[mode]
+        out, cm = ops.label_refine(feat_t.detach(), self.prototypes, p1.detach() if views & 2 else None,
+                                   p2.detach() if views & 2 else None, label_t_soft, temp, return_ws=True, views=views)
         self._classmax_ws = cm       # per-image per-class maxima of the result (reused by the fused trainer)
         return out

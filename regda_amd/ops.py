@@ -104,19 +104,38 @@ def lrh(labels, regions, percent, class_num, ignore_label, max_regions=4096, che
     return out
 
 
-def label_refine(feat, protos, p1, p2, soft, temp=2.0, out=None, return_ws=False):
-    _need_cuda(feat, protos, p1, p2, soft)
-    feat, protos, p1, p2, soft = [t.contiguous().float() for t in (feat, protos, p1, p2, soft)]
-    b, k, h, w = feat.shape
-    c = protos.shape[0]
+def label_refine(feat, protos, p1, p2, soft, temp=2.0, out=None, return_ws=False, views=3):
+    """views: bit 0 = prototype view, bit 1 = prediction view (3 = mode 'all'); inputs of a view that is off may be None."""
+    pview, lview = bool(views & 1), bool(views & 2)
+    assert views in (1, 2, 3)
+    soft = soft.contiguous().float()
+    _need_cuda(soft)
+    b, c = soft.shape[:2]
     H, W = soft.shape[-2:]
-    assert p1.shape == (b, c, h, w) and p2.shape == (b, c, h, w) and soft.shape == (b, c, H, W)
+    k = 4
+    if pview:
+        _need_cuda(feat, protos)
+        feat, protos = feat.contiguous().float(), protos.contiguous().float()
+        k = feat.shape[1]
+        h, w = feat.shape[-2:]
+        assert feat.shape[0] == b and protos.shape == (c, k)
+    if lview:
+        _need_cuda(p1, p2)
+        p1, p2 = p1.contiguous().float(), p2.contiguous().float()
+        h, w = p1.shape[-2:]
+        assert p1.shape == (b, c, h, w) and p2.shape == (b, c, h, w)
+        assert not pview or feat.shape[-2:] == (h, w)
     if out is None:
         out = torch.empty_like(soft)
     L = lib()
-    ws = _ws(L.size('rgda_label_refine_workspace', b, c, h, w), feat.device)
-    L.call('rgda_label_refine', feat.data_ptr(), protos.data_ptr(), p1.data_ptr(), p2.data_ptr(), soft.data_ptr(),
-           out.data_ptr(), b, k, c, h, w, H, W, float(temp), ws.data_ptr(), ws.numel(), _stream())
+    ws = _ws(L.size('rgda_label_refine_workspace', b, c, h, w), soft.device)
+    if views == 3:
+        L.call('rgda_label_refine', feat.data_ptr(), protos.data_ptr(), p1.data_ptr(), p2.data_ptr(), soft.data_ptr(),
+               out.data_ptr(), b, k, c, h, w, H, W, float(temp), ws.data_ptr(), ws.numel(), _stream())
+    else:
+        L.call('rgda_label_refine_views', _p(feat if pview else None), _p(protos if pview else None),
+               _p(p1 if lview else None), _p(p2 if lview else None), soft.data_ptr(), out.data_ptr(), b, k, c, h, w, H, W,
+               float(temp), views, ws.data_ptr(), ws.numel(), _stream())
     if return_ws:
         off = L.size('rgda_label_refine_classmax_offset', b, c, h, w)
         return out, ws[off:]

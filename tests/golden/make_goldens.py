@@ -167,6 +167,12 @@ def gold_refine():
     soft = torch.softmax(torch.randn(b, C, 64, 64) * 3, 1)
     out = al.label_refine(None, feat_t, [p1, p2], soft, refine=True, mode='all', temp=2.0)
     dist = al._pearson_dist(feat_t.permute(0, 2, 3, 1).reshape(-1, k), protos)
+    # the other refine modes with label_t_sup=None, and the single-tensor prediction branch (no random numbers drawn)
+    out_p = al.label_refine(None, feat_t, [p1, p2], soft, refine=True, mode='p', temp=2.0)
+    out_l = al.label_refine(None, feat_t, [p1, p2], soft, refine=True, mode='l', temp=1.5)
+    out_1 = al.label_refine(None, feat_t, p1, soft, refine=True, mode='all', temp=2.0)
+    out_n = al.label_refine(None, feat_t, [p1, p2], soft, refine=True, mode='n', temp=2.0)
+    assert out_n is soft
     feat_s = torch.randn(b, k, h, w)
     lab_s = torch.from_numpy(np.kron(np.random.default_rng(3).integers(-1, 6, size=(b, 4, 4)),
                                      np.ones((16, 16), np.int64)))
@@ -174,7 +180,8 @@ def gold_refine():
     ds = al.update_prototype(feat_s, lab_s)
     # class absent from the batch keeps its old prototype
     save('refine.npz', feat_t=feat_t.numpy(), protos=protos.numpy(), p1=p1.numpy(), p2=p2.numpy(),
-         soft=soft.numpy(), out=out.numpy(), dist=dist.numpy(), feat_s=feat_s.numpy(),
+         soft=soft.numpy(), out=out.numpy(), out_p=out_p.numpy(), out_l=out_l.numpy(), out_1=out_1.numpy(),
+         dist=dist.numpy(), feat_s=feat_s.numpy(),
          lab_s=lab_s.numpy().astype(np.int8), ds=ds.numpy().astype(np.int8),
          protos_new=al.prototypes.numpy())
 

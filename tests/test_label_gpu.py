@@ -115,6 +115,26 @@ def test_label_refine_golden(mods, gold):
     np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=2e-4, atol=2e-6)
 
 
+def test_label_refine_other_modes_golden(mods, gold):
+    """Modes 'p' / 'l' / 'n' / 's' with label_t_sup=None and the single-tensor prediction branch
+    (regda/gast/alignment.py:199,212-236,260-261) against outputs of the reference's own Aligner."""
+    g = gold('refine.npz')
+    al = mods.Aligner(None, feat_channels=64, class_num=6, ignore_label=-1, decay=0.996)
+    al.prototypes = cu(g['protos']).clone()
+    feat, p1, p2, soft = cu(g['feat_t']), cu(g['p1']), cu(g['p2']), cu(g['soft'])
+    for key, preds, mode, temp in (('out_p', [p1, p2], 'p', 2.0), ('out_l', [p1, p2], 'l', 1.5), ('out_1', p1, 'all', 2.0)):
+        out = al.label_refine(None, feat, preds, soft, True, mode, temp)
+        np.testing.assert_allclose(out.cpu().numpy(), g[key], rtol=2e-4, atol=2e-6, err_msg=key)
+    # a single tensor is the two-head kernel fed the same logits twice: bit-identical to passing it as a pair
+    assert torch.equal(al.label_refine(None, feat, p1, soft, True, 'l', 2.0),
+                       al.label_refine(None, feat, [p1, p1], soft, True, 'l', 2.0))
+    for mode in ('n', 's'):
+        assert al.label_refine(None, feat, [p1, p2], soft, True, mode, 2.0) is soft      # no view: returned as is
+    assert al.label_refine(None, feat, [p1, p2], soft, False, 'all', 2.0) is soft
+    with pytest.raises(NotImplementedError):                                              # superpixel view: not built
+        al.label_refine(torch.zeros(2, 1, 64, 64, dtype=torch.int64, device='cuda'), feat, [p1, p2], soft, True, 'all')
+
+
 def test_label_refine_full_size_vs_oracle(mods):
     g = torch.Generator().manual_seed(11)
     b, k, h, w = 2, 2048, 32, 32

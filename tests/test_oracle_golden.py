@@ -66,6 +66,12 @@ def test_label_refine_and_prototypes(gold):
     np.testing.assert_allclose(dist.numpy()[big], d_ref[big], rtol=1e-5, atol=1e-6)
     out = labelpath.label_refine(t('feat_t'), t('protos'), [t('p1'), t('p2')], t('soft'))
     np.testing.assert_allclose(out.numpy(), g['out'], rtol=2e-5, atol=1e-6)
+    # the other modes the reference offers with label_t_sup=None, and the single-tensor prediction branch
+    for key, preds, mode, temp in (('out_p', [t('p1'), t('p2')], 'p', 2.0), ('out_l', [t('p1'), t('p2')], 'l', 1.5),
+                                   ('out_1', t('p1'), 'all', 2.0)):
+        o = labelpath.label_refine(t('feat_t'), t('protos'), preds, t('soft'), True, mode, temp)
+        np.testing.assert_allclose(o.numpy(), g[key], rtol=2e-5, atol=1e-6, err_msg=key)
+    assert labelpath.label_refine(t('feat_t'), t('protos'), [t('p1'), t('p2')], t('soft'), True, 'n') is not None
     new, ds = labelpath.update_prototype(t('feat_s'), t('lab_s').long(), t('protos'))
     assert np.array_equal(ds.numpy(), g['ds'].astype(np.int64))
     np.testing.assert_allclose(new.numpy(), g['protos_new'], rtol=1e-5, atol=1e-6)

@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--serial', action='store_true', help='one stream only (clean per-kernel profiles)')
     ap.add_argument('--no-comm-overlap', action='store_true', help='all-reduce the whole gradient after backward instead of bucket by bucket during it')
-    ap.add_argument('--eager', action='store_true', help='one Python -> ctypes call per launch instead of the recorded launch plan (regda_amd/plan.py, the single-GPU default)')
+    ap.add_argument('--eager', action='store_true', help='one Python -> ctypes call per launch instead of the recorded launch plan (regda_amd/plan.py, the default)')
     ap.add_argument('--no-h2d', action='store_true', help='reuse one device-resident batch instead of staging a fresh pinned host batch per step over a copy stream')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 24.7 vs 24.1 ms)')
     ap.add_argument('--relu-mask', type=int, default=None, help='tuning: keep ReLU sign bits for units with at least this many channels (model default: all units)')
@@ -266,7 +266,7 @@ def main():
         one()
     torch.cuda.synchronize()
     graphed = planned = False
-    if world == 1 and not args.graph and not args.eager:
+    if not args.graph and not args.eager:      # (the collectives of a multi-GPU step are host actions of the plan)
         try:        # the step is a static launch sequence: replay it below the ABI (one C loop per segment)
             step.record_plan(batch['images_s'], batch['label_s'], batch['images_t'], soft, batch['regs_t'])
             it[0] += 1

@@ -93,3 +93,58 @@ def test_class_balance_counts_go_through_the_process_group(nccl_world1):
     freq = 0.01 * cnt / (cnt.sum() + 1e-7) + 0.99 * torch.ones(6, device='cuda') / 6
     torch.testing.assert_close(cb.freq, freq, rtol=1e-6, atol=1e-7)
     assert w.shape == (6,) and float(w.max()) <= 1.0
+
+
+def test_recorded_plan_replays_the_collectives(nccl_world1):
+    """The multi-GPU step as a recorded launch plan (bench.py's default at every world size): the bucketed gradient
+    all-reduces, their stream waits and the prototype average are host actions of the plan and are re-issued by every
+    replay -- counted here through the reducer, and the replayed steps track the eager ones."""
+    import torch.distributed as dist_mod
+    from regda_amd.models.Encoder import Deeplabv2
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=2)
+    ones = torch.ones(4, 512)
+    b = make_batch(b=2, size=128, seed=13)
+    calls = []
+    real = dist_mod.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.numel())
+        return real(t, *a, **k)
+
+    def run(use_plan):
+        m = Deeplabv2(dict(backbone=dict(resnet_type=rt, output_stride=16, pretrained=False), multi_layer=True,
+                           cascade=False, use_ppm=True, ppm=dict(num_classes=6, use_aux=False, fc_dim=2048),
+                           inchannels=2048, num_classes=6, is_ins_norm=True))
+        m.load_state_dict(sd, strict=True)
+        m.set_drop_masks(ones, ones)
+        st = SSLStep(m, torch.randn(6, 2048, generator=torch.Generator().manual_seed(3)), bucket_elems=1 << 20)
+        outs = []
+        for i in range(4):
+            if use_plan and i == 1:
+                st.record_plan(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'])
+                outs.append([float(x.item()) for x in st._out])
+                continue
+            outs.append([float(x.item()) for x in st.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'],
+                                                          b['regs_t'], lr=1e-3)])
+        torch.cuda.synchronize()
+        return m, st, outs
+
+    dist_mod.all_reduce = counting
+    try:
+        m_e, st_e, out_e = run(False)
+        n_eager = len(calls)
+        del calls[:]
+        m_p, st_p, out_p = run(True)
+        n_plan = len(calls)
+    finally:
+        dist_mod.all_reduce = real
+    per_step = len(st_e.reducer.buckets) + 1                    # gradient buckets + the prototype average
+    assert per_step >= 4 and n_eager == 4 * per_step
+    assert st_p._plan is not None and n_plan == n_eager         # every replay issued every collective again
+    for oe, op in zip(out_e, out_p):
+        assert op[0] == pytest.approx(oe[0], rel=5e-2) and op[2] == pytest.approx(oe[2], rel=0.3)
+    assert ((m_p.flat_p - m_e.flat_p).norm() / m_e.flat_p.norm()).item() < 1e-3
+    assert ((st_p.prototypes - st_e.prototypes).norm() / st_e.prototypes.norm()).item() < 5e-3

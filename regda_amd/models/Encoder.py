@@ -418,7 +418,11 @@ class Deeplabv2(nn.Module):
         self._wt_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._wt_blocks = blk
         self.stem_wb = torch.zeros(64, 1, STEM_KP, dtype=BF, device=dev)
-        self.stem_gtmp = torch.zeros(64, 1, STEM_KP, device=dev)
+        # fp32 landing buffers of the weight gradients that are not written straight into the flat gradient (stem, head
+        # slices): ONE arena, zeroed by one fill at the start of every backward pass
+        n_head = 0 if self.head_kind == 'aspp' else 2 * (512 * 9 * 2048 + len(POOL_SCALES) * 9 * 512 * 512)
+        self.grad_arena = torch.zeros(64 * STEM_KP + n_head, device=dev)
+        self.stem_gtmp = self.grad_arena[:64 * STEM_KP].view(64, 1, STEM_KP)
         # head 3x3 conv (4096 -> 512) split into its feature half and the four PPM branches (see ppm_tap_matrix):
         #   wfeat [512][9][2048]            the feature-map half, contiguous
         #   wz[i] [9*512][1][512]           Z = q_i @ W_tap^T for all nine taps at once (a 1x1 conv, Cout = 4608)
@@ -429,14 +433,24 @@ class Deeplabv2(nn.Module):
         if self.head_kind == 'aspp':
             self._build_aspp_weights()
             return
+        apos = [64 * STEM_KP]
+
+        def arena(*shape):
+            n = 1
+            for d in shape:
+                n *= d
+            t = self.grad_arena[apos[0]:apos[0] + n].view(*shape)
+            apos[0] += n
+            return t
         for head in ('layer5', 'layer6'):
             self.head_w[head] = {
                 'wfeat': torch.zeros(512, 9, 2048, dtype=BF, device=dev),
                 'wz': [torch.zeros(9 * 512, 1, 512, dtype=BF, device=dev) for _ in POOL_SCALES],
                 'wzt': [torch.zeros(512, 1, 9 * 512, dtype=BF, device=dev) for _ in POOL_SCALES],
-                'gfeat': torch.zeros(512, 9, 2048, device=dev),
-                'gz': [torch.zeros(9 * 512, 1, 512, device=dev) for _ in POOL_SCALES],
+                'gfeat': arena(512, 9, 2048),
+                'gz': [arena(9 * 512, 1, 512) for _ in POOL_SCALES],
             }
+        assert apos[0] == self.grad_arena.numel()
         self._hw_ready = None
         # the head slices are two more tables for the same kernel: the forward operands (feature half + stacked tap
         # filters; also all the EMA teacher needs) and the transposes for the gradient w.r.t. the PPM branches
@@ -755,7 +769,6 @@ class Deeplabv2(nn.Module):
         gview = conv.g.view(512, 9, 4096)
         # weight gradients land in contiguous fp32 buffers (the kernels write [Cout][taps][Cin] densely) and are
         # added into the strided slices of the real gradient behind the grouped launch
-        plan.host(hw['gfeat'].zero_)
         T['wgrad_pending'].append((xn, dc, hw['gfeat'], N, h, w, h, w, 3, 3, 1, 1, 1))
         T['wgrad_pending_flop'] += 2.0 * M * 512 * 2048 * 9
         T['wgrad_post'].append(lambda gv=gview, t=hw['gfeat']: gv[:, :, :2048].add_(t))
@@ -777,7 +790,6 @@ class Deeplabv2(nn.Module):
             dzr = dz.view(N * s * s, 9 * 512)
             dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
             ops.conv2d(dzr, hw['wzt'][i], dq, N, s, s, s, s, 1, 1, 1, 0, 1)
-            plan.host(hw['gz'][i].zero_)
             T['wgrad_pending'].append((qs[i], dzr, hw['gz'][i], N, s, s, s, s, 1, 1, 1, 0, 1))
             T['wgrad_post'].append(lambda gv=gview, t=hw['gz'][i], i=i:
                                    gv[:, :, 2048 + 512 * i: 2048 + 512 * (i + 1)].add_(t.view(9, 512, 512).permute(1, 0, 2)))
@@ -877,7 +889,6 @@ class Deeplabv2(nn.Module):
         ops.bn_bwd_apply(g, y if (relu and rmask is None) else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm,
                          bn.dgamma, bn.dbeta, nscale, Ho * Wo, groups=G, relu_mask=rmask)
         if stem:
-            plan.host(self.stem_gtmp.zero_)
             ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
             ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
             return None, gm
@@ -983,15 +994,15 @@ class Deeplabv2(nn.Module):
         mats = self._mats(h, w)
         if T is not None:
             # Dropout2d(0.1) keep-masks, scaled: drawn from torch's generator at every step (a host action of a plan)
-            masks = [torch.empty(N, 512, device=dev) for _ in range(2)]
+            both = torch.empty(2, N, 512, device=dev)
+            masks = [both[0], both[1]]
 
             def draw():
-                for i, mk in enumerate(masks):
-                    if self._drop_override is not None:
-                        m = self._drop_override[i]
+                if self._drop_override is not None:
+                    for mk, m in zip(masks, self._drop_override):
                         mk.copy_(m.to(dev).float().repeat(N // m.shape[0], 1) / 0.9)
-                    else:
-                        mk.copy_((torch.rand(N, 512, device=dev) >= 0.1).float() / 0.9)
+                else:                       # three in-place kernels for both heads (ten when drawn head by head)
+                    both.uniform_().ge_(0.1).mul_(1.0 / 0.9)
             plan.host(draw)
         else:
             masks = [None, None]
@@ -1053,6 +1064,7 @@ class Deeplabv2(nn.Module):
                 self._wt_ready = None
         plan.host(wait_transposed_weights)
         T['on_progress'] = on_progress
+        plan.host(self.grad_arena.zero_)
         T['wgrad_pending'], T['wgrad_pending_flop'], T['wgrad_post'] = [], 0.0, []
         T['sums_pool'] = _StatsPool(sum(T['groups'] * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)
         C, B = self.convs, self.bns

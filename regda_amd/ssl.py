@@ -43,6 +43,7 @@ class SSLStep:
         bounds = model.param_boundaries()
         self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
+        self.source_side = overlap_wgrad    # source half of the label path on the second stream
         self._graph = None
         self._plan = None
         self._proto_ready = None
@@ -151,7 +152,6 @@ class SSLStep:
             m.train()
         self._mark('step start')
         m._maybe_sync()
-        plan.host(m.flat_g.zero_)
         # source and target batch go through the network TOGETHER (twice the GEMM rows per launch), as two
         # BatchNorm groups: statistics, running-stat updates and gradients stay per domain like the
         # reference's two separate forward calls (train_ssl_reg.py:210-212)
@@ -171,6 +171,11 @@ class SSLStep:
             with ops.use_stream(self.wgrad_stream):
                 soft_t = self.teacher_probs(images_t, snapshot=False)
                 self._mark('teacher forward done (side)', self.wgrad_stream)
+                # the gradient buffer is cleared here, behind the teacher and next to the student's forward (nothing
+                # writes it before the main stream has joined this one), instead of ahead of the student's first kernel
+                plan.host(m.flat_g.zero_)
+        else:
+            plan.host(m.flat_g.zero_)
         x1, x2, feat = m._forward_plan([images_s.contiguous().float(), images_t.contiguous().float()], T)
         self._mark('student forward done')
         s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
@@ -187,12 +192,25 @@ class SSLStep:
                 main.wait_event(self._proto_ready)
                 self._proto_ready = None
         plan.host(wait_prototypes)
+        # the source half of the label path (source loss, prototype update) is independent of the target chain
+        # (refine -> select -> LRH -> target loss): with a second stream it runs there, next to the target chain
+        side = self.wgrad_stream if self.source_side else None
+        if side is not None:
+            plan.wait_event(side, plan.record_event(main))
+            with ops.use_stream(side):
+                loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
         if self.refine_label:
             soft, cm = ops.label_refine(feat_t, self.prototypes, t1, t2, soft_t, self.temp, return_ws=True)
             hard = ops.pseudo_select(soft, self.top, self.low, self.ig, classmax_ws=cm, check=False)
         else:
             soft = soft_t
             hard = ops.pseudo_select(soft_t, self.top, self.low, self.ig, check=False)
+        if side is not None:
+            # update_prototype rewrites the prototypes label_refine has just read
+            plan.wait_event(side, plan.record_event(main))
+            with ops.use_stream(side):
+                ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
+            source_done = plan.record_event(side)
         if self.keep_debug:
             self.debug = dict(t1=t1, t2=t2, s1=s1, s2=s2, feat_t=feat_t, feat_s=feat_s, soft_in=soft_t, soft=soft,
                               hard_selected=hard)
@@ -204,24 +222,28 @@ class SSLStep:
                 self.lrh_ws = torch.empty(need, dtype=torch.uint8, device=m.device)
             hard = ops.lrh(hard, regs.contiguous(), self.percent, self.C, self.ig, self.max_regions, check=False,
                            ws=self.lrh_ws)
-        ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
+        if side is None:
+            ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
         if self.world > 1 or self.reducer.force:
             # keep the prototypes identical on every rank: averaged over the ranks.  Nothing of THIS step
             # reads them any more (label_refine is done), so the 48 KB all-reduce -- pure latency -- runs on the second
             # stream next to backward and the next step's label path waits for it
-            side = self.wgrad_stream if self.wgrad_stream is not None else main
-            if side is not main:
-                plan.wait_event(side, plan.record_event(main))
+            pside = self.wgrad_stream if self.wgrad_stream is not None else main
+            if pside is not main and side is None:
+                plan.wait_event(pside, plan.record_event(main))
 
             def sync_prototypes():
                 torch.distributed.all_reduce(self.prototypes, group=self.group)
                 self.prototypes.div_(self.world)
-            with ops.use_stream(side):
+            with ops.use_stream(pside):
                 plan.host(sync_prototypes)
-                plan.host(lambda: setattr(self, '_proto_ready', side.record_event() if side is not main else None))
+                plan.host(lambda: setattr(self, '_proto_ready', pside.record_event() if pside is not main else None))
         # ---- losses + d(loss)/d(logits)
-        loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
+        if side is None:
+            loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
         loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
+        if side is not None:
+            plan.wait_event(main, source_done)       # source loss, its logit gradients, the new prototypes
         self._mark('label path + losses done')
         # from here on the step no longer reads its input tensors (images: stem im2col of student and teacher; labels,
         # soft labels and region maps: the label path and the losses): an input prefetcher may overwrite them

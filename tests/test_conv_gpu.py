@@ -185,9 +185,11 @@ def test_stem_im2col_columns_exact(ops, N, H, W):
     assert float(got[:, 147:].abs().max()) == 0.0
 
 
-def test_batchnorm_fwd_bwd(ops):
+@pytest.mark.parametrize('N,C,H,W', [(4, 64, 8, 8), (2, 256, 8, 8), (2, 2048, 4, 4), (3, 72, 5, 7), (2, 1024, 16, 16)])
+def test_batchnorm_fwd_bwd(ops, N, C, H, W):
+    """Standalone statistics / apply / backward-reduce / backward-apply kernels against torch autograd; the wide rows
+    (C > 128) are split over several 128-channel workgroups, C = 72 leaves a partial channel vector block."""
     g = torch.Generator().manual_seed(2)
-    N, C, H, W = 4, 64, 8, 8
     M = N * H * W
     x = rbf(torch.randn(N, C, H, W, generator=g) * 2 + 0.5)
     res = rbf(torch.randn(N, C, H, W, generator=g))

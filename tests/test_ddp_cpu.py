@@ -21,6 +21,16 @@ def test_bucket_plan_covers_buffer_in_reverse():
     assert make_buckets([], 10, 4) == [(0, 10)]
     # every bucket except the last-issued reaches the minimum size
     assert all(e - s >= 200 for s, e in b[:-1])
+    # the last-issued bucket (first layers: final only when backward ends) is kept short when a cut allows it
+    b = make_buckets([100, 300, 350, 900], 1000, 200, tail_elems=120)
+    assert b[-1] == (0, 100) and b[-2][0] == 100 and sum(e - s for s, e in b) == 1000
+    for (a0, a1), (b0, b1) in zip(b, b[1:]):
+        assert b1 == a0 and a0 < a1
+    assert make_buckets([100, 300], 1000, 250, tail_elems=50) == [(300, 1000), (0, 300)]      # no cut that short
+    # ResNet-101-like layout (elements): stem + layer1 + layer2 = 1.44 M, layer3 blocks of 1.1 M, layer4, two heads
+    cuts = [9408, 225000, 1440000] + [1440000 + 1117000 * i for i in range(1, 24)] + [27000000, 42000000, 65000000]
+    b = make_buckets(cuts, 88653900, 12 << 20)
+    assert b[-1] == (0, 1440000) and all(e - s >= (12 << 20) for s, e in b[:-2])
 
 
 def _free_port():

@@ -134,3 +134,37 @@ extern "C" int probe_run_store(int mode, int blocks, int threads, void* dst, con
     else probe_store<3><<<blocks, threads, 0, st>>>((pf4*)dst, (const pf4*)src, nvec);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// Sustained matrix-pipe rate: every wave issues `iters` x 8 independent v_mfma_f32_32x32x16_bf16 on operands it
+// loaded once (no memory or LDS traffic inside the loop).  `seed` words are the operands (random bf16 data or zeros:
+// the clock the chip sustains depends on the data).  out gets one value per wave so nothing is optimised away.
+__global__ void __launch_bounds__(512) probe_mfma_rate(const unsigned* seed, float* out, int iters) {
+    const int l = threadIdx.x & 63;
+    u16x8 a[2], b[4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 8; ++j) a[i][j] = (unsigned short)seed[(l * 16 + i * 8 + j) & 4095];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) b[i][j] = (unsigned short)(seed[(l * 32 + i * 8 + j + 1024) & 4095] >> 16);
+    f32x16 acc[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                                    __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j)
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (l == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = s;
+}
+
+extern "C" int probe_run_mfma_rate(const void* seed, void* out, int blocks, int threads, int iters, void* stream) {
+    probe_mfma_rate<<<blocks, threads, 0, (hipStream_t)stream>>>((const unsigned*)seed, (float*)out, iters);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

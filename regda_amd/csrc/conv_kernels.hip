@@ -111,6 +111,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             }
         }
     __syncthreads();
+    if (a.dbg && t == 0) a.dbg[(16384 + blockIdx.x) * 4 + 0] = __builtin_readcyclecounter();
     constexpr int VPR = BC / 8;              // 16-byte vectors per C row
     constexpr int RPP = NT / VPR;            // rows per pass
     const int cv = t % VPR, rr = t / VPR;
@@ -201,6 +202,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             *(u16x8*)(a.y + (size_t)m * a.ldy + co) = val;
         }
     }
+    if (a.dbg && t == 0) a.dbg[(16384 + blockIdx.x) * 4 + 1] = __builtin_readcyclecounter();
     if (a.stats && flush) {
         // lanes with equal cv inside a wave: strides VPR, 2*VPR, ... < 64
 #pragma unroll
@@ -218,6 +220,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             }
         }
         __syncthreads();
+        if (a.dbg && t == 0) a.dbg[(16384 + blockIdx.x) * 4 + 2] = __builtin_readcyclecounter();
         if (t < 2 * BC) {
             int which = t / BC, c = t % BC;
             float tot = 0.f;

@@ -23,6 +23,9 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_PAIR_STUDENT = 1087.0     # (fwd + dgrad + wgrad) x (src + tgt) conv FLOPs
 GFLOP_PER_PAIR_TEACHER = 181.17     # + one eval forward of the EMA teacher on the target image
 MFMA_PEAK_TFLOPS = 2500.0       # bf16 dense, MI355X_MICROARCH.md
+# what the matrix pipes sustain on N(0,1) bf16 operands with no data movement at all (2440 on all-zero operands):
+# measured, scripts/dev/dev_mfma_ceiling.py -> profiles/r02_mfma_ceiling.txt.  Reported next to the nominal peak only.
+MFMA_SUSTAINED_TFLOPS = 1810.0
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 achievable)
 
 
@@ -389,7 +392,11 @@ def main():
                            'step_executed_mfma_frac': gf / (dt / args.steps * 1e3) / MFMA_PEAK_TFLOPS,
                            # BASELINE.json's MFMA target is stated on the 3x3 convolutions (forward + both gradients)
                            'conv3x3': {'achieved': c3['tflops'], 'frac': c3['tflops'] / MFMA_PEAK_TFLOPS,
+                                       'frac_of_sustained': c3['tflops'] / MFMA_SUSTAINED_TFLOPS,
                                        'unit': 'TFLOP/s', 'gflop_per_step': c3['gflop'], 'ms_per_step': c3['ms']},
+                           'mfma_sustained_peak': {'value': MFMA_SUSTAINED_TFLOPS, 'unit': 'TFLOP/s',
+                                                   'what': 'back-to-back v_mfma_f32_32x32x16_bf16 on N(0,1) operands, no '
+                                                           'memory traffic (2440 on zeros); profiles/r02_mfma_ceiling.txt'},
                            'by_kernel': kern}
     if rank == 0 and world == 1 and args.align_steps > 0:
         from regda_amd.align import AlignStep

@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--no-comm-overlap', action='store_true', help='all-reduce the whole gradient after backward instead of bucket by bucket during it')
     ap.add_argument('--eager', action='store_true', help='one Python -> ctypes call per launch instead of the recorded launch plan (regda_amd/plan.py, the default)')
     ap.add_argument('--no-h2d', action='store_true', help='reuse one device-resident batch instead of staging a fresh pinned host batch per step over a copy stream')
-    ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.2: 24.7 vs 24.1 ms)')
+    ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than the recorded plan on ROCm 7.2: 22.4 vs 21.0 ms/step)')
     ap.add_argument('--relu-mask', type=int, default=None, help='tuning: keep ReLU sign bits for units with at least this many channels (model default: all units)')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--phases', action='store_true', help='HIP-event phase marks of one extra step, to stderr')

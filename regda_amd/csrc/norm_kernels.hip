@@ -46,9 +46,32 @@ static __device__ __forceinline__ void cvt8(const u16x8& v, float (&f)[8]) {
     for (int e = 0; e < 8; ++e) f[e] = bf2f(v[e]);
 }
 // rows handled per thread per batch in the streaming kernels: all loads of a batch are issued before the first
-// use, so every wave keeps 4 (x up to 3 operands) 16-byte loads in flight
+// use, so every wave keeps ROW_BATCH (x up to 3 operands) 16-byte loads in flight.  Per kernel (whole-step A/B on one
+// box, scripts/dev/multi_ab.sh): the forward apply is flat between 3 and 4 (8: +0.4 ms); the backward apply, which
+// streams three operands, wants 2 (1: +0.25, 3: +0.1, 4: +0.25 ms -- the registers of a deeper batch cost occupancy)
 #ifndef ROW_BATCH
 #define ROW_BATCH 4
+#endif
+#ifndef RB_BWD
+#define RB_BWD 2
+#endif
+#ifndef RB_APPLY
+#define RB_APPLY ROW_BATCH
+#endif
+#ifndef RB_REDUCE
+#define RB_REDUCE ROW_BATCH
+#endif
+#ifndef RB_BWD
+#define RB_BWD ROW_BATCH
+#endif
+#ifndef RB_INORM
+#define RB_INORM ROW_BATCH
+#endif
+#ifndef RB_MIX
+#define RB_MIX ROW_BATCH
+#endif
+#ifndef RB_CLS
+#define RB_CLS ROW_BATCH
 #endif
 // sign mask of 8 packed bf16 values: bit e = [value e > 0]
 static __device__ __forceinline__ unsigned char relu_bits(const uint4& v) {
@@ -265,10 +288,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
     }
     long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
-    for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
-        u16x8 xv[ROW_BATCH], rv[ROW_BATCH];
+    for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * RB_APPLY) {
+        u16x8 xv[RB_APPLY], rv[RB_APPLY];
 #pragma unroll
-        for (int u = 0; u < ROW_BATCH; ++u) {
+        for (int u = 0; u < RB_APPLY; ++u) {
             const long long r = rb + (long long)u * rpb;
             if (r < r1) {
                 xv[u] = *(const u16x8*)(x + r * ldx + cg);
@@ -276,7 +299,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
             }
         }
 #pragma unroll
-        for (int u = 0; u < ROW_BATCH; ++u) {
+        for (int u = 0; u < RB_APPLY; ++u) {
             const long long r = rb + (long long)u * rpb;
             if (r >= r1) break;
             float f[8];
@@ -387,11 +410,11 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
         for (int e = 0; e < 8; ++e) { mean[e] = mi[cg + e]; istd[e] = mi[C + cg + e]; }
         long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
         long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
-        for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
-            u16x8 gv[ROW_BATCH], xv[ROW_BATCH], yv[ROW_BATCH];
-            unsigned mb[ROW_BATCH];
+        for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * RB_REDUCE) {
+            u16x8 gv[RB_REDUCE], xv[RB_REDUCE], yv[RB_REDUCE];
+            unsigned mb[RB_REDUCE];
 #pragma unroll
-            for (int u = 0; u < ROW_BATCH; ++u) {
+            for (int u = 0; u < RB_REDUCE; ++u) {
                 const long long r = rb + (long long)u * rpb;
                 if (r < r1) {
                     gv[u] = *(const u16x8*)(g + r * ldg + cg);
@@ -403,7 +426,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                 }
             }
 #pragma unroll
-            for (int u = 0; u < ROW_BATCH; ++u) {
+            for (int u = 0; u < RB_REDUCE; ++u) {
                 const long long r = rb + (long long)u * rpb;
                 if (r >= r1) break;
                 float gf[8], xf[8];
@@ -511,11 +534,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     }
     long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
-    for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * ROW_BATCH) {
-        u16x8 gv[ROW_BATCH], xv[ROW_BATCH], yv[ROW_BATCH];
-        unsigned mb[ROW_BATCH];
+    for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * RB_BWD) {
+        u16x8 gv[RB_BWD], xv[RB_BWD], yv[RB_BWD];
+        unsigned mb[RB_BWD];
 #pragma unroll
-        for (int u = 0; u < ROW_BATCH; ++u) {
+        for (int u = 0; u < RB_BWD; ++u) {
             const long long r = rb + (long long)u * rpb;
             if (r < r1) {
                 gv[u] = *(const u16x8*)(g + r * ldg + cg);
@@ -527,7 +550,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             }
         }
 #pragma unroll
-        for (int u = 0; u < ROW_BATCH; ++u) {
+        for (int u = 0; u < RB_BWD; ++u) {
             const long long r = rb + (long long)u * rpb;
             if (r >= r1) break;
             float gf[8], xf[8];
@@ -679,13 +702,13 @@ __global__ void __launch_bounds__(256) instnorm_fwd_kernel(const bf16_t* __restr
     const bf16_t* xb = x + (size_t)n * HW * ldx;
     float s[8] = {0}, q[8] = {0};
     if (cok)
-        for (int pb = rl; pb < HW; pb += 32 * ROW_BATCH) {           // ROW_BATCH loads in flight per thread
-            u16x8 v[ROW_BATCH];
+        for (int pb = rl; pb < HW; pb += 32 * RB_INORM) {           // RB_INORM loads in flight per thread
+            u16x8 v[RB_INORM];
 #pragma unroll
-            for (int u = 0; u < ROW_BATCH; ++u)
+            for (int u = 0; u < RB_INORM; ++u)
                 if (pb + u * 32 < HW) v[u] = *(const u16x8*)(xb + (size_t)(pb + u * 32) * ldx + cg);
 #pragma unroll
-            for (int u = 0; u < ROW_BATCH; ++u) {
+            for (int u = 0; u < RB_INORM; ++u) {
                 if (pb + u * 32 >= HW) break;
                 float f[8];
                 cvt8(v[u], f);
@@ -892,17 +915,17 @@ __global__ void __launch_bounds__(256) spatial_mix_kernel(const bf16_t* __restri
     }
     float acc[8] = {0};
     if (cok)
-        for (int jb = lo + sl; jb <= hi; jb += SL * ROW_BATCH) {
-            float m[ROW_BATCH];
-            u16x8 v[ROW_BATCH];
+        for (int jb = lo + sl; jb <= hi; jb += SL * RB_MIX) {
+            float m[RB_MIX];
+            u16x8 v[RB_MIX];
 #pragma unroll
-            for (int u = 0; u < ROW_BATCH; ++u) {
+            for (int u = 0; u < RB_MIX; ++u) {
                 const int j = jb + u * SL;
                 m[u] = (j <= hi) ? mrow[j] : 0.f;
                 if (m[u] != 0.f) v[u] = *(const u16x8*)(in + ((size_t)n * J + j) * ldin + cv * 8);
             }
 #pragma unroll
-            for (int u = 0; u < ROW_BATCH; ++u) {
+            for (int u = 0; u < RB_MIX; ++u) {
                 if (m[u] == 0.f) continue;
                 float f[8];
                 cvt8(v[u], f);
@@ -1142,11 +1165,11 @@ __global__ void __launch_bounds__(256) classifier_bwd_kernel(const bf16_t* __res
     long long M = (long long)N * HW;
     long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     if (cok)
-        for (long long mb = r0 + rl; mb < r1; mb += (long long)rpb * ROW_BATCH) {
-            float gq[ROW_BATCH][NC];
-            u16x8 hv[ROW_BATCH];
+        for (long long mb = r0 + rl; mb < r1; mb += (long long)rpb * RB_CLS) {
+            float gq[RB_CLS][NC];
+            u16x8 hv[RB_CLS];
 #pragma unroll
-            for (int u = 0; u < ROW_BATCH; ++u) {          // all loads of the batch first
+            for (int u = 0; u < RB_CLS; ++u) {          // all loads of the batch first
                 const long long m = mb + (long long)u * rpb;
                 if (m < r1) {
                     int n = (int)(m / HW), p = (int)(m % HW);
@@ -1156,7 +1179,7 @@ __global__ void __launch_bounds__(256) classifier_bwd_kernel(const bf16_t* __res
                 }
             }
 #pragma unroll
-            for (int u = 0; u < ROW_BATCH; ++u) {
+            for (int u = 0; u < RB_CLS; ++u) {
                 const long long m = mb + (long long)u * rpb;
                 if (m >= r1) break;
                 float h[8], o[8];

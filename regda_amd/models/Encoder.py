@@ -275,7 +275,10 @@ class Deeplabv2(nn.Module):
         self.fuse_bn_bwd = True      # fold BN-backward reductions into the producing data-gradient conv
         # weight gradients are collected and launched in groups (rgda_conv2d_wgrad_grouped) once this much work
         # is pending; 0 = one launch per layer
-        self.wgrad_group_gflop = 250.0
+        self.wgrad_group_gflop = 500.0
+        # ... and always where backward leaves these stages (so that what is still queued when the main chain ends is
+        # one stage's worth, whatever the threshold): '' = never
+        self.wgrad_flush_after = ('layer2',)
         # keep ReLU sign bits (1/16 of y) for the backward pass instead of re-reading y, for units with at least this
         # many channels (0 / False = never, 1 / True = always).  Round 1 kept them for the 1024-channel units only; with
         # the leaner BatchNorm kernels of round 2 every unit pays (A/B on one box: threshold 1024 -> 21.83, 512 -> 21.77,
@@ -1132,6 +1135,10 @@ class Deeplabv2(nn.Module):
             else:
                 g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm, consumer=below)
             self._progress(T, self._offset_of(p + '.conv1'))
+            if bi > 0 and T['wgrad_pending']:
+                stage = p.split('.')[-2]                      # 'encoder.resnet.layerK.i' -> 'layerK'
+                if stage in self.wgrad_flush_after and self.blocks[bi - 1][0].split('.')[-2] != stage:
+                    self._flush_wgrads(T)
         # layer1's queued weight gradients go to the second stream NOW, next to the stem's backward (max-pool, BN, its
         # own weight gradient: ~0.4 ms on this stream) -- flushed after it they were a tail the optimizer waited for
         if self.early_last_flush:

@@ -214,7 +214,9 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
     const int grp = blockIdx.x / bpg, chunk = blockIdx.x % bpg;     // M = rows of ONE group
-    __shared__ float smean[2048], sistd[2048];
+    // (vpb <= 16 from elementwise_grid: 128 channels per workgroup.  1 KB, not 16: a small footprint lets these
+    // workgroups sit on a CU next to the other stream's 72-147 KB convolution workgroups)
+    __shared__ float smean[128], sistd[128];
     if (stats) {
         // train mode with the finalize step folded in: the workgroup rebuilds mean / invstd of its vpb*8 channels
         // from the conv epilogue's replicated accumulators, one channel per thread, and shares them through LDS

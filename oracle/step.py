@@ -14,7 +14,9 @@ class CpuStep:
     def __init__(self, sd, prototypes, resnet_type='resnet101', class_num=6, ignore_label=-1,
                  lr=1e-2, momentum=0.9, weight_decay=5e-4, max_norm=32.0,
                  cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996,
-                 refine_temp=2.0, sam_refine=True):
+                 refine_temp=2.0, sam_refine=True, balancer_s=None, balancer_t=None):
+        # balancer_s / balancer_t: labelpath.ClassBalanceState (--bcs / --bct, train_ssl_reg.py:125-158) or None
+        self.balancer_s, self.balancer_t = balancer_s, balancer_t
         self.sd = {k: v.clone() for k, v in sd.items()}
         self.names = model.param_names(self.sd)
         for k in self.names:
@@ -49,8 +51,8 @@ class CpuStep:
                                                           self.percent, self.C, self.ig))
             self.prototypes, _ = labelpath.update_prototype(feat_s, label_s, self.prototypes,
                                                             self.pdecay, self.C, self.ig)
-        loss_s = labelpath.loss_calc([s1, s2], label_s, self.ig)
-        loss_t = labelpath.loss_calc([t1, t2], hard, self.ig)
+        loss_s = labelpath.loss_calc([s1, s2], label_s, self.ig, self.balancer_s)
+        loss_t = labelpath.loss_calc([t1, t2], hard, self.ig, self.balancer_t)
         loss = loss_s + loss_t
         t_lab = time.time()
         params = [sd[k] for k in self.names]

@@ -36,9 +36,14 @@ def recording():
 def host(fn):
     """Run `fn()` now; when a plan is being recorded also store it as a host action of the plan (re-run at replay on
     the torch stream that is current now)."""
-    out = fn()
-    if _ACTIVE is not None:
-        _ACTIVE._host(fn)
+    global _ACTIVE
+    act, _ACTIVE = _ACTIVE, None        # entry points called BY the action belong to it (re-run with it), not to the table
+    try:
+        out = fn()
+    finally:
+        _ACTIVE = act
+    if act is not None:
+        act._host(fn)
     return out
 
 

@@ -20,7 +20,8 @@ class SSLStep:
     def __init__(self, model, prototypes, class_num=6, ignore_label=-1, momentum=0.9, weight_decay=5e-4,
                  max_norm=32.0, cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996, refine_temp=2.0,
                  sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=12 << 20,
-                 process_group=None, overlap_wgrad=True, overlap_comm=True):
+                 process_group=None, overlap_wgrad=True, overlap_comm=True, class_balancer_s=None,
+                 class_balancer_t=None):
         self.model = model
         self.C, self.ig = class_num, ignore_label
         self.momentum, self.wd, self.max_norm = momentum, weight_decay, max_norm
@@ -44,6 +45,9 @@ class SSLStep:
         self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
         self.source_side = overlap_wgrad    # source half of the label path on the second stream
+        # --bcs / --bct of tools/train_ssl_reg.py:54-58,125-158: regda_amd.gast.balance.ClassBalance objects whose
+        # frequency EMA re-weights the source / target cross-entropy per class (None = plain CE, the default)
+        self.class_balancer_s, self.class_balancer_t = class_balancer_s, class_balancer_t
         self._graph = None
         self._plan = None
         self._proto_ready = None
@@ -140,6 +144,20 @@ class SSLStep:
         self._graph.replay()
         return self._out
 
+    def _class_weights(self, balancer, label):
+        """Per-class CE weights of the two heads [2, C] (or None): loss_calc(multi=True) calls the loss once per head
+        and every call EMA-updates the balancer (regda/gast/balance.py:27-35), so the heads see consecutive states.
+        A host action of a recorded step: the counts and the 6-element arithmetic are re-run at every replay."""
+        if balancer is None:
+            return None
+        cw = torch.empty(2, self.C, device=label.device)
+
+        def update():
+            for hd in range(2):
+                cw[hd].copy_(balancer.next_class_weight(label))
+        plan.host(update)
+        return cw
+
     def _mark(self, name, stream=None):
         if self.marks is not None:
             ev = torch.cuda.Event(enable_timing=True)
@@ -198,7 +216,8 @@ class SSLStep:
         if side is not None:
             plan.wait_event(side, plan.record_event(main))
             with ops.use_stream(side):
-                loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
+                loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig,
+                                                   self._class_weights(self.class_balancer_s, label_s), True)
         if self.refine_label:
             soft, cm = ops.label_refine(feat_t, self.prototypes, t1, t2, soft_t, self.temp, return_ws=True)
             hard = ops.pseudo_select(soft, self.top, self.low, self.ig, classmax_ws=cm, check=False)
@@ -240,8 +259,9 @@ class SSLStep:
                 plan.host(lambda: setattr(self, '_proto_ready', pside.record_event() if pside is not main else None))
         # ---- losses + d(loss)/d(logits)
         if side is None:
-            loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig, None, True)
-        loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, None, True)
+            loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig,
+                                               self._class_weights(self.class_balancer_s, label_s), True)
+        loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, self._class_weights(self.class_balancer_t, hard), True)
         if side is not None:
             plan.wait_event(main, source_done)       # source loss, its logit gradients, the new prototypes
         self._mark('label path + losses done')

@@ -394,3 +394,57 @@ def test_device_prefetcher_delivers_the_host_batches_in_order():
     # same weights (lr = 0), same batch -> same source loss up to atomics noise; different batches differ
     assert losses[0] == pytest.approx(losses[3], rel=2e-2) and losses[1] == pytest.approx(losses[4], rel=2e-2)
     assert abs(losses[0] - losses[1]) > 1e-3 * abs(losses[0])
+
+
+def test_fused_step_with_class_balancing_matches_oracle_step():
+    """--bcs 1 --bct 1 (tools/train_ssl_reg.py:54-58,125-158): ClassBalance re-weights the source and the target
+    cross-entropy per class from an EMA of the class frequencies, updated once per head per loss call.  The fused step
+    with two balancers against the oracle step with two (oracle.labelpath.ClassBalanceState, pinned by loss.npz), two
+    steps each, eagerly and as a recorded plan: losses, gradient norm and the balancers' frequency state."""
+    from regda_amd.gast.balance import ClassBalance
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    from oracle import labelpath as olp
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=6)
+    b = make_batch(b=4, size=128, seed=11, device='cpu')
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(1))
+    ones = torch.ones(4, 512)
+    # a skewed starting state and a fast EMA, so that the weights differ by class and move from call to call
+    f0s, f0t = torch.tensor([0.5, 0.2, 0.1, 0.1, 0.05, 0.05]), torch.tensor([0.05, 0.05, 0.1, 0.1, 0.2, 0.5])
+    cb_s, cb_t = olp.ClassBalanceState(6, -1, 0.5, 0.5), olp.ClassBalanceState(6, -1, 0.5, 0.5)
+    cb_s.freq, cb_t.freq = f0s.clone(), f0t.clone()
+    cpu = CpuStep(sd, protos, resnet_type=rt, lr=1e-3, balancer_s=cb_s, balancer_t=cb_t)
+    refs = [cpu.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], (ones, ones), (ones, ones))
+            for _ in range(2)]
+    plain = CpuStep(sd, protos, resnet_type=rt, lr=1e-3).step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'],
+                                                               b['regs_t'], (ones, ones), (ones, ones))
+    assert abs(refs[0]['loss_source'] - plain['loss_source']) > 0.03 * plain['loss_source']     # the weights do act
+    g = {k: v.cuda() for k, v in b.items()}
+    for use_plan in (False, True):
+        m = build(rt)
+        m.load_state_dict(sd, strict=True)
+        m.set_drop_masks(ones, ones)
+        bs, bt = ClassBalance(6, -1, 0.5, 0.5), ClassBalance(6, -1, 0.5, 0.5)
+        bs.freq, bt.freq = f0s.cuda(), f0t.cuda()
+        st = SSLStep(m, protos, class_balancer_s=bs, class_balancer_t=bt)
+        vals = lambda o: [float(x.item()) for x in o]       # (the squared gradient norm is one buffer, rewritten per step)
+        outs = [vals(st.step(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'], 1e-3))]
+        if use_plan:
+            st.record_plan(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'])
+            outs.append(vals(st._out))
+        else:
+            outs.append(vals(st.step(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'], 1e-3)))
+        for (ls, lt, gn), ref in zip(outs, refs):
+            assert ls == pytest.approx(ref['loss_source'], rel=0.03), use_plan
+            assert lt == pytest.approx(ref['loss_target'], rel=0.08, abs=0.02), use_plan
+            assert gn ** 0.5 == pytest.approx(ref['grad_norm'], rel=0.08), use_plan
+        # four EMA updates each (two heads x two steps); the source labels are identical, the target pseudo labels
+        # differ in a few borderline pixels
+        torch.testing.assert_close(bs.freq.cpu(), cb_s.freq, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bt.freq.cpu(), cb_t.freq, rtol=2e-2, atol=2e-4)
+        if use_plan:            # a replay updates the balancers again
+            fq = bs.freq.clone()
+            st.step(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'], 1e-3)
+            torch.cuda.synchronize()
+            assert not torch.equal(bs.freq, fq)

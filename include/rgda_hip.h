@@ -73,6 +73,14 @@ int rgda_lrh(const int64_t* labels, const int64_t* regions, int64_t* out, int b,
              int class_num, int ignore_label, float percent, int max_regions, void* ws,
              size_t ws_bytes, rgda_stream_t stream);
 
+/* SAM.get_local_regions, the region-map assembly only   regda/utils/local_region_homog.py:51-56.
+ * masks: uint8 [K][HW] (non-zero = inside), the automatic mask generator's masks in ITS order; areas int64 [K];
+ * regions int32 [HW] out: 1 + the last mask index with area >= area_threshold covering the pixel, 0 where none does
+ * (later masks overwrite earlier ones).  The generator itself (third-party segment_anything) is not part of this
+ * library.  Bit-exact. */
+int rgda_masks_to_regions(const uint8_t* masks, const int64_t* areas, int32_t* regions, int K, int64_t HW,
+                          int64_t area_threshold, rgda_stream_t stream);
+
 /* Aligner.label_refine(None, feat_t, [p1,p2], soft, refine=1, mode='all', temp)
  *   regda/gast/alignment.py:194-265 (+ _pearson_dist :396-423, _softmax_T, _logits_norm).
  * feat: NCHW f32 (b,k,h,w); protos (c,k) f32; p1,p2: NCHW f32 (b,c,h,w);

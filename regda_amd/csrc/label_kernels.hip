@@ -522,6 +522,52 @@ extern "C" int rgda_label_refine_views(const float* feat, const float* protos, c
 }
 
 // --------------------------------------------------------------------------------------
+// SAM region map assembly   (regda/utils/local_region_homog.py:51-56, inside SAM.get_local_regions)
+// --------------------------------------------------------------------------------------
+// region[p] = 1 + the LAST mask index k (generator order) with areas[k] >= threshold and masks[k][p] != 0, else 0:
+// what painting the kept masks one over the other leaves.  A thread owns 16 consecutive pixels (one 16-byte load per
+// mask) and walks the masks from the last to the first until all 16 are decided.
+__global__ void __launch_bounds__(256) masks_to_regions_kernel(const uint8_t* __restrict__ masks,
+                                                               const long long* __restrict__ areas,
+                                                               int* __restrict__ regions, int K, long long HW,
+                                                               long long thr) {
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (p0 >= HW) return;
+    int out[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] = 0;
+    const bool full = p0 + 16 <= HW && (HW & 15) == 0;
+    unsigned open_mask = 0xffffu;
+    for (int k = K - 1; k >= 0 && open_mask; --k) {
+        if (areas[k] < thr) continue;
+        const uint8_t* m = masks + (size_t)k * HW + p0;
+        __attribute__((aligned(16))) uint8_t v[16];
+        if (full) {
+            *(uint4*)v = *(const uint4*)m;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = (p0 + e < HW) ? m[e] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (((open_mask >> e) & 1u) && v[e]) { out[e] = k + 1; open_mask &= ~(1u << e); }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        if (p0 + e < HW) regions[p0 + e] = out[e];
+}
+
+extern "C" int rgda_masks_to_regions(const uint8_t* masks, const int64_t* areas, int32_t* regions, int K, int64_t HW,
+                                     int64_t area_threshold, rgda_stream_t stream) {
+    if (!regions || K < 0 || HW <= 0 || (K > 0 && (!masks || !areas))) return RGDA_ERR_ARG;
+    const long long threads = (HW + 15) / 16;
+    masks_to_regions_kernel<<<(unsigned)cdiv(threads, 256), 256, 0, to_stream(stream)>>>(
+        masks, (const long long*)areas, regions, K, HW, area_threshold);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// --------------------------------------------------------------------------------------
 // update_prototype   (regda/gast/alignment.py:86-90, 300-327, 456-481)
 // --------------------------------------------------------------------------------------
 // one workgroup per low-res cell: histogram of the s x s block over C+1 classes

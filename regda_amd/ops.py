@@ -104,6 +104,21 @@ def lrh(labels, regions, percent, class_num, ignore_label, max_regions=4096, che
     return out
 
 
+def masks_to_regions(masks, areas, area_threshold=1024):
+    """masks (K,H,W) uint8 / bool, areas (K,) int64 -> (H,W) int32 region map (local_region_homog.py:51-56)."""
+    _need_cuda(masks, areas)
+    K, H, W = masks.shape
+    masks = masks.contiguous().to(torch.uint8) if masks.dtype != torch.uint8 else masks.contiguous()
+    areas = areas.contiguous().to(torch.int64)
+    assert areas.shape == (K,)
+    out = torch.empty((H, W), dtype=torch.int32, device=masks.device)
+    if H * W == 0:
+        return out
+    lib().call('rgda_masks_to_regions', masks.data_ptr() if K else 0, areas.data_ptr() if K else 0, out.data_ptr(), K, H * W,
+               int(area_threshold), _stream())
+    return out
+
+
 def label_refine(feat, protos, p1, p2, soft, temp=2.0, out=None, return_ws=False, views=3):
     """views: bit 0 = prototype view, bit 1 = prediction view (3 = mode 'all'); inputs of a view that is off may be None."""
     pview, lview = bool(views & 1), bool(views & 2)

@@ -186,6 +186,46 @@ def gold_refine():
          protos_new=al.prototypes.numpy())
 
 
+def gold_regions():
+    """SAM.get_local_regions (regda/utils/local_region_homog.py:41-64) -- the reference's OWN assembly of the region map
+    from the mask generator's output: masks in generator order, those with area >= area_thrshold painted one over the
+    other as ids i + 1.  The third-party generator (segment_anything) and the image reader are replaced by synthetic
+    annotations; the loop that runs is the reference's."""
+    import cv2
+    from regda.utils.local_region_homog import SAM
+    rng = np.random.default_rng(77)
+    out = {}
+    for ci, (h, w, k, thr) in enumerate([(64, 64, 12, 100), (48, 80, 40, 64), (96, 96, 5, 1024), (64, 64, 0, 100)]):
+        anns = []
+        for i in range(k):
+            m = np.zeros((h, w), bool)
+            y0, x0 = rng.integers(0, h - 2), rng.integers(0, w - 2)
+            hh, ww = rng.integers(2, h // 2), rng.integers(2, w // 2)
+            m[y0:y0 + hh, x0:x0 + ww] = True
+            m &= rng.random((h, w)) < 0.9                       # ragged masks
+            anns.append({'segmentation': m, 'area': int(m.sum())})
+        if k:
+            anns[k // 2]['area'] = thr                          # exactly at the threshold: kept (>=)
+            anns[0]['area'] = thr - 1                           # just below: dropped
+
+        class _Gen:
+            def generate(self, image, _a=anns):
+                return _a
+        sam = SAM.__new__(SAM)
+        sam.model = _Gen()
+        cv2.imread = lambda p, _s=(h, w): np.zeros(_s + (3,), np.uint8)
+        cv2.cvtColor = lambda im, code: im
+        cv2.COLOR_BGR2RGB = 4
+        reg = sam.get_local_regions(image_path='unused.png', area_thrshold=thr, save=False, show=False)
+        assert reg.dtype == np.int32 and reg.shape == (h, w)
+        out[f'masks{ci}'] = np.stack([a['segmentation'] for a in anns]).astype(np.uint8) if k else np.zeros((0, h, w), np.uint8)
+        out[f'areas{ci}'] = np.array([a['area'] for a in anns], np.int64)
+        out[f'thr{ci}'] = np.int64(thr)
+        out[f'regions{ci}'] = reg
+    out['n'] = np.int64(4)
+    save('regions.npz', **out)
+
+
 def gold_loss():
     torch.manual_seed(9)
     b, C = 2, 6
@@ -459,6 +499,6 @@ def gold_aspp():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta', 'pcl', 'align', 'aspp']
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta', 'pcl', 'align', 'aspp', 'regions']
     for w in which:
         globals()['gold_' + w]()

@@ -202,3 +202,37 @@ def test_teacher_probs_vs_oracle(mods):
     ref = opath.teacher_probs(p1, p2, (512, 512))
     out = mods.ops.teacher_probs(p1.cuda(), p2.cuda(), (512, 512)).cpu()
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_sam_region_map_assembly_bit_exact(mods, gold):
+    """rgda_masks_to_regions (the reference's own part of SAM.get_local_regions, local_region_homog.py:51-56) against the
+    region maps the reference loop produced, a ragged size against the oracle, and the `SAM` mirror around a stand-in
+    mask generator."""
+    from regda_amd import ops
+    from regda_amd.utils.local_region_homog import SAM, regions_from_anns
+    from oracle import regions as oreg
+    g = gold('regions.npz')
+    for i in range(int(g['n'])):
+        masks, areas, thr = g[f'masks{i}'], g[f'areas{i}'], int(g[f'thr{i}'])
+        out = ops.masks_to_regions(torch.from_numpy(masks).cuda(), torch.from_numpy(areas).cuda(), thr)
+        assert out.dtype == torch.int32 and np.array_equal(out.cpu().numpy(), g[f'regions{i}']), i
+    rng = np.random.default_rng(5)
+    masks = (rng.random((37, 33, 17)) < 0.15).astype(np.uint8)             # 561 pixels: not a multiple of 16
+    areas = masks.reshape(37, -1).sum(1).astype(np.int64)
+    thr = int(np.median(areas))
+    out = ops.masks_to_regions(torch.from_numpy(masks).cuda(), torch.from_numpy(areas).cuda(), thr)
+    assert np.array_equal(out.cpu().numpy(), oreg.regions_from_masks(masks, areas, thr))
+    big = (rng.random((250, 512, 512)) < 0.01).astype(np.uint8)            # a production-size case (250 masks, 512^2)
+    big[3, 100:300, 50:400] = 1
+    ab = big.reshape(250, -1).sum(1).astype(np.int64)
+    out = ops.masks_to_regions(torch.from_numpy(big).cuda(), torch.from_numpy(ab).cuda(), 1024)
+    assert np.array_equal(out.cpu().numpy(), oreg.regions_from_masks(big, ab, 1024))
+    anns = [{'segmentation': masks[k].astype(bool), 'area': int(areas[k])} for k in range(37)]
+
+    class Gen:
+        def generate(self, image):
+            assert image.shape == (33, 17, 3)
+            return anns
+    reg = SAM(Gen()).get_local_regions(np.zeros((33, 17, 3), np.uint8), area_thrshold=thr)
+    assert reg.dtype == np.int32 and np.array_equal(reg, oreg.regions_from_masks(masks, areas, thr))
+    assert int(regions_from_anns([], (8, 8)).abs().sum()) == 0

@@ -307,3 +307,15 @@ def test_eval_metrics_against_scikit_learn_definitions():
     assert np.isnan(iou[-1])                                  # 0 / 0 for the absent class, like numpy does in `ever`
     s = evalpath.summary(cm[:-1, :-1], ignore_labels=[0])
     assert s['miou'] == np.round(np.mean(np.round(iou[1:-1], 5)), 5)
+
+
+def test_sam_region_map_assembly(gold):
+    """oracle/regions.py against the reference's own loop (SAM.get_local_regions, local_region_homog.py:51-56) run on
+    synthetic annotations: ids = generator index + 1, area threshold inclusive, later masks over earlier ones."""
+    from oracle import regions as oreg
+    g = gold('regions.npz')
+    for i in range(int(g['n'])):
+        out = oreg.regions_from_masks(g[f'masks{i}'], g[f'areas{i}'], int(g[f'thr{i}']))
+        assert out.dtype == np.int32 and np.array_equal(out, g[f'regions{i}']), i
+    k = g['masks0'].shape[0]
+    assert (g['regions0'] != 1).all() and (g['regions0'] == k // 2 + 1).any()      # below / exactly at the threshold

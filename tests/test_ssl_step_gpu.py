@@ -287,8 +287,7 @@ def test_teacher_sees_the_same_batchnorm_statistics_with_and_without_stream_over
 def test_plan_replay_matches_the_eager_step():
     """SSLStep.record_plan(): the recorded launch table replayed by rgda_plan_run (plus its host actions) against the
     same steps run eagerly -- same losses, BatchNorm buffers and weights up to the run-to-run noise of atomic summation
-    order, new inputs and learning rates are picked up, and the host enqueues a step several times faster."""
-    import time
+    order, new inputs and learning rates are picked up."""
     from regda_amd.ssl import SSLStep
     from regda_amd.synthetic import make_batch
     rt = 'resnet17t'
@@ -313,10 +312,7 @@ def test_plan_replay_matches_the_eager_step():
                 # that the recorded step IS step i (same inputs); the eager arm runs it with lrs[0] as well
                 out.append([float(x.item()) for x in st._out])
                 continue
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
             o = st.step(b['images_s'], b['label_s'], b['images_t'], None, b['regs_t'], lr if not (i == 1) else lrs[0])
-            host.append(time.perf_counter() - t0)
             out.append([float(x.item()) for x in o])
         torch.cuda.synchronize()
         return m, st, out, host
@@ -339,8 +335,8 @@ def test_plan_replay_matches_the_eager_step():
     assert (m_p.flat_buf - m_e.flat_buf).norm().item() < 2e-2 * m_e.flat_buf.norm().item()
     sh = (st_p.teacher.flat_p - st_e.teacher.flat_p).norm() / st_e.teacher.flat_p.norm()
     assert sh.item() < 1e-3
-    # host time of a replayed step against an eager one (both asynchronous)
-    assert min(host_p[1:]) < 0.8 * min(host_e[1:]), (host_p, host_e)       # ~270 launches here; 3x at the full-size step's 680
+    # (host time of a replayed step vs an eager one is reported by bench.py: host_enqueue_ms_per_step; no wall-clock
+    # thresholds in the parity suite)
 
 
 def sd_flat(m, sd):

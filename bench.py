@@ -31,7 +31,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 achieva
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=1, help='number of ranks (one per GPU); without a launcher environment and N > 1 the script re-executes itself under torch.distributed.run')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="'gloo' = launcher self-test without GPUs (rendezvous + one all-reduce, no step)")
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8, help='source (= target) images per GPU')
@@ -47,6 +48,7 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than the recorded plan on ROCm 7.2: 22.4 vs 21.0 ms/step)')
     ap.add_argument('--relu-mask', type=int, default=None, help='tuning: keep ReLU sign bits for units with at least this many channels (model default: all units)')
     ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline (default: physical cores of one socket within the affinity mask / cgroup quota)')
     ap.add_argument('--phases', action='store_true', help='HIP-event phase marks of one extra step, to stderr')
     ap.add_argument('--align-steps', type=int, default=0, help='also time this many stage-2 ("align", SURVEY 8f.2) '
                     'iterations on the same model and batch; adds "align_step" to the JSON')
@@ -179,15 +181,75 @@ def conv_flops_probe(step_fn, park_ms=150.0):
     return out
 
 
+def host_cores():
+    """How many threads the CPU baseline may use: the physical cores of ONE socket (/proc/cpuinfo: distinct
+    (physical id, core id) pairs of the first package), intersected with this process's affinity mask and capped by
+    the cgroup CPU quota (cpu.max / cfs_quota_us).  Returns (threads, dict describing each limit)."""
+    info = {'logical_cpus': os.cpu_count() or 1}
+    cores_by_pkg, cpu_core = {}, {}
+    try:
+        cur = {}
+        for line in open('/proc/cpuinfo'):
+            if ':' in line:
+                k, v = (t.strip() for t in line.split(':', 1))
+                cur[k] = v
+            elif cur:
+                if 'processor' in cur:
+                    pkg, core = cur.get('physical id', '0'), cur.get('core id', cur['processor'])
+                    cores_by_pkg.setdefault(pkg, set()).add(core)
+                    cpu_core[int(cur['processor'])] = (pkg, core)
+                cur = {}
+        if cur and 'processor' in cur:
+            pkg, core = cur.get('physical id', '0'), cur.get('core id', cur['processor'])
+            cores_by_pkg.setdefault(pkg, set()).add(core)
+            cpu_core[int(cur['processor'])] = (pkg, core)
+    except OSError:
+        pass
+    info['sockets'] = max(len(cores_by_pkg), 1)
+    first = sorted(cores_by_pkg)[0] if cores_by_pkg else None
+    info['physical_cores_per_socket'] = len(cores_by_pkg[first]) if first is not None else info['logical_cpus']
+    try:
+        aff = os.sched_getaffinity(0)
+    except AttributeError:
+        aff = set(range(info['logical_cpus']))
+    info['affinity_cpus'] = len(aff)
+    # physical cores of the first socket this process is allowed on
+    allowed = {cpu_core[c] for c in aff if c in cpu_core}
+    if allowed:
+        pk = sorted({p for p, _ in allowed})[0]
+        n = len({c for p, c in allowed if p == pk})
+    else:
+        n = min(info['physical_cores_per_socket'], len(aff))
+    quota = None
+    for path, parse_q in (('/sys/fs/cgroup/cpu.max', lambda t: None if t.split()[0] == 'max' else float(t.split()[0]) / float(t.split()[1])),
+                          ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', None)):
+        try:
+            t = open(path).read().strip()
+            if parse_q is not None:
+                quota = parse_q(t)
+            elif int(t) > 0:
+                quota = int(t) / float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read().strip())
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    info['cgroup_cpu_quota'] = quota
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n), info
+
+
 def cpu_baseline(args):
     """The CPU oracle (oracle/step.py: the reference's step restated in stock PyTorch fp32) on a bounded
-    sample: b = cpu_batch + cpu_batch images, 1 warm-up + timed steps until ~20 s."""
+    sample: b = cpu_batch + cpu_batch images, 1 warm-up + timed steps until ~20 s.  Threads = physical cores of one
+    socket within the affinity mask / cgroup quota; a short 8-thread probe step is reported next to it so
+    the scaling (or the limit that prevents it) can be read off the line."""
     import torch
     from oracle import model as omodel
     from oracle.step import CpuStep
     from regda_amd.synthetic import make_batch
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads, limits = host_cores()
+    if args.cpu_threads:
+        threads = args.cpu_threads
     torch.set_num_threads(threads)
     b = args.cpu_batch
     batch = make_batch(b=b, size=args.size, seed=2333, device='cpu')
@@ -199,20 +261,60 @@ def cpu_baseline(args):
     run()
     warm = time.time() - t0
     n, t0 = 0, time.time()
+    phases = {}
     while n < 1 or (time.time() - t0 < 15.0 and n < 5):
-        run()
+        ph = {}
+        st.step(batch['images_s'], batch['label_s'], batch['images_t'], batch['soft_t'], batch['regs_t'], lr=1e-4, phases=ph)
+        for k, v in ph.items():
+            phases[k] = phases.get(k, 0.0) + v
         n += 1
     dt = (time.time() - t0) / n
-    return dict(value=b / dt, unit='pairs/s', cores=threads, kind='port',
+    probe = None
+    if threads > 8:         # one step at 8 threads (the container probe of SURVEY 8d): does the box scale beyond it?
+        torch.set_num_threads(8)
+        t1 = time.time()
+        run()
+        probe = time.time() - t1
+        torch.set_num_threads(threads)
+    return dict(value=b / dt, unit='pairs/s', cores=threads, threads=threads, kind='port', host=limits,
+                s_per_step=dt, phases_s={k: v / n for k, v in phases.items()},
+                s_per_step_8_threads=probe,
                 sample=f'oracle/step.py (stock PyTorch CPU fp32, offline soft labels), {args.model}, b={b}+{b} {args.size}x{args.size}, '
-                       f'{n} timed step(s) after 1 warm-up ({warm:.1f}s), {dt:.2f} s/step')
+                       f'{n} timed step(s) after 1 warm-up ({warm:.1f}s), {dt:.2f} s/step on {threads} threads '
+                       f'(= physical cores of one socket within affinity / cgroup quota)')
+
+
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-exec this command line under
+    `python -m torch.distributed.run --nproc-per-node N` (one process per GPU) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:         # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(respawn_under_launcher(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    if args.backend == 'gloo':          # launcher self-test on a CPU box: rendezvous, one all-reduce, one JSON line
+        dist.init_process_group('gloo')
+        t = torch.ones(1) * (dist.get_rank() + 1)
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({'launcher_selftest': True, 'n_gpus': world, 'ranks': dist.get_world_size(), 'sum': float(t.item())}))
+        dist.destroy_process_group()
+        return
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
@@ -348,6 +450,7 @@ def main():
                                f'{args.size}x{args.size} per GPU, ' + ('online EMA teacher' if teacher else 'offline soft labels'),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'gflop_per_pair': gflop_pair},
         'pairs_per_sec_per_gpu': value / world,
+        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
         # whole-step MFMA fraction on the REFERENCE's convolution FLOPs (1268 GFLOP/pair with the teacher forward): an
         # "effective" figure -- the step executes fewer (the head conv is re-associated); the executed-FLOP
         # fraction is roofline.step_executed_mfma_frac

@@ -98,3 +98,28 @@ def test_single_process_reducer_is_a_noop():
     from regda_amd.gast.balance import sync_class_counts
     cnt = torch.tensor([4.0, 5.0])
     assert sync_class_counts(cnt) is cnt and torch.equal(cnt, torch.tensor([4.0, 5.0]))
+
+
+def test_bench_launcher_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` without a launcher environment re-executes itself under torch.distributed.run with
+    two ranks (here: the gloo self-test leg, no GPU); a launcher that started a different number of ranks is an error;
+    host_cores() respects the affinity mask."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['ranks'] == 2 and out['sum'] == 3.0
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo'],
+                       env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr
+    sys.path.insert(0, root)
+    import bench
+    n, info = bench.host_cores()
+    assert 1 <= n <= info['affinity_cpus'] and n <= info['physical_cores_per_socket']

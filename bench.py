@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--no-h2d', action='store_true', help='reuse one device-resident batch instead of staging a fresh pinned host batch per step over a copy stream')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than the recorded plan on ROCm 7.2: 22.4 vs 21.0 ms/step)')
     ap.add_argument('--relu-mask', type=int, default=None, help='tuning: keep ReLU sign bits for units with at least this many channels (model default: all units)')
+    ap.add_argument('--wgrad-group-gflop', type=float, default=None, help='tuning: weight gradients are queued and launched in groups of at least this much work (model default: 500)')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline (default: physical cores of one socket within the affinity mask / cgroup quota)')
     ap.add_argument('--phases', action='store_true', help='HIP-event phase marks of one extra step, to stderr')
@@ -343,6 +344,8 @@ def main():
             model.convs[f'{head}.conv_last.4'].w.mul_(40.0)
     if args.relu_mask is not None:
         model.relu_sign_mask = args.relu_mask
+    if args.wgrad_group_gflop is not None:
+        model.wgrad_group_gflop = args.wgrad_group_gflop
     model.sync_weights()
     if world > 1:       # identical initial weights on every rank
         dist.broadcast(model.flat_p, 0)
@@ -518,7 +521,7 @@ def main():
                                      'contrastive loss on the features'}
     if rank == 0 and world == 1 and args.tta_tiles > 0:
         from regda_amd.utils.tools import pre_slide
-        tm = step.teacher if step.teacher is not None else model
+        tm = step.teacher_model() if step.teacher is not None else model       # EMA weights + the student's current BN buffers
         tm.eval()
         tile = batch['images_t'][:1].contiguous()
         with torch.no_grad():

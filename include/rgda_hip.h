@@ -26,11 +26,25 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 3
+#define RGDA_ABI_VERSION 4
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
- * copy b % 8, i.e. the copy of the XCD it runs on, so the fp32 atomics stay inside one XCD's L2); consumers
- * sum the copies.  A "stats"/"sums" buffer is therefore f32[RGDA_STAT_REPLICAS][2][C], zeroed by the caller. */
+ * copy b % 8, i.e. the copy of the XCD it runs on, so the atomics stay inside one XCD's L2); consumers
+ * sum the copies.  A "stats"/"sums" buffer is therefore rgda_stat_t[RGDA_STAT_REPLICAS][2][C], zeroed by the caller.
+ *
+ * rgda_stat_t is 64-bit FIXED POINT (ABI 4; fp32 before): every workgroup reduces its rows in a fixed order, converts
+ * the partial sum to round(v * 2^FRAC) and adds it with an integer atomic.  Integer addition is associative, so the
+ * totals -- and everything computed from them: BatchNorm outputs, running statistics, BatchNorm gradients -- do not
+ * depend on the order in which workgroups retire: two runs of the same step are bit-identical (fp32 atomics made the
+ * batch statistics differ in the last bits from run to run, which moved thresholded pseudo labels).
+ *   forward  (sum y, sum y^2 of conv outputs):  FRAC = 26 -> resolution 1.5e-8 per partial (below BatchNorm's eps by
+ *            three orders of magnitude after the division by the row count), |total| < 1.4e11
+ *   backward (sum g', sum g' xhat):             FRAC = 40 -> resolution 9e-13 per partial, |total| < 8.4e6
+ * Partials outside the range are clamped, non-finite partials add nothing (the non-finite ELEMENTS still propagate
+ * through the element-wise passes and the loss). */
 #define RGDA_STAT_REPLICAS 8
+#define RGDA_STAT_FRAC_FWD 26
+#define RGDA_STAT_FRAC_BWD 40
+typedef int64_t rgda_stat_t;
 #define RGDA_LAYOUT_TILE 64      /* tile edge of rgda_weight_transpose_batched (block accounting of its table) */
 
 typedef void* rgda_stream_t; /* hipStream_t */
@@ -144,14 +158,14 @@ int rgda_class_count(const int64_t* label, int32_t* cnt, int64_t n, int c, rgda_
  *   res_relu_mask : NULL or uint8 [N*Ho*Wo][Cout/8] sign bits (rgda_bn_train_apply): res is added only where its
  *          bit is set -- the gradient of a residual connection gated by the ReLU it passed through, so that gated
  *          copy never has to be written to memory
- *   stats: NULL or f32[RGDA_STAT_REPLICAS][2][Cout]; per-channel sum and sum of squares of the
- *          (bf16-rounded) outputs are atomically accumulated (BatchNorm batch stats)
+ *   stats: NULL or rgda_stat_t[RGDA_STAT_REPLICAS][2][Cout] (FRAC_FWD); per-channel sum and sum of squares of the
+ *          (bf16-rounded) outputs are accumulated order-independently (BatchNorm batch stats)
  *   mode 0: y[n,ho,wo] = sum x[n, ho*stride-pad+kh*dil, wo*stride-pad+kw*dil] * w
  *   mode 1: y[n,ho,wo] = sum x[n, (ho+pad-kh*dil)/stride, (wo+pad-kw*dil)/stride] * w
  *           (terms with a non-integer or out-of-range source are zero)
  * Requires Cin % 32 == 0, Cout % 8 == 0, ld* % 8 == 0. */
 int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res,
-                int ldres, const uint8_t* res_relu_mask, float* stats, int stat_groups, int N, int H, int W,
+                int ldres, const uint8_t* res_relu_mask, rgda_stat_t* stats, int stat_groups, int N, int H, int W,
                 int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int mode,
                 rgda_stream_t stream);
 
@@ -170,7 +184,7 @@ int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void* y, int ldy
  * sums[group][REPLICAS][2][Cout] += (sum g', sum g' * xhat) -- exactly what rgda_bn_bwd_reduce would compute
  * from the stored tensor, without re-reading it. */
 int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                      const uint8_t* res_relu_mask, float* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
+                      const uint8_t* res_relu_mask, rgda_stat_t* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
                       const void* bn_x, int bn_ldx,
                       const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N, int H,
                       int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
@@ -183,10 +197,16 @@ int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy,
 int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, int rows_per_group);
 
 /* Weight gradient: dw[co][tap][ci] (f32, row stride taps*Cin) +=
- *   sum_p dy[p][co] * x[src(p,tap)][ci]   (same geometry as mode 0 above). */
+ *   sum_p dy[p][co] * x[src(p,tap)][ci]   (same geometry as mode 0 above).
+ * Reproducible: the pixel (K) dimension of a layer is split over several workgroups only through the workspace --
+ * every split leaves its partial tile there, the LAST workgroup of a tile to arrive (a counter per tile) adds the
+ * partials in split order 0, 1, ... and is the only one that adds to dw (ABI 4; every split added to dw with fp32
+ * atomics before: the arrival order moved the last bits from run to run).  ws: rgda_conv2d_wgrad_workspace bytes, or NULL = never
+ * split (slow for layers with few tiles).  The first 64 KiB of ws are tile counters: ZERO them once after
+ * allocation; every call leaves them zero.  Calls that share a ws must be ordered on one stream. */
 int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int N, int H,
                       int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride,
-                      int pad, int dil, rgda_stream_t stream);
+                      int pad, int dil, void* ws, size_t ws_bytes, rgda_stream_t stream);
 
 /* The weight gradients of several layers in as few launches as possible (same arithmetic as n calls of
  * rgda_conv2d_wgrad, accumulated into each dw).  Layers that map to the same kernel instantiation share a
@@ -201,7 +221,8 @@ typedef struct rgda_wgrad_desc {
     int ldx, lddy;
     int N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil;
 } rgda_wgrad_desc;
-int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, rgda_stream_t stream);
+size_t rgda_conv2d_wgrad_workspace(const rgda_wgrad_desc* descs, int n);
+int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, void* ws, size_t ws_bytes, rgda_stream_t stream);
 
 /* Stem im2col: NCHW f32 image (N,3,H,W) -> [N*Ho*Wo][Kp] bf16 patches of the
  * 7x7/2 pad-3 conv (regda/_resnets.py:150-151), k index = (kh*7+kw)*3+c, zero padded to Kp. */
@@ -209,7 +230,7 @@ int rgda_stem_im2col(const float* img, void* col, int N, int H, int W, int Ho, i
                      rgda_stream_t stream);
 
 /* BatchNorm2d (train) on PxC bf16, nn.BatchNorm2d defaults (eps 1e-5, momentum .1):
- *  finalize: stats f32[REPLICAS][2][C] (sum,sumsq over M rows) -> mean/invstd f32[2][C] in `mi`,
+ *  finalize: stats rgda_stat_t[REPLICAS][2][C] (sum,sumsq over M rows, FRAC_FWD) -> mean/invstd f32[2][C] in `mi`,
  *            running_mean/var/num_batches_tracked update.  If stats==NULL, eval mode:
  *            mi is filled from the running statistics.
  *  apply   : y = act( (x-mean)*invstd*gamma+beta [+ res] ) [* nscale[n][c]]
@@ -218,8 +239,8 @@ int rgda_stem_im2col(const float* img, void* col, int N, int H, int W, int Ho, i
  * SSL step run through the network together) that are normalised INDEPENDENTLY, like the reference's two
  * separate forward calls; stats / sums are laid out [groups][REPLICAS][2][C], mi [groups][2][C]; running
  * statistics are updated group after group. */
-int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, int C, rgda_stream_t stream);
-int rgda_bn_finalize(const float* stats, float* mi, float* running_mean, float* running_var,
+int rgda_bn_stats(const void* x, int ldx, rgda_stat_t* stats, int64_t M, int C, rgda_stream_t stream);
+int rgda_bn_finalize(const rgda_stat_t* stats, float* mi, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, int64_t M, int C, int groups, float eps,
                      float momentum, rgda_stream_t stream);
 int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, const float* beta,
@@ -229,22 +250,22 @@ int rgda_bn_apply(const void* x, int ldx, const float* mi, const float* gamma, c
  * running statistics are written by one designated workgroup per channel block.
  * relu_mask (optional, needs relu): uint8 [M][C/8], bit e of byte k = [y[row][8k+e] > 0] -- the only thing the
  * backward pass needs from y; reading it instead of y saves 15/16 of that operand's HBM traffic there. */
-int rgda_bn_train_apply(const void* x, int ldx, const float* stats, float* mi, float* running_mean,
+int rgda_bn_train_apply(const void* x, int ldx, const rgda_stat_t* stats, float* mi, float* running_mean,
                         float* running_var, int64_t* num_batches_tracked, const float* gamma,
                         const float* beta, const void* res, int ldres, const float* nscale,
                         int rows_per_image, void* y, int ldy, uint8_t* relu_mask, int64_t M, int C, int relu,
                         int groups, float eps, float momentum, rgda_stream_t stream);
-/* sums f32[REPLICAS][2][C] must be ZERO on entry (the caller clears one arena per backward pass):
+/* sums rgda_stat_t[REPLICAS][2][C] (FRAC_BWD) must be ZERO on entry (the caller clears one arena per backward pass):
  * sums[0] += sum(g'), sums[1] += sum(g' * xhat), g' = g*[y>0]*nscale.  With relu, [y>0] comes from relu_mask
  * when given, else from y. */
 int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask, const void* x,
-                       int ldx, const float* mi, const float* nscale, int rows_per_image, float* sums,
+                       int ldx, const float* mi, const float* nscale, int rows_per_image, rgda_stat_t* sums,
                        int64_t M, int C, int relu, int groups, rgda_stream_t stream);
 /* dx = gamma*invstd*(g' - sum(g')/M - xhat*sum(g' xhat)/M); gmask (optional) = g';
  * dgamma += sum(g' xhat), dbeta += sum(g') (f32, accumulated) */
 int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask, const void* x,
                       int ldx, const float* mi, const float* gamma, const float* nscale,
-                      int rows_per_image, const float* sums, void* dx, int lddx, void* gmask,
+                      int rows_per_image, const rgda_stat_t* sums, void* dx, int lddx, void* gmask,
                       int ldgm, float* dgamma, float* dbeta, int64_t M, int C, int relu, int groups,
                       rgda_stream_t stream);
 

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) pcl_count_kernel(const int64_t* __restric
 template <int C, int PX, int SL>
 __global__ void __launch_bounds__(PX * SL) pcl_kernel(const float* __restrict__ feat, const int64_t* __restrict__ labels,
                                                       const float* __restrict__ pn, const int* __restrict__ count,
-                                                      float* loss, bf16_t* __restrict__ dfeat, int lddf, int accumulate,
+                                                      rgda_stat_t* loss_acc, bf16_t* __restrict__ dfeat, int lddf, int accumulate,
                                                       int K, int hw, int ignore_label, float inv_temp, float weight) {
     extern __shared__ float lds[];          // pn[C][K] | red[SL][PX][C+1] | coef[PX][C+1] | tile (bf16 [PX][KC+8])
     constexpr int KC = 128;                 // channels per transposed store chunk
@@ -73,8 +73,6 @@ __global__ void __launch_bounds__(PX * SL) pcl_kernel(const float* __restrict__ 
     for (int c = 0; c < C; ++c) r[1 + c] = d[c];
     __syncthreads();
     const int n = *count;
-    // no pixel kept: nn.CrossEntropyLoss averages over zero elements -> NaN loss (and zero gradients), like the reference
-    if (n == 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(loss, __builtin_nanf(""));
     if (slice == 0) {
         float* cf = coef + lane * (C + 1);
         const long long lab = ok ? labels[(size_t)b * hw + p] : (long long)ignore_label;
@@ -110,10 +108,10 @@ __global__ void __launch_bounds__(PX * SL) pcl_kernel(const float* __restrict__ 
             }
             cf[0] = gd * inv_temp / (nrm * nrm * nrm);            // beta
         }
-        // loss: one atomic per wave
+        // loss: one fixed-point integer atomic per wave (order-independent total, common.h: stat_add)
         float tot = contrib;
         for (int o = PX / 2; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-        if (lane == 0 && tot != 0.f) atomicAdd(loss, tot);
+        if (lane == 0 && tot != 0.f) stat_add(loss_acc, tot, RGDA_STAT_FRAC_BWD);
     }
     __syncthreads();
     if (!dfeat) return;
@@ -158,6 +156,12 @@ __global__ void __launch_bounds__(PX * SL) pcl_kernel(const float* __restrict__ 
     }
 }
 
+// *loss += the accumulated total; no pixel kept: nn.CrossEntropyLoss averages over zero elements -> NaN loss (and zero
+// gradients), like the reference
+__global__ void pcl_loss_finish_kernel(const rgda_stat_t* acc, const int* count, float* loss) {
+    *loss += (*count == 0) ? __builtin_nanf("") : (float)((double)*acc * (1.0 / (double)(1ll << RGDA_STAT_FRAC_BWD)));
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t rgda_pcl_loss_workspace(int C, int K) {
@@ -176,7 +180,8 @@ extern "C" int rgda_pcl_loss(const float* feat, const int64_t* labels, const flo
     float* pn = (float*)ws;
     int* count = (int*)((char*)ws + align256((size_t)C * K * 4));
     int* flag = count + 1;
-    if (hipMemsetAsync(count, 0, 8, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    rgda_stat_t* lacc = (rgda_stat_t*)(count + 2);           // the loss total of this call, fixed point
+    if (hipMemsetAsync(count, 0, 16, st) != hipSuccess) return RGDA_ERR_LAUNCH;
     pcl_prep_kernel<<<C, 256, 0, st>>>(protos, pn, K);
     RGDA_CHECK_LAUNCH();
     const long long n = (long long)b * h * w;
@@ -189,8 +194,10 @@ extern "C" int rgda_pcl_loss(const float* feat, const int64_t* labels, const flo
         hipFuncSetAttribute((const void*)pcl_kernel<6, PX, SL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return RGDA_ERR_LAUNCH;
     dim3 grid(cdiv(h * w, PX), b);
-    pcl_kernel<6, PX, SL><<<grid, PX * SL, lds, st>>>(feat, labels, pn, count, loss, (bf16_t*)dfeat, lddf, accumulate, K, h * w,
+    pcl_kernel<6, PX, SL><<<grid, PX * SL, lds, st>>>(feat, labels, pn, count, lacc, (bf16_t*)dfeat, lddf, accumulate, K, h * w,
                                                       ignore_label, 1.f / temperature, weight);
+    RGDA_CHECK_LAUNCH();
+    pcl_loss_finish_kernel<<<1, 1, 0, st>>>(lacc, count, loss);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -60,6 +60,24 @@ static __device__ __forceinline__ float wave_max(float v) {
 
 #define NREP RGDA_STAT_REPLICAS
 
+// ---- order-independent per-channel accumulators (include/rgda_hip.h: rgda_stat_t, 64-bit fixed point).
+// A workgroup's partial sum (reduced in a fixed order inside the workgroup) -> round(v * 2^frac) -> integer atomic.
+static __device__ __forceinline__ long long stat_fix(float v, int frac) {
+    const double d = (double)v * (double)(1ll << frac);         // exact (a power-of-two scale)
+    if (!(fabs(d) < 0x1p62)) return (d == d && fabs(d) != __builtin_inf()) ? (d > 0 ? (1ll << 62) : -(1ll << 62)) : 0ll;
+    return __double2ll_rn(d);
+}
+static __device__ __forceinline__ void stat_add(rgda_stat_t* p, float v, int frac) {
+    atomicAdd((unsigned long long*)p, (unsigned long long)stat_fix(v, frac));
+}
+// total of statistic `which` (0: first sum, 1: second) of channel c over the replicas of one row group, as a double
+static __device__ __forceinline__ double stat_total(const rgda_stat_t* __restrict__ st, int C, int c, int which, int frac) {
+    long long t = 0;
+#pragma unroll
+    for (int r = 0; r < NREP; ++r) t += st[(size_t)(2 * r + which) * C + c];
+    return (double)t * (1.0 / (double)(1ll << frac));
+}
+
 // Tuning hooks (tile overrides, per-workgroup timestamps, ablation switches) read environment variables.  They exist
 // only in a tuning build (`make TUNING=1`, what scripts/dev/dev_*.py expect); the product library never looks at the
 // environment.

@@ -25,7 +25,7 @@ struct ConvArgs {
     const bf16_t* w;
     bf16_t* y;
     const bf16_t* res;
-    float* stats;
+    rgda_stat_t* stats;
     int ldx, ldy, ldres;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, mode;
     int M;
@@ -226,8 +226,15 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             float tot = 0.f;
 #pragma unroll
             for (int wv = 0; wv < NW; ++wv) tot += red[(wv * 2 + which) * BC + c];
-            if (c0 + c < a.Cout)
-                atomicAdd(&a.stats[(((size_t)(m0 / a.rows_per_group) * NREP + replica) * 2 + which) * a.Cout + c0 + c], tot);
+            if (c0 + c < a.Cout) {
+                rgda_stat_t* dst = &a.stats[(((size_t)(m0 / a.rows_per_group) * NREP + replica) * 2 + which) * a.Cout + c0 + c];
+#ifdef RGDA_TUNING      // timing experiments (wrong results): 16 = no statistics atomics, 32 = fp32 atomics on the same words
+                if (a.skip & 16) {}
+                else if (a.skip & 32) atomicAdd((float*)dst, tot);
+                else
+#endif
+                stat_add(dst, tot, a.bn_x ? RGDA_STAT_FRAC_BWD : RGDA_STAT_FRAC_FWD);
+            }
         }
     }
 }
@@ -615,7 +622,7 @@ struct BnBwdFuse { const void* y; int ldy; const unsigned char* mask; const void
 struct BnEvalFuse { const float* rm; const float* rv; const float* gamma; const float* beta; float eps; int relu; };
 
 static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                         const unsigned char* res_mask, float* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                         const unsigned char* res_mask, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int kh, int kw, int stride, int pad, int dil, int mode, const BnBwdFuse* bnb,
                          rgda_stream_t stream, const BnEvalFuse* bne = nullptr) {
     if (!x || !wgt || !y) return RGDA_ERR_ARG;
@@ -708,7 +715,7 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
 }
 
 extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                           const uint8_t* res_relu_mask, float* stats, int stat_groups, int N, int H, int W, int Cin,
+                           const uint8_t* res_relu_mask, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin,
                            int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int mode,
                            rgda_stream_t stream) {
     return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, res_relu_mask, stats, stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
@@ -725,7 +732,7 @@ extern "C" int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void*
 }
 
 extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
-                                 const uint8_t* res_relu_mask, float* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
+                                 const uint8_t* res_relu_mask, rgda_stat_t* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
                                  const void* bn_x, int bn_ldx,
                                  const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N,
                                  int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
@@ -748,8 +755,85 @@ struct WgradArgs {
     int tiles_co, tiles_ci, splits, kt_per_split;
     int howo_shift, wo_shift;   // log2 when powers of two, else -1
     int tap_fused;              // host side: which kernel family the layer maps to
+    float* ws_part;             // splits > 1: this layer's partial tiles [tile][split][accumulators of the workgroup]
+    int* ws_cnt;                //             and its per-tile arrival counters (zero before and after the launch)
     unsigned long long* dbg;    // tuning builds only: per-workgroup phase timestamps
 };
+
+// ---- reproducible split-K: the workgroups that share a result tile leave their accumulators in the workspace; the
+// last one to arrive (one atomic counter per tile) sums the partials in split order and returns true -- it alone then
+// adds the total to dW.  No workgroup ever waits for another one.
+// The partials cross XCDs (each XCD has its own L2).  They are written and read with device-scope accesses
+// (`sc1`: write-through / coherent read), the stores are acknowledged (vmcnt 0) before the workgroup's arrival is
+// counted with a device-scope atomic, and the reader issues its loads after it has seen the count: no cache-wide
+// write-back / invalidate.  (`__threadfence()` -- buffer_wbl2 + buffer_inv on every wave -- in these two places cost
+// 2.5 ms per step.)  NACC = f32x16 accumulators per thread, NT = threads per workgroup.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#define RGDA_AUX_SC1 16     /* cache-policy operand of the raw buffer builtins: bit 4 = sc1 (device scope) on gfx94x/95x */
+template <int NACC, int NT>
+static __device__ __forceinline__ bool split_k_combine(const WgradArgs& a, int tile, int split, f32x16 (&acc)[NACC],
+                                                       unsigned char* smem) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int t = threadIdx.x;
+    constexpr int SLICE_B = NACC * 16 * NT * 4;                        // bytes per partial tile
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.ws_part + (size_t)tile * a.splits * (SLICE_B / 4)), 0, a.splits * SLICE_B, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x4 v = {__float_as_uint(acc[q][4 * g]), __float_as_uint(acc[q][4 * g + 1]),
+                             __float_as_uint(acc[q][4 * g + 2]), __float_as_uint(acc[q][4 * g + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((q * 4 + g) * NT + t) * 16, split * SLICE_B, RGDA_AUX_SC1);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's partial values have reached memory ...
+    __syncthreads();                                        // ... every thread's have, before the arrival is counted
+    int* flag = (int*)smem;
+    if (t == 0) *flag = atomicAdd(a.ws_cnt + tile, 1);
+    __syncthreads();
+    const bool last = (*flag == a.splits - 1);
+    if (!last) return false;
+    // in chunks of <= 4 accumulators: all 16 loads of a split are in flight together (one memory round trip per split
+    // and chunk; an element-by-element loop is a dependent round trip per 16 bytes), the adds keep split order
+    constexpr int CH = (NACC <= 4) ? NACC : ((NACC % 3 == 0) ? 3 : 4);
+    static_assert(NACC % CH == 0, "accumulator count must divide into chunks");
+#pragma unroll
+    for (int q0 = 0; q0 < NACC; q0 += CH) {
+        f32x4 sum[CH * 4];
+#pragma unroll
+        for (int i = 0; i < CH * 4; ++i) sum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < a.splits; sp += 2) {                    // fixed order, whoever arrived first
+            u32x4 v[CH * 4], w[CH * 4];                               // two splits per round trip
+            const bool two = sp + 1 < a.splits;
+#pragma unroll
+            for (int i = 0; i < CH * 4; ++i)
+                v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((q0 * 4 + i) * NT + t) * 16, sp * SLICE_B, RGDA_AUX_SC1);
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < CH * 4; ++i)
+                    w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((q0 * 4 + i) * NT + t) * 16, (sp + 1) * SLICE_B, RGDA_AUX_SC1);
+            }
+#pragma unroll
+            for (int i = 0; i < CH * 4; ++i)
+                sum[i] += f32x4{__uint_as_float(v[i][0]), __uint_as_float(v[i][1]), __uint_as_float(v[i][2]), __uint_as_float(v[i][3])};
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < CH * 4; ++i)
+                    sum[i] += f32x4{__uint_as_float(w[i][0]), __uint_as_float(w[i][1]), __uint_as_float(w[i][2]), __uint_as_float(w[i][3])};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CH * 4; ++i) {
+            const int q = q0 + i / 4, g = i % 4;
+            acc[q][4 * g] = sum[i][0]; acc[q][4 * g + 1] = sum[i][1]; acc[q][4 * g + 2] = sum[i][2]; acc[q][4 * g + 3] = sum[i][3];
+        }
+    }
+    if (t == 0) a.ws_cnt[tile] = 0;        // ready for the next launch (nobody else looks at this counter any more)
+    return true;
+#else
+    return false;
+#endif
+}
 
 // WI x WJ waves tile the [BCO][BCI] result; 8 waves (two per SIMD) keep the 8-byte transposing LDS reads and the
 // MFMA pipe busy while the other wave of the SIMD waits (one wave per SIMD reaches a fraction of the LDS rate).
@@ -981,9 +1065,16 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
             }
         }
     }
-    // ---- split-K reduction: fp32 atomics straight into the gradient buffer (128 B per half-wave).
+    // ---- dW += the tile: ONE workgroup per tile adds (the only split, or the last of the splits to arrive, with the
+    // ordered sum of all partials), so the result does not depend on any arrival order.  The add itself is still the
+    // fire-and-forget fp32 atomic (a plain read-modify-write is a dependent memory round trip per element: +3 ms/step).
     // 32-bit element offsets off one base (a layer's dW is far below 2^31 elements): no 64-bit multiplies here.
     if (a.dbg) tq2 = __builtin_readcyclecounter();
+    if (a.splits > 1 && a.ws_part) {
+        __syncthreads();                   // every wave is done with the LDS ring
+        f32x16 (&flat)[FI * FJ] = *reinterpret_cast<f32x16 (*)[FI * FJ]>(&acc[0][0]);
+        if (!split_k_combine<FI * FJ, 64 * NW>(a, (tap * a.tiles_ci + tci) * a.tiles_co + tco, split, flat, smem)) return;
+    }
     const int lcol = lane & 31, lk = lane >> 5;
     const unsigned rs = (unsigned)(taps * a.Cin);
     const bool full = (co0 + BCO <= a.Cout) && (ci0 + BCI <= a.Cin);
@@ -1142,6 +1233,10 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradGroup g) {
             stage = (stage == STAGES - 1) ? 0 : stage + 1;
         }
     }
+    if (a.splits > 1 && a.ws_part) {
+        __syncthreads();                   // every wave is done with the LDS ring
+        if (!split_k_combine<9, 256>(a, tci * a.tiles_co + tco, split, acc, smem)) return;
+    }
     const int lcol = lane & 31, lk = lane >> 5;
     const int ci = ci0 + wj * 32 + lcol;
     if (ci < a.Cin) {
@@ -1182,7 +1277,7 @@ static int wgrad_prepare(const rgda_wgrad_desc& d, WgradArgs& a) {
     a.wo_shift = ilog2_exact(d.Wo);
     a.dbg = nullptr;
     if (const char* e = TUNE_ENV("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
-    a.splits = 1; a.kt_per_split = 0;
+    a.splits = 1; a.kt_per_split = 0; a.ws_part = nullptr; a.ws_cnt = nullptr;
     // tap-fused path: 3x3, stride 1, "same" padding, the map tiles into 64-pixel row blocks
     a.tap_fused = 0;
     if (d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == d.dil && d.Ho == d.H && d.Wo == d.W &&
@@ -1217,28 +1312,92 @@ static inline int wgrad_ktiles(const WgradArgs& a) {
     return a.N * (a.H / (64 / wt)) * (a.W / wt);
 }
 
-// one launch for the layers g.a[0..n): split K just enough that the launch has >= ~2 workgroups per CU (generic)
-// or ~1 (tap-fused: 147 KB of atomics per split), never fewer than 16 K tiles per split
-static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
-    int total = 0;
-    for (int l = 0; l < g.n; ++l) total += wgrad_tiles(g.a[l]);
-    const int target = (kind >= WK_F64_1 || kind == WK_G256_128) ? 256 : 512;     // one workgroup per CU for the 144 KB tiles
+// floats a workgroup of kernel family `kind` leaves in the workspace per split (its accumulators)
+static inline size_t wgrad_slice_floats(int kind) {
+    switch (kind) {
+        case WK_G128_128: return 128 * 128;
+        case WK_G128_64: return 128 * 64;
+        case WK_G64_128: return 64 * 128;
+        case WK_G64_64: return 64 * 64;
+        case WK_G256_128: return 256 * 128;
+        default: return 9 * 64 * 64;            // tap-fused: nine 64 x 64 taps
+    }
+}
+#define RGDA_WGRAD_WS_COUNTERS (64 * 1024)      // bytes of tile counters at the head of the workspace (16 K tiles per launch)
+
+// K splits of the layers of one launch (g.a[0..n)); 1 without a workspace.  One split count S for the launch (a layer
+// with few K tiles gets fewer: never fewer than 16 K tiles per split), chosen by a round model of the launch: its
+// workgroups run in ceil(workgroups / capacity) rounds (capacity = 256, one workgroup per CU, for the 144 KB tiles;
+// 512 for the small ones) of ceil(K tiles / S) tile steps each, plus 8 + 2 S tile steps when S > 1: the partial tiles'
+// trip through the workspace and the last workgroup's walk over the S partials.  (Splitting "until the chip is full" -- the rule before ABI 4 -- made
+// 336 workgroups out of 112 tiles: two rounds of 86 steps where S = 2 gives one round of 128.)
+// Returns the bytes of partial tiles the launch needs behind the counters.
+static size_t wgrad_plan_splits(int kind, WgradGroup& g, bool have_ws) {
+    const int capacity = (kind >= WK_F64_1 || kind == WK_G256_128) ? 256 : 512;
     int minkt = 16;
     if (const char* e = TUNE_ENV("RGDA_WGRAD_MINKT")) minkt = atoi(e);                     // tuning experiments only
-    int items = 0;
+    int best = 1;
+    int rule = 1;
+    if (const char* e = TUNE_ENV("RGDA_WGRAD_RULE")) rule = atoi(e);                       // tuning experiments only
+    if (have_ws && rule == 0) {            // the pre-ABI-4 rule: split until the launch fills the chip
+        int total = 0;
+        for (int l = 0; l < g.n; ++l) total += wgrad_tiles(g.a[l]);
+        best = cdiv(capacity, total);
+    } else if (have_ws) {
+        long long best_cost = -1;
+        for (int S = 1; S <= 128; S += (S < 16 ? 1 : 4)) {
+            long long wgs = 0, steps = 0;
+            for (int l = 0; l < g.n; ++l) {
+                const int KT = wgrad_ktiles(g.a[l]);
+                int sl = S;
+                if (sl > KT / minkt) sl = KT / minkt;
+                if (sl < 1) sl = 1;
+                const int per = cdiv(KT, sl);
+                wgs += (long long)wgrad_tiles(g.a[l]) * cdiv(KT, per);
+                if (per > steps) steps = per;
+            }
+            const long long cost = (long long)cdiv(wgs, capacity) * (steps + (S > 1 ? 8 + 2 * S : 0));
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = S; }
+        }
+    }
+    if (const char* e = TUNE_ENV("RGDA_WGRAD_SPLITS")) best = atoi(e);                     // tuning experiments only
+    size_t floats = 0;
+    int items = 0, tiles_before = 0;
     for (int l = 0; l < g.n; ++l) {
         WgradArgs& a = g.a[l];
         const int KT = wgrad_ktiles(a);
-        int splits = cdiv(target, total);
+        int splits = best;
         if (splits > KT / minkt) splits = KT / minkt;
         if (splits < 1) splits = 1;
-        if (const char* e = TUNE_ENV("RGDA_WGRAD_SPLITS")) splits = atoi(e);               // tuning experiments only
         a.kt_per_split = cdiv(KT, splits);
         a.splits = cdiv(KT, a.kt_per_split);
         g.first[l] = items;
         items += wgrad_tiles(a) * a.splits;
+        // workspace slots of this layer (offsets here; the launch turns them into pointers)
+        a.ws_part = (float*)(uintptr_t)floats;
+        a.ws_cnt = (int*)(uintptr_t)tiles_before;
+        if (a.splits > 1) {
+            floats += (size_t)wgrad_tiles(a) * a.splits * wgrad_slice_floats(kind);
+            tiles_before += wgrad_tiles(a);
+        }
     }
     for (int l = g.n; l <= RGDA_WGRAD_MAXG; ++l) g.first[l] = items;
+    return floats * 4;
+}
+
+static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipStream_t st) {
+    const size_t need = wgrad_plan_splits(kind, g, ws != nullptr);
+    int tiles_split = 0;
+    for (int l = 0; l < g.n; ++l)
+        if (g.a[l].splits > 1) tiles_split += wgrad_tiles(g.a[l]);
+    if (need && (ws_bytes < RGDA_WGRAD_WS_COUNTERS + need || (size_t)tiles_split * 4 > RGDA_WGRAD_WS_COUNTERS)) return RGDA_ERR_WORKSPACE;
+    for (int l = 0; l < g.n; ++l) {
+        WgradArgs& a = g.a[l];
+        a.ws_part = (float*)((char*)ws + RGDA_WGRAD_WS_COUNTERS) + (size_t)(uintptr_t)a.ws_part;
+        a.ws_cnt = (int*)ws + (size_t)(uintptr_t)a.ws_cnt;
+        if (TUNE_ENV("RGDA_WGRAD_ATOMIC")) a.ws_part = nullptr;    // tuning only: every split adds to dW itself (not reproducible)
+    }
+    const int items = g.first[RGDA_WGRAD_MAXG];
     // keeping a layer's work items on one XCD (one L2) pays where the items of a layer re-read the same rows many
     // times (the taps of the small-channel 3x3 layers in the 64x64 kernel: 297 -> 220 us; tap-fused: 2 %); the
     // grouped 1x1 layers of the 128x128 kernel measured 9 % SLOWER with it (207 -> 225 us), so they keep b -> item b
@@ -1261,9 +1420,10 @@ static int wgrad_launch(int kind, WgradGroup& g, hipStream_t st) {
     return RGDA_OK;
 }
 
-extern "C" int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, rgda_stream_t stream) {
-    if (n < 0 || (n > 0 && !descs)) return RGDA_ERR_ARG;
-    hipStream_t st = to_stream(stream);
+// walks the list the way the launches are cut (per kernel family, RGDA_WGRAD_MAXG layers per launch) and calls
+// fn(kind, group) for every launch, in issue order
+template <typename F>
+static int wgrad_for_each_launch(const rgda_wgrad_desc* descs, int n, F fn) {
     static thread_local WgradGroup groups[WK_COUNT];
     for (int k = 0; k < WK_COUNT; ++k) groups[k].n = 0;
     // validate everything first: nothing is launched for a list with a bad entry
@@ -1278,25 +1438,43 @@ extern "C" int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, rg
         WgradGroup& g = groups[kind];
         g.a[g.n++] = a;
         if (g.n == RGDA_WGRAD_MAXG) {
-            int rc = wgrad_launch(kind, g, st);
+            int rc = fn(kind, g);
             if (rc != RGDA_OK) return rc;
             g.n = 0;
         }
     }
     for (int k = 0; k < WK_COUNT; ++k)
         if (groups[k].n) {
-            int rc = wgrad_launch(k, groups[k], st);
+            int rc = fn(k, groups[k]);
             if (rc != RGDA_OK) return rc;
         }
     return RGDA_OK;
 }
 
+extern "C" size_t rgda_conv2d_wgrad_workspace(const rgda_wgrad_desc* descs, int n) {
+    if (n <= 0 || !descs) return RGDA_WGRAD_WS_COUNTERS;
+    size_t most = 0;
+    wgrad_for_each_launch(descs, n, [&](int kind, WgradGroup& g) {
+        const size_t b = wgrad_plan_splits(kind, g, true);
+        if (b > most) most = b;
+        return (int)RGDA_OK;
+    });
+    return RGDA_WGRAD_WS_COUNTERS + most;       // the launches of one call run one after the other: they share the space
+}
+
+extern "C" int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, void* ws, size_t ws_bytes, rgda_stream_t stream) {
+    if (n < 0 || (n > 0 && !descs)) return RGDA_ERR_ARG;
+    if (ws && (ws_bytes < RGDA_WGRAD_WS_COUNTERS || ((uintptr_t)ws & 15))) return RGDA_ERR_WORKSPACE;
+    hipStream_t st = to_stream(stream);
+    return wgrad_for_each_launch(descs, n, [&](int kind, WgradGroup& g) { return wgrad_launch(kind, g, ws, ws_bytes, st); });
+}
+
 extern "C" int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int N, int H, int W,
                                  int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
-                                 rgda_stream_t stream) {
+                                 void* ws, size_t ws_bytes, rgda_stream_t stream) {
     rgda_wgrad_desc d;
     d.x = x; d.dy = dy; d.dw = dw; d.ldx = ldx; d.lddy = lddy;
     d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Ho = Ho; d.Wo = Wo; d.Cout = Cout; d.kh = kh; d.kw = kw;
     d.stride = stride; d.pad = pad; d.dil = dil;
-    return rgda_conv2d_wgrad_grouped(&d, 1, stream);
+    return rgda_conv2d_wgrad_grouped(&d, 1, ws, ws_bytes, stream);
 }

@@ -670,31 +670,36 @@ __global__ void __launch_bounds__(256) downscale_label16_kernel(const int64_t* _
     if (threadIdx.x < C && wg_cnt[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (float)wg_cnt[threadIdx.x]);
 }
 
-// one wavefront per (image, channel) row of hw features; per-class sums, one atomic per class
+// one workgroup per feature channel k: its 256 threads walk that channel's hw values of every image (image after
+// image), the six per-class sums are reduced wave -> LDS -> thread in a fixed order and leave with plain stores -- no
+// atomics, bit-reproducible prototypes
 template <int C>
 __global__ void __launch_bounds__(256) proto_accum_kernel(const float* __restrict__ feat,
                                                           const int64_t* __restrict__ label_ds, float* sums, int K,
-                                                          int hw, int rows) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // b*K + k
-    if (row >= rows) return;
-    const int lane = threadIdx.x & 63;
-    const int b = row / K, k = row % K;
-    const float* f = feat + (size_t)row * hw;
-    const int64_t* l = label_ds + (size_t)b * hw;
+                                                          int hw, int B) {
+    __shared__ float red[4][C];
+    const int k = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    for (int p = lane; p < hw; p += 64) {
-        float v = f[p];
-        int c0 = (int)l[p];
+    for (int b = 0; b < B; ++b) {
+        const float* f = feat + ((size_t)b * K + k) * hw;
+        const int64_t* l = label_ds + (size_t)b * hw;
+        for (int p = t; p < hw; p += 256) {
+            float v = f[p];
+            int c0 = (int)l[p];
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] += (c0 == c) ? v : 0.f;
+            for (int c = 0; c < C; ++c) acc[c] += (c0 == c) ? v : 0.f;
+        }
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         float s = wave_sum(acc[c]);
-        if (lane == 0 && s != 0.f) atomicAdd(&sums[(size_t)c * K + k], s);
+        if (lane == 0) red[wave][c] = s;
     }
+    __syncthreads();
+    if (t < C) sums[(size_t)t * K + k] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
 }
 
 __global__ void __launch_bounds__(256) proto_finalize_kernel(float* protos, const float* __restrict__ sums,
@@ -728,8 +733,7 @@ extern "C" int rgda_proto_update(const float* feat, const int64_t* label, float*
     else
         downscale_label_kernel<<<b * h * w, 256, 0, st>>>(label, label_ds, cnt, flag, h, w, scale, c, ignore_label, min_ratio);
     RGDA_CHECK_LAUNCH();
-    int rows = b * k;
-    proto_accum_kernel<6><<<cdiv(rows, 4), 256, 0, st>>>(feat, label_ds, sums, k, h * w, rows);
+    proto_accum_kernel<6><<<k, 256, 0, st>>>(feat, label_ds, sums, k, h * w, b);
     RGDA_CHECK_LAUNCH();
     float omd = (float)(1.0 - (double)decay);
     proto_finalize_kernel<<<cdiv((long long)c * k, 256), 256, 0, st>>>(protos, sums, cnt, k, c * k, omd, decay);

@@ -85,10 +85,11 @@ static __device__ __forceinline__ void store8(bf16_t* p, const float (&f)[8]) {
     *(uint4*)p = v;
 }
 
-// reduce two 8-vectors over the row lanes of a block and atomically add to out0[c], out1[c]
+// reduce two 8-vectors over the row lanes of a block (fixed order) and add them to out0[c], out1[c] as fixed-point
+// integers (order-independent totals, common.h: stat_add)
 static __device__ __forceinline__ void block_reduce_atomic(float (&s)[8], float (&q)[8], int cvl, int rl, int vpb,
-                                                           int rpb, int cglobal, bool cok, float* out0, float* out1,
-                                                           float* lds) {
+                                                           int rpb, int cglobal, bool cok, rgda_stat_t* out0,
+                                                           rgda_stat_t* out1, float* lds, int frac) {
     // lds: [rpb][vpb*8][2]
     __syncthreads();
 #pragma unroll
@@ -105,14 +106,14 @@ static __device__ __forceinline__ void block_reduce_atomic(float (&s)[8], float 
                 a += lds[((r * vpb + cvl) * 8 + e) * 2 + 0];
                 b += lds[((r * vpb + cvl) * 8 + e) * 2 + 1];
             }
-            atomicAdd(out0 + cglobal + e, a);
-            atomicAdd(out1 + cglobal + e, b);
+            stat_add(out0 + cglobal + e, a, frac);
+            stat_add(out1 + cglobal + e, b, frac);
         }
     }
 }
 
 // ------------------------------------------------------------------ BN statistics (standalone)
-__global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict__ x, int ldx, float* stats,
+__global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict__ x, int ldx, rgda_stat_t* stats,
                                                        long long M, int C, int vpb, int rpb, int rows_per_block) {
     __shared__ float lds[256 * 16];
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
@@ -127,11 +128,11 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
         }
-    float* rep = stats + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NREP - 1)) * 2 * C;
-    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, rep, rep + C, lds);
+    rgda_stat_t* rep = stats + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NREP - 1)) * 2 * C;
+    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, rep, rep + C, lds, RGDA_STAT_FRAC_FWD);
 }
 
-extern "C" int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, int C, rgda_stream_t stream) {
+extern "C" int rgda_bn_stats(const void* x, int ldx, rgda_stat_t* stats, int64_t M, int C, rgda_stream_t stream) {
     if (!x || !stats || M <= 0 || C <= 0 || (C & 7) || (ldx & 7)) return RGDA_ERR_ARG;
     RowLayout L = row_layout(C);
     if (L.vpb > 16) { L.vpb = 16; L.rpb = 16; }          // fewer closing atomics per workgroup, see rgda_bn_bwd_reduce
@@ -143,26 +144,35 @@ extern "C" int rgda_bn_stats(const void* x, int ldx, float* stats, int64_t M, in
 }
 
 // ------------------------------------------------------------------ BN finalize
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, float* mi, float* rm, float* rv,
+// mean, biased variance and 1 / sqrt(var + eps) of channel c from one row group's accumulators: fp64 from the exact
+// integer totals (every consumer goes through here, so forward, backward and the running update see the same values)
+static __device__ __forceinline__ void stat_moments(const rgda_stat_t* __restrict__ st, int C, int c, double invM, float eps,
+                                                    float& mean, float& var, float& istd) {
+    const double m = stat_total(st, C, c, 0, RGDA_STAT_FRAC_FWD) * invM;
+    double v = stat_total(st, C, c, 1, RGDA_STAT_FRAC_FWD) * invM - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    istd = 1.f / sqrtf((float)v + eps);       // (fp32: a double-precision sqrt + divide per channel shows in the apply passes)
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const rgda_stat_t* stats, float* mi, float* rm, float* rv,
                                                           long long* nbt, double M, int C, int groups, float eps,
                                                           float mom) {
     int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     for (int g = 0; g < groups; ++g) {          // group after group: the reference runs src then tgt
-        const float* st = stats ? stats + (size_t)g * NREP * 2 * C : nullptr;
+        const rgda_stat_t* st = stats ? stats + (size_t)g * NREP * 2 * C : nullptr;
         float* m = mi + (size_t)g * 2 * C;
         if (st) {
-            double s0 = 0.0, s1 = 0.0;
-            for (int r = 0; r < NREP; ++r) { s0 += st[(size_t)(2 * r) * C + c]; s1 += st[(size_t)(2 * r + 1) * C + c]; }
-            double mean = s0 / M;
-            double var = s1 / M - mean * mean;     // biased (normalisation)
-            if (var < 0) var = 0;
-            m[c] = (float)mean;
-            m[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            float mean, var, istd;                  // biased variance (normalisation)
+            stat_moments(st, C, c, 1.0 / M, eps, mean, var, istd);
+            m[c] = mean;
+            m[C + c] = istd;
             if (rm) {
-                double unb = (M > 1) ? var * M / (M - 1.0) : var;   // unbiased (running update)
-                rm[c] = (1.f - mom) * rm[c] + mom * (float)mean;
-                rv[c] = (1.f - mom) * rv[c] + mom * (float)unb;
+                const float unb = (M > 1) ? (float)M / (float)(M - 1.0) : 1.f;   // unbiased (running update)
+                rm[c] = (1.f - mom) * rm[c] + mom * mean;
+                rv[c] = (1.f - mom) * rv[c] + mom * var * unb;
             }
             if (c == 0 && nbt) *nbt += 1;
         } else {
@@ -172,7 +182,7 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, fl
     }
 }
 
-extern "C" int rgda_bn_finalize(const float* stats, float* mi, float* running_mean, float* running_var,
+extern "C" int rgda_bn_finalize(const rgda_stat_t* stats, float* mi, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, int64_t M, int C, int groups, float eps,
                                 float momentum, rgda_stream_t stream) {
     if (!mi || C <= 0 || groups < 1 || (M % groups) || (!stats && (!running_mean || !running_var))) return RGDA_ERR_ARG;
@@ -185,20 +195,11 @@ extern "C" int rgda_bn_finalize(const float* stats, float* mi, float* running_me
 }
 
 // per-channel batch statistics of one row group from the replicated (sum, sumsq) accumulators
-static __device__ __forceinline__ void group_stats(const float* __restrict__ stats, int grp, int C, int cg, float invM,
+static __device__ __forceinline__ void group_stats(const rgda_stat_t* __restrict__ stats, int grp, int C, int cg, float invM,
                                                    float eps, float (&mean)[8], float (&istd)[8], float (&var)[8]) {
-    const float* st = stats + (size_t)grp * NREP * 2 * C;
+    const rgda_stat_t* st = stats + (size_t)grp * NREP * 2 * C;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < NREP; ++r) { s0 += st[(size_t)(2 * r) * C + cg + e]; s1 += st[(size_t)(2 * r + 1) * C + cg + e]; }
-        float m = s0 * invM;
-        float v = fmaxf(s1 * invM - m * m, 0.f);
-        mean[e] = m;
-        var[e] = v;
-        istd[e] = 1.f / sqrtf(v + eps);
-    }
+    for (int e = 0; e < 8; ++e) stat_moments(st, C, cg + e, (double)invM, eps, mean[e], var[e], istd[e]);
 }
 
 // ------------------------------------------------------------------ BN apply (forward)
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
                                                        int ldres, const float* __restrict__ nscale, int rpi,
                                                        bf16_t* __restrict__ y, int ldy, long long M, int C, int relu,
                                                        int vpb, int rpb, int rows_per_block, int bpg,
-                                                       const float* __restrict__ stats, float* mi_out, float* rm,
+                                                       const rgda_stat_t* __restrict__ stats, float* mi_out, float* rm,
                                                        float* rv, long long* nbt, int groups, float eps, float mom,
                                                        uint8_t* __restrict__ mask_out) {
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
@@ -220,16 +221,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
     if (stats) {
         // train mode with the finalize step folded in: the workgroup rebuilds mean / invstd of its vpb*8 channels
         // from the conv epilogue's replicated accumulators, one channel per thread, and shares them through LDS
-        const float invM = 1.f / (float)M;
-        const float* st = stats + (size_t)grp * NREP * 2 * C;
+        const double invM = 1.0 / (double)M;
+        const rgda_stat_t* st = stats + (size_t)grp * NREP * 2 * C;
         for (int c = threadIdx.x; c < vpb * 8; c += 256) {
             int cc = blockIdx.y * vpb * 8 + c;
             if (cc < C) {
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int r = 0; r < NREP; ++r) { s0 += st[(size_t)(2 * r) * C + cc]; s1 += st[(size_t)(2 * r + 1) * C + cc]; }
-                float m = s0 * invM;
-                const float is = 1.f / sqrtf(fmaxf(s1 * invM - m * m, 0.f) + eps);
+                float m, v0, is;
+                stat_moments(st, C, cc, invM, eps, m, v0, is);
                 smean[c] = m;
                 sistd[c] = is;
                 if (chunk == 0) {
@@ -245,12 +243,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
                         for (int g = 0; g < 8; ++g) {
                             if (g < groups) {
-                                const float* sg = stats + (size_t)g * NREP * 2 * C;
-                                float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-                                for (int r = 0; r < NREP; ++r) { t0 += sg[(size_t)(2 * r) * C + cc]; t1 += sg[(size_t)(2 * r + 1) * C + cc]; }
-                                gm[g] = t0 * invM;
-                                gv[g] = fmaxf(t1 * invM - gm[g] * gm[g], 0.f);
+                                float gis;
+                                stat_moments(stats + (size_t)g * NREP * 2 * C, C, cc, invM, eps, gm[g], gv[g], gis);
                             }
                         }
                         float a = rm[cc], b = rv[cc];
@@ -367,7 +361,7 @@ extern "C" int rgda_bn_apply(const void* x, int ldx, const float* mi, const floa
     return RGDA_OK;
 }
 
-extern "C" int rgda_bn_train_apply(const void* x, int ldx, const float* stats, float* mi, float* running_mean,
+extern "C" int rgda_bn_train_apply(const void* x, int ldx, const rgda_stat_t* stats, float* mi, float* running_mean,
                                    float* running_var, int64_t* num_batches_tracked, const float* gamma,
                                    const float* beta, const void* res, int ldres, const float* nscale,
                                    int rows_per_image, void* y, int ldy, uint8_t* relu_mask, int64_t M, int C,
@@ -396,7 +390,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                                                             const uint8_t* __restrict__ rmask,
                                                             const bf16_t* __restrict__ x, int ldx,
                                                             const float* __restrict__ mi, const float* __restrict__ nscale,
-                                                            int rpi, float* sums, long long M, int C, int relu, int vpb,
+                                                            int rpi, rgda_stat_t* sums, long long M, int C, int relu, int vpb,
                                                             int rpb, int rows_per_block, int bpg) {
     __shared__ float lds[256 * 16];
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
@@ -455,13 +449,13 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
             }
         }
     }
-    float* rep = sums + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NREP - 1)) * 2 * C;
-    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, rep, rep + C, lds);
+    rgda_stat_t* rep = sums + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (NREP - 1)) * 2 * C;
+    block_reduce_atomic(s, q, cvl, rl, vpb, rpb, cg, cok, rep, rep + C, lds, RGDA_STAT_FRAC_BWD);
 }
 
 extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask,
                                   const void* x, int ldx, const float* mi, const float* nscale, int rows_per_image,
-                                  float* sums, int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
+                                  rgda_stat_t* sums, int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
     if (!g || !x || !mi || !sums || (relu && !y && !relu_mask) || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || (ldx & 7)) return RGDA_ERR_ARG;
     if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     hipStream_t st = to_stream(stream);
@@ -489,7 +483,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ x, int ldx,
                                                            const float* __restrict__ mi, const float* __restrict__ gamma,
                                                            const float* __restrict__ nscale, int rpi,
-                                                           const float* __restrict__ sums, bf16_t* __restrict__ dx,
+                                                           const rgda_stat_t* __restrict__ sums, bf16_t* __restrict__ dx,
                                                            int lddx, bf16_t* __restrict__ gmask, int ldgm, float* dgamma,
                                                            float* dbeta, long long M, int C, int relu, int vpb, int rpb,
                                                            int rows_per_block, int bpg) {
@@ -508,18 +502,27 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     for (int c = threadIdx.x; c < vpb * 8; c += 256) {
         const int cc = blockIdx.y * vpb * 8 + c;
         if (cc < C) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < NREP; ++r) { t1 += sums[(size_t)(2 * r) * C + cc]; t2 += sums[(size_t)(2 * r + 1) * C + cc]; }
+            const float t1 = (float)stat_total(sums, C, cc, 0, RGDA_STAT_FRAC_BWD);
+            const float t2 = (float)stat_total(sums, C, cc, 1, RGDA_STAT_FRAC_BWD);
             const float is = mi[C + cc];
             sk0[0 * nch + c] = mi[cc];
             sk0[1 * nch + c] = is;
             sk0[2 * nch + c] = gamma[cc] * is;
             sk0[3 * nch + c] = t1 * invM;
             sk0[4 * nch + c] = t2 * invM;
-            if (chunk == 0 && dgamma) {      // one workgroup per group folds that group's sums into the grads
-                atomicAdd(dgamma + cc, t2);
-                atomicAdd(dbeta + cc, t1);
+            if (chunk == 0 && grp == 0 && dgamma) {
+                // ONE workgroup per channel block folds the sums of every group into the parameter gradients, group
+                // after group (a fixed order: nothing depends on which group's workgroup retires first).  The add itself
+                // is the fire-and-forget atomic: a plain read-modify-write puts two dependent memory round trips in front
+                // of this workgroup's barrier (+0.7 ms per step when the weight gradients keep the memory system busy)
+                const int groups = gridDim.x / bpg;
+                float dg = t2, db = t1;
+                for (int g2 = 1; g2 < groups; ++g2) {
+                    dg += (float)stat_total(sums + (size_t)g2 * NREP * 2 * C, C, cc, 1, RGDA_STAT_FRAC_BWD);
+                    db += (float)stat_total(sums + (size_t)g2 * NREP * 2 * C, C, cc, 0, RGDA_STAT_FRAC_BWD);
+                }
+                atomicAdd(dgamma + cc, dg);
+                atomicAdd(dbeta + cc, db);
             }
         }
     }
@@ -586,7 +589,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
 extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask,
                                  const void* x, int ldx,
                                  const float* mi, const float* gamma, const float* nscale, int rows_per_image,
-                                 const float* sums, void* dx, int lddx, void* gmask, int ldgm, float* dgamma,
+                                 const rgda_stat_t* sums, void* dx, int lddx, void* gmask, int ldgm, float* dgamma,
                                  float* dbeta, int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
     if (!g || !x || !mi || !gamma || !sums || !dx || (relu && !y && !relu_mask) || M <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
     if ((ldg & 7) || (ldx & 7) || (lddx & 7) || (gmask && (ldgm & 7)) || ((dgamma == nullptr) != (dbeta == nullptr)))

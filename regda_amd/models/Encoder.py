@@ -1181,10 +1181,11 @@ class Deeplabv2(nn.Module):
 
 
 class _StatsPool:
-    """One zero-initialised fp32 arena per forward for every BatchNorm's (sum, sumsq) accumulator."""
+    """One zero-initialised arena per forward for every BatchNorm's (sum, sumsq) accumulator (rgda_stat_t: 64-bit
+    fixed point, order-independent totals -- include/rgda_hip.h)."""
 
     def __init__(self, n, device):
-        self.buf = torch.empty(n, device=device)
+        self.buf = torch.empty(n, dtype=torch.int64, device=device)
         plan.host(self.buf.zero_)
         self.off = 0
 

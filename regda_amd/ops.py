@@ -42,6 +42,25 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+STAT_FRAC_FWD, STAT_FRAC_BWD = 26, 40       # RGDA_STAT_FRAC_FWD / _BWD (include/rgda_hip.h, checked by tests/test_abi.py)
+
+
+def new_stats(*shape, device='cuda'):
+    """A zeroed per-channel accumulator, rgda_stat_t[...][RGDA_STAT_REPLICAS][2][C] (64-bit fixed point)."""
+    return torch.zeros(*shape, dtype=torch.int64, device=device)
+
+
+def stats_value(stats, backward=False):
+    """Accumulators -> float64 values (sum over nothing: the caller still adds up the replica axis)."""
+    return stats.double() * 2.0 ** -(STAT_FRAC_BWD if backward else STAT_FRAC_FWD)
+
+
+def _stat(t):
+    if t is not None and t.dtype != torch.int64:
+        raise TypeError('BatchNorm statistic accumulators are int64 fixed point (ops.new_stats), got %s' % t.dtype)
+    return _p(t)
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -225,11 +244,11 @@ def _ld(t):
 def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1,
            res_mask=None):
     """x [N*H*W, Cin(view)], w bf16 [Cout, kh*kw, Cin] contiguous, y [N*Ho*Wo, Cout(view)].
-    stats: f32 [stat_groups][8][2][Cout] accumulators (zeroed by the caller)."""
+    stats: rgda_stat_t (int64) [stat_groups][8][2][Cout] accumulators (zeroed by the caller; ops.new_stats)."""
     Cout, taps, Cin = w.shape
     assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
     lib().call('rgda_conv2d', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
-               _ld(res) if res is not None else 0, _p(res_mask), _p(stats), stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
+               _ld(res) if res is not None else 0, _p(res_mask), _stat(stats), stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
                pad, dil, mode, _stream())
 
 
@@ -248,7 +267,7 @@ def conv2d_bnbwd(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, 
     Cout, taps, Cin = w.shape
     assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
     lib().call('rgda_conv2d_bnbwd', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
-               _ld(res) if res is not None else 0, _p(res_mask), sums.data_ptr(), groups, _p(bn_y), _ld(bn_y) if bn_y is not None else 0,
+               _ld(res) if res is not None else 0, _p(res_mask), _stat(sums), groups, _p(bn_y), _ld(bn_y) if bn_y is not None else 0,
                _p(relu_mask), bn_x.data_ptr(), _ld(bn_x), bn_mi.data_ptr(), _p(nscale), rows_per_image, int(relu), N, H, W, Cin, Ho, Wo,
                Cout, kh, kw, stride, pad, dil, mode, _stream())
 
@@ -257,14 +276,31 @@ def conv2d_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
     """dw f32 [Cout, kh*kw, Cin] contiguous, accumulated."""
     Cout, taps, Cin = dw.shape
     assert dw.is_contiguous() and dw.dtype == torch.float32
-    lib().call('rgda_conv2d_wgrad', x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dw.data_ptr(), N, H, W, Cin, Ho, Wo,
-               Cout, kh, kw, stride, pad, dil, _stream())
+    conv2d_wgrad_grouped([(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil)])
 
 
 class _WgradDesc(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('ldx', ctypes.c_int),
                 ('lddy', ctypes.c_int)] + [(k, ctypes.c_int) for k in
                                            ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'kh', 'kw', 'stride', 'pad', 'dil')]
+
+
+_WGRAD_WS = {}          # (device index, raw stream) -> workspace of the weight-gradient launches issued on that stream
+_WGRAD_WS_OLD = []      # outgrown workspaces stay allocated: a recorded plan (regda_amd/plan.py) may hold their address
+
+
+def _wgrad_ws(nbytes, device):
+    """The split-K workspace of the current stream (rgda_conv2d_wgrad: counters zeroed once, calls ordered on one
+    stream share it).  Grown on demand; never freed."""
+    key = (device.index, _stream())
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _WGRAD_WS_OLD.append(ws)
+        ws = torch.empty(max(nbytes, 32 << 20), dtype=torch.uint8, device=device)
+        ws[:65536].zero_()
+        _WGRAD_WS[key] = ws
+    return ws
 
 
 def conv2d_wgrad_grouped(items):
@@ -279,7 +315,10 @@ def conv2d_wgrad_grouped(items):
         d.x, d.dy, d.dw, d.ldx, d.lddy = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ld(x), _ld(dy)
         d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
         d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
-    lib().call('rgda_conv2d_wgrad_grouped', ctypes.cast(arr, ctypes.c_void_p), len(items), _stream())
+    L = lib()
+    ap = ctypes.cast(arr, ctypes.c_void_p)
+    ws = _wgrad_ws(L.size('rgda_conv2d_wgrad_workspace', ap, len(items)), items[0][0].device)
+    L.call('rgda_conv2d_wgrad_grouped', ap, len(items), ws.data_ptr(), ws.numel(), _stream())
 
 
 def stem_im2col(img, col, N, H, W, Ho, Wo):
@@ -287,11 +326,11 @@ def stem_im2col(img, col, N, H, W, Ho, Wo):
 
 
 def bn_stats(x, stats, M, C):
-    lib().call('rgda_bn_stats', x.data_ptr(), _ld(x), stats.data_ptr(), M, C, _stream())
+    lib().call('rgda_bn_stats', x.data_ptr(), _ld(x), _stat(stats), M, C, _stream())
 
 
 def bn_finalize(stats, mi, rm, rv, nbt, M, C, eps=1e-5, momentum=0.1, groups=1):
-    lib().call('rgda_bn_finalize', _p(stats), mi.data_ptr(), _p(rm), _p(rv), _p(nbt), M, C, groups, eps, momentum,
+    lib().call('rgda_bn_finalize', _stat(stats), mi.data_ptr(), _p(rm), _p(rv), _p(nbt), M, C, groups, eps, momentum,
                _stream())
 
 
@@ -303,7 +342,7 @@ def bn_apply(x, mi, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_
 
 def bn_train_apply(x, stats, mi, rm, rv, nbt, gamma, beta, y, M, C, relu, res=None, nscale=None, rows_per_image=0,
                    groups=1, eps=1e-5, momentum=0.1, relu_mask=None):
-    lib().call('rgda_bn_train_apply', x.data_ptr(), _ld(x), stats.data_ptr(), mi.data_ptr(), _p(rm), _p(rv), _p(nbt),
+    lib().call('rgda_bn_train_apply', x.data_ptr(), _ld(x), _stat(stats), mi.data_ptr(), _p(rm), _p(rv), _p(nbt),
                gamma.data_ptr(), beta.data_ptr(), _p(res), _ld(res) if res is not None else 0, _p(nscale),
                rows_per_image, y.data_ptr(), _ld(y), _p(relu_mask), M, C, int(relu), groups, eps, momentum, _stream())
 
@@ -311,14 +350,14 @@ def bn_train_apply(x, stats, mi, rm, rv, nbt, gamma, beta, y, M, C, relu, res=No
 def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0, groups=1, relu_mask=None):
     lib().call('rgda_bn_bwd_reduce', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, _p(relu_mask),
                x.data_ptr(), _ld(x),
-               mi.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), M, C, int(relu), groups, _stream())
+               mi.data_ptr(), _p(nscale), rows_per_image, _stat(sums), M, C, int(relu), groups, _stream())
 
 
 def bn_bwd_apply(g, y, x, mi, gamma, sums, dx, M, C, relu, gmask=None, dgamma=None, dbeta=None, nscale=None,
                  rows_per_image=0, groups=1, relu_mask=None):
     lib().call('rgda_bn_bwd_apply', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, _p(relu_mask),
                x.data_ptr(), _ld(x),
-               mi.data_ptr(), gamma.data_ptr(), _p(nscale), rows_per_image, sums.data_ptr(), dx.data_ptr(), _ld(dx),
+               mi.data_ptr(), gamma.data_ptr(), _p(nscale), rows_per_image, _stat(sums), dx.data_ptr(), _ld(dx),
                _p(gmask), _ld(gmask) if gmask is not None else 0, _p(dgamma), _p(dbeta), M, C, int(relu), groups,
                _stream())
 

@@ -78,7 +78,11 @@ class SSLStep:
         assert not self.first, 'run one eager step before capture()'
         if self.world > 1:
             raise RuntimeError('whole-step graphs are single-GPU; the multi-GPU path stays eager')
-        self._static = [None if t is None else t.clone() for t in (images_s, label_s, images_t, soft_t, regs_t)]
+        if self.class_balancer_s is not None or self.class_balancer_t is not None:
+            # ClassBalance.next_class_weight rebinds its frequency tensor and is host arithmetic: a graph would keep the
+            # address of the pre-capture tensor and never advance the EMA.  record_plan() re-runs it as a host action.
+            raise RuntimeError('class balancing (--bcs / --bct) is host-side state: use record_plan(), not capture()')
+        self._static = self._static_inputs(images_s, label_s, images_t, soft_t, regs_t)
         torch.cuda.synchronize()
         m = self.model
         m._hw_ready = m._wt_ready = None          # everything recorded before the synchronize is complete
@@ -91,7 +95,28 @@ class SSLStep:
         m._hw_ready = m._wt_ready = None          # (they are events inside the graph now: nothing to wait for outside)
         self._graph = g
 
-    def record_plan(self, images_s, label_s, images_t, soft_t, regs_t):
+    @staticmethod
+    def _static_inputs(images_s, label_s, images_t, soft_t, regs_t):
+        """Static input buffers of a recorded / captured step, in the dtype and layout the step's kernels read (the
+        conversions `_step` would otherwise do with torch ops at record time only): fp32 contiguous images and soft
+        labels, int64 contiguous labels and region maps.  `copy_` into them converts whatever the caller passes."""
+        conv = lambda t, dt: None if t is None else t.detach().to(dt).contiguous().clone()
+        return [conv(images_s, torch.float32), conv(label_s, torch.int64), conv(images_t, torch.float32),
+                conv(soft_t, torch.float32), conv(regs_t, torch.int64)]
+
+    def teacher_model(self):
+        """The EMA teacher, ready to be evaluated or saved: shadow weights as they stand, BatchNorm buffers adopted from
+        the student NOW (the teacher keeps a snapshot, not an alias: with offline soft labels nothing else refreshes
+        it), bf16 mirror current, eval mode."""
+        t = self.teacher
+        if t is None:
+            return None
+        t.adopt_buffers(self.model)
+        t.refresh_from_master(mirror_is_fresh=not self.first)
+        t.eval()
+        return t
+
+    def record_plan(self, images_s, label_s, images_t, soft_t, regs_t, lr=None):
         """Record one whole step (all streams) as a launch plan (regda_amd/plan.py): its ~750 entry-point calls become
         rows of a table that `rgda_plan_run` walks in C, the torch ops / stream waits between them stay host actions.
         Later `step()` calls replay the plan on the recorded buffers (a private memory pool): same kernels, same
@@ -100,8 +125,11 @@ class SSLStep:
         buffers at every replay; the returned tensors (losses, `last_hard`, ...) are overwritten by the next step."""
         assert not self.first, 'run one eager step before record_plan()'
         assert self._graph is None and self._plan is None
-        self._static = [None if t is None else t.clone() for t in (images_s, label_s, images_t, soft_t, regs_t)]
+        self._static = self._static_inputs(images_s, label_s, images_t, soft_t, regs_t)
+        if lr is not None:          # recording IS a real step: run it with this learning rate (default: the last one)
+            self.lr_dev.fill_(float(lr))
         torch.cuda.synchronize()
+        self._plan_stream = torch.cuda.current_stream()
         p = plan.Plan()
 
         def run():
@@ -126,14 +154,26 @@ class SSLStep:
         return self._inputs_done.ev
 
     def _replay_plan(self, images_s, label_s, images_t, soft_t, regs_t, lr):
-        for dst, src in zip(self._static, (images_s, label_s, images_t, soft_t, regs_t)):
-            if dst is not None and src is not dst:
-                dst.copy_(src, non_blocking=True)
-        self.lr_dev.fill_(float(lr))
-        m = self.model
-        if m.flat_p._version != m._synced_version:      # weights were changed from outside (load_state_dict, ...)
-            m.sync_weights()
-        self._plan.replay()
+        # the table rows carry the stream handles of the recording: the input copies and the learning-rate fill must
+        # be ordered on that same stream, whatever stream the caller has made current
+        rec = self._plan_stream
+        cur = torch.cuda.current_stream()
+        if cur != rec:
+            rec.wait_stream(cur)
+        with ops.use_stream(rec):       # host-action entry points (class weights, ...) land on the recorded stream too
+            for dst, src in zip(self._static, (images_s, label_s, images_t, soft_t, regs_t)):
+                assert (dst is None) == (src is None), 'a recorded step keeps its input signature (soft labels or not)'
+                if dst is not None and src is not dst:
+                    dst.copy_(src, non_blocking=True)
+            self.lr_dev.fill_(float(lr))
+            m = self.model
+            if not m.training:
+                m.train()
+            if m.flat_p._version != m._synced_version:      # weights were changed from outside (load_state_dict, ...)
+                m.sync_weights()
+            self._plan.replay()
+        if cur != rec:
+            cur.wait_stream(rec)
         return self._out
 
     def _replay(self, images_s, label_s, images_t, soft_t, regs_t, lr):

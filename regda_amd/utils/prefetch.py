@@ -31,6 +31,10 @@ class DevicePrefetcher:
         self.consumed = [None] * depth      # event: the step that read the slot has been enqueued and finished with it
         self.i = 0                          # index of the next batch handed out
         self.bytes_per_batch = sum(v.numel() * v.element_size() for v in self.host[0].values() if v is not None)
+        if self.single:
+            # `into` are the live input buffers of a recorded step: whatever has been enqueued on the current stream so
+            # far (a step still reading them) must be done before the first batch lands there
+            self.consumed[0] = torch.cuda.current_stream().record_event()
         self._stage(0)
 
     def _stage(self, i):

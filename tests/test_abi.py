@@ -7,7 +7,13 @@ from regda_amd import _lib
 def test_library_loads_and_exports_all_symbols():
     L = _lib.lib()
     assert L.missing == [], f'declared but not exported: {L.missing}'
-    assert L.raw('rgda_abi_version')() == 3
+    assert L.raw('rgda_abi_version')() == 4
+    # the fixed-point formats of the per-channel accumulators (rgda_stat_t) as the Python side scales them
+    import re
+    from regda_amd import ops
+    hdr = open(_lib.HEADER_PATH).read()
+    assert int(re.search(r'#define\s+RGDA_STAT_FRAC_FWD\s+(\d+)', hdr).group(1)) == ops.STAT_FRAC_FWD
+    assert int(re.search(r'#define\s+RGDA_STAT_FRAC_BWD\s+(\d+)', hdr).group(1)) == ops.STAT_FRAC_BWD
     assert L.raw('rgda_strerror')(0) == b'ok'
     assert b'workspace' in L.raw('rgda_strerror')(-2)
     assert len(L.protos) >= 30
@@ -39,9 +45,9 @@ def test_plan_replay_dispatch_table_and_error_rows():
     assert L.raw('rgda_plan_fn_id')(b'rgda_lrh_workspace') == -1 and L.raw('rgda_plan_fn_id')(b'nope') == -1
     assert max(len(a) for _, a in L.protos.values()) <= MAX_ARGS
     rows = (PlanEntry * 3)()
-    rows[0].fn, rows[0].nargs = ids['rgda_conv2d_wgrad_grouped'], 3          # (NULL, 0, stream): a valid empty list
+    rows[0].fn, rows[0].nargs = ids['rgda_conv2d_wgrad_grouped'], 5          # (NULL, 0, NULL, 0, stream): a valid empty list
     rows[1].fn, rows[1].nargs = ids['rgda_lrh'], len(L.protos['rgda_lrh'][1])    # null pointers -> RGDA_ERR_ARG
-    rows[2].fn, rows[2].nargs = ids['rgda_conv2d_wgrad_grouped'], 3
+    rows[2].fn, rows[2].nargs = ids['rgda_conv2d_wgrad_grouped'], 5
     failed = ctypes.c_int(-1)
     assert L.raw('rgda_plan_run')(rows, 1, ctypes.byref(failed)) == 0 and failed.value == -1
     assert L.raw('rgda_plan_run')(rows, 3, ctypes.byref(failed)) == -1 and failed.value == 1

@@ -73,14 +73,14 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     xg = to_pxc(x)
     wg = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin).to(BF).cuda().contiguous()
     y = torch.zeros(N * Ho * Wo, Cout, dtype=BF, device='cuda')
-    stats = torch.zeros(8, 2, Cout, device='cuda')
+    stats = ops.new_stats(8, 2, Cout)
     ops.conv2d(xg, wg, y, N, H, W, Ho, Wo, k, k, s, p, d, 0, None, stats, 1)
     out = from_pxc(y, N, Ho, Wo)
     assert relerr(out, ref) < 1e-2, 'forward'
     # BatchNorm statistics fused in the epilogue (of the bf16-rounded outputs)
     yf = y.float()
-    torch.testing.assert_close(stats.sum(0)[0].cpu(), yf.sum(0).cpu(), rtol=1e-3, atol=1e-2)
-    torch.testing.assert_close(stats.sum(0)[1].cpu(), (yf * yf).sum(0).cpu(), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(ops.stats_value(stats).sum(0)[0].float().cpu(), yf.sum(0).cpu(), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(ops.stats_value(stats).sum(0)[1].float().cpu(), (yf * yf).sum(0).cpu(), rtol=1e-3, atol=1e-2)
     # data gradient = conv in mode 1 with [Cin][tap][Cout] weights (+ residual add in the epilogue)
     dy = rbf(torch.randn(N, Cout, Ho, Wo, generator=g))
     xr = x.clone().requires_grad_(True)
@@ -202,7 +202,7 @@ def test_batchnorm_fwd_bwd(ops, N, C, H, W):
     go = rbf(torch.randn(N, C, H, W, generator=g))
     yr.backward(go)
     xg = to_pxc(x)
-    stats = torch.zeros(8, 2, C, device='cuda')
+    stats = ops.new_stats(8, 2, C)
     ops.bn_stats(xg, stats, M, C)
     mi = torch.empty(2, C, device='cuda')
     rmg, rvg, nbt = rm.cuda(), rv.cuda(), torch.zeros((), dtype=torch.int64, device='cuda')
@@ -213,7 +213,7 @@ def test_batchnorm_fwd_bwd(ops, N, C, H, W):
     y = torch.empty(M, C, dtype=BF, device='cuda')
     ops.bn_apply(xg, mi, gamma.cuda(), beta.cuda(), y, M, C, True, to_pxc(res))
     assert relerr(from_pxc(y, N, H, W), yr.detach()) < 1e-2
-    sums = torch.zeros(8, 2, C, device='cuda')
+    sums = ops.new_stats(8, 2, C)
     gg = to_pxc(go)
     ops.bn_bwd_reduce(gg, y, xg, mi, sums, M, C, True)
     dx = torch.empty(M, C, dtype=BF, device='cuda')
@@ -247,7 +247,7 @@ def test_relu_sign_mask_replaces_y_in_the_backward_kernels(ops, C):
     res = torch.randn(M, C, generator=g).to(BF).cuda()
     gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
     ns = ((torch.rand(N, C, generator=g) > 0.2).float() / 0.8).cuda()
-    stats = torch.zeros(G, 8, 2, C, device='cuda')
+    stats = ops.new_stats(G, 8, 2, C)
     for gi in range(G):
         ops.bn_stats(x[gi * M // G:(gi + 1) * M // G], stats[gi], M // G, C)
     mi = torch.empty(G, 2, C, device='cuda')
@@ -263,13 +263,13 @@ def test_relu_sign_mask_replaces_y_in_the_backward_kernels(ops, C):
     out = {}
     for tag, kw in (('y', dict()), ('mask', dict(relu_mask=mask))):
         yy = y if tag == 'y' else None
-        sums = torch.zeros(G, 8, 2, C, device='cuda')
+        sums = ops.new_stats(G, 8, 2, C)
         ops.bn_bwd_reduce(go, yy, x, mi, sums, M, C, True, ns, H * W, groups=G, **kw)
         dx = torch.empty(M, C, dtype=BF, device='cuda')
         gm = torch.empty(M, C, dtype=BF, device='cuda')
         dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
         ops.bn_bwd_apply(go, yy, x, mi, gamma, sums, dx, M, C, True, gm, dgam, dbet, ns, H * W, groups=G, **kw)
-        out[tag] = (sums.sum(1), dx, gm, dgam, dbet)
+        out[tag] = (ops.stats_value(sums, backward=True).sum(1).float(), dx, gm, dgam, dbet)
     for a, b in zip(out['y'][1:3], out['mask'][1:3]):
         assert torch.equal(a, b)
     for a, b in zip((out['y'][0],) + out['y'][3:], (out['mask'][0],) + out['mask'][3:]):
@@ -281,10 +281,10 @@ def test_relu_sign_mask_replaces_y_in_the_backward_kernels(ops, C):
         got = []
         for tag in ('y', 'mask'):
             dx = torch.empty(M, C, dtype=BF, device='cuda')
-            sums = torch.zeros(G, 8, 2, C, device='cuda')
+            sums = ops.new_stats(G, 8, 2, C)
             ops.conv2d_bnbwd(dy, wt, dx, N, H, W, H, W, k, k, 1, 1, 1, 1, res, sums, G, y if tag == 'y' else None, x, mi,
                              True, ns, H * W, relu_mask=mask if tag == 'mask' else None)
-            got.append((dx, sums.sum(1)))
+            got.append((dx, ops.stats_value(sums, backward=True).sum(1).float()))
         assert torch.equal(got[0][0], got[1][0])
         torch.testing.assert_close(got[0][1], got[1][1], rtol=1e-5, atol=1e-3)
 
@@ -445,7 +445,7 @@ def test_batchnorm_bwd_with_dropout_scale(ops, C, N, HW):
     go = rbf(torch.randn(N, C, HW, generator=g))
     yr.backward(go)
     xg = x.to(BF).cuda()
-    stats = torch.zeros(8, 2, C, device='cuda')
+    stats = ops.new_stats(8, 2, C)
     ops.bn_stats(xg, stats, M, C)
     mi = torch.empty(2, C, device='cuda')
     ops.bn_finalize(stats, mi, None, None, None, M, C)
@@ -454,7 +454,7 @@ def test_batchnorm_bwd_with_dropout_scale(ops, C, N, HW):
     ref_y = yr.detach().permute(0, 2, 1).reshape(M, C)
     assert relerr(y.float().cpu(), ref_y) < 1e-2
     gg = go.permute(0, 2, 1).reshape(M, C).to(BF).cuda().contiguous()
-    sums = torch.zeros(8, 2, C, device='cuda')
+    sums = ops.new_stats(8, 2, C)
     ops.bn_bwd_reduce(gg, y, xg, mi, sums, M, C, True, ns.cuda(), HW)
     dx = torch.empty(M, C, dtype=BF, device='cuda')
     dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
@@ -478,14 +478,15 @@ def test_conv_dgrad_with_fused_bn_backward_reduction(ops, groups):
     mi = torch.stack([torch.randn(groups, Cf, generator=g) * 0.1, torch.rand(groups, Cf, generator=g) + 0.5], 1).cuda().contiguous()
     ns = ((torch.rand(N, Cf, generator=g) > 0.2).float() / 0.8).cuda()
     dx = torch.empty(M, Cf, dtype=BF, device='cuda')
-    sums = torch.zeros(groups, 8, 2, Cf, device='cuda')
+    sums = ops.new_stats(groups, 8, 2, Cf)
     ops.conv2d_bnbwd(dy, wt, dx, N, H, W, H, W, k, k, 1, 1, 1, 1, res, sums, groups, cy, cx, mi, True, ns, H * W)
     dx2 = torch.empty_like(dx)
     ops.conv2d(dy, wt, dx2, N, H, W, H, W, k, k, 1, 1, 1, 1, res, None)
     assert torch.equal(dx, dx2)
-    ref = torch.zeros(groups, 8, 2, Cf, device='cuda')
+    ref = ops.new_stats(groups, 8, 2, Cf)
     ops.bn_bwd_reduce(dx, cy, cx, mi, ref, M, Cf, True, ns, H * W, groups=groups)
-    torch.testing.assert_close(sums.sum(1).cpu(), ref.sum(1).cpu(), rtol=2e-4, atol=2e-2)
+    torch.testing.assert_close(ops.stats_value(sums, backward=True).sum(1).float().cpu(),
+                               ops.stats_value(ref, backward=True).sum(1).float().cpu(), rtol=2e-4, atol=2e-2)
 
 
 def test_weight_layout_table_modes(ops):
@@ -645,13 +646,13 @@ def test_large_1x1_conv_plain_residual_and_statistics(ops, N, H, W, Ci, Co):
     assert torch.equal(y, ref.to(BF)) or relerr(y.float().cpu(), ref.cpu()) < 4e-3
     # statistics of the STORED values, per group (2 groups = source / target batch), summed over the replicas
     groups = 2
-    st = torch.zeros(groups, 8, 2, Co, device='cuda')
+    st = ops.new_stats(groups, 8, 2, Co)
     y2 = torch.empty_like(y)
     ops.conv2d(x, w, y2, N, H, W, H, W, 1, 1, 1, 0, 1, 0, stats=st, stat_groups=groups)
     assert torch.equal(y2, y)
     yg = y.float().view(groups, M // groups, Co)
-    torch.testing.assert_close(st.sum(1)[:, 0].cpu(), yg.sum(1).cpu(), rtol=1e-4, atol=0.5)
-    torch.testing.assert_close(st.sum(1)[:, 1].cpu(), (yg * yg).sum(1).cpu(), rtol=1e-4, atol=0.5)
+    torch.testing.assert_close(ops.stats_value(st).sum(1)[:, 0].float().cpu(), yg.sum(1).cpu(), rtol=1e-4, atol=0.5)
+    torch.testing.assert_close(ops.stats_value(st).sum(1)[:, 1].float().cpu(), (yg * yg).sum(1).cpu(), rtol=1e-4, atol=0.5)
     # residual added before the store
     y3 = torch.empty_like(y)
     ops.conv2d(x, w, y3, N, H, W, H, W, 1, 1, 1, 0, 1, 0, res, None)
@@ -679,14 +680,15 @@ def test_large_1x1_conv_fused_bn_backward_sums_and_masks(ops):
     cx = torch.randn(M, Cf, generator=g).to(BF).cuda()
     mi = torch.stack([torch.randn(groups, Cf, generator=g) * 0.1, torch.rand(groups, Cf, generator=g) + 0.5], 1).cuda().contiguous()
     dx = torch.empty(M, Cf, dtype=BF, device='cuda')
-    sums = torch.zeros(groups, 8, 2, Cf, device='cuda')
+    sums = ops.new_stats(groups, 8, 2, Cf)
     ops.conv2d_bnbwd(dy, wt, dx, N, H, W, H, W, 1, 1, 1, 0, 1, 1, res, sums, groups, cy, cx, mi, True, res_mask=rmask)
     gated = torch.where(keep.cuda(), res, torch.zeros_like(res))
     ref = dy.float() @ wt.float().view(Cf, Cb).t() + gated.float()
     assert relerr(dx.float().cpu(), ref.cpu()) < 8e-3
-    want = torch.zeros(groups, 8, 2, Cf, device='cuda')
+    want = ops.new_stats(groups, 8, 2, Cf)
     ops.bn_bwd_reduce(dx, cy, cx, mi, want, M, Cf, True, groups=groups)
-    torch.testing.assert_close(sums.sum(1).cpu(), want.sum(1).cpu(), rtol=2e-4, atol=0.5)
+    torch.testing.assert_close(ops.stats_value(sums, backward=True).sum(1).float().cpu(),
+                               ops.stats_value(want, backward=True).sum(1).float().cpu(), rtol=2e-4, atol=0.5)
 
 
 def test_large_1x1_conv_inference_batchnorm(ops):
@@ -756,13 +758,13 @@ def test_big_tile_forward_statistics_residual(ops, N, H, W, Ci, Co, k, pad, dil)
     ops.conv2d(x, w, y, N, H, W, H, W, k, k, 1, pad, dil, 0)
     assert relerr(y.float(), ref) < 6e-3 and rel_l2(y, ref) < 3e-3          # one bf16 rounding of the output
     # residual added before the store + per-group statistics of the STORED values (the head conv's epilogue)
-    st = torch.zeros(groups, 8, 2, Co, device='cuda')
+    st = ops.new_stats(groups, 8, 2, Co)
     y2 = torch.empty_like(y)
     ops.conv2d(x, w, y2, N, H, W, H, W, k, k, 1, pad, dil, 0, res, st, groups)
     assert rel_l2(y2, ref + res.float()) < 4e-3
     yg = y2.float().view(groups, M // groups, Co)
-    torch.testing.assert_close(st.sum(1)[:, 0], yg.sum(1), rtol=1e-4, atol=0.5)
-    torch.testing.assert_close(st.sum(1)[:, 1], (yg * yg).sum(1), rtol=1e-4, atol=0.5)
+    torch.testing.assert_close(ops.stats_value(st).sum(1)[:, 0].float(), yg.sum(1), rtol=1e-4, atol=0.5)
+    torch.testing.assert_close(ops.stats_value(st).sum(1)[:, 1].float(), (yg * yg).sum(1), rtol=1e-4, atol=0.5)
 
 
 def test_big_tile_inference_batchnorm_epilogue(ops):
@@ -814,10 +816,11 @@ def test_big_tile_data_gradient_with_fused_bn_backward(ops, Cf, Cb, k, pad, dil)
     mi = torch.stack([torch.randn(groups, Cf, generator=g) * 0.1, torch.rand(groups, Cf, generator=g) + 0.5], 1).cuda().contiguous()
     for use_mask in (False, True):
         dx2 = torch.empty_like(dx)
-        sums = torch.zeros(groups, 8, 2, Cf, device='cuda')
+        sums = ops.new_stats(groups, 8, 2, Cf)
         ops.conv2d_bnbwd(dy, wt, dx2, N, H, W, H, W, k, k, 1, pad, dil, 1, res, sums, groups,
                          None if use_mask else cy, cx, mi, True, relu_mask=mask if use_mask else None)
         assert torch.equal(dx2, dx)
-        want = torch.zeros(groups, 8, 2, Cf, device='cuda')
+        want = ops.new_stats(groups, 8, 2, Cf)
         ops.bn_bwd_reduce(dx2, cy, cx, mi, want, M, Cf, True, groups=groups)
-        torch.testing.assert_close(sums.sum(1), want.sum(1), rtol=3e-4, atol=0.5)
+        torch.testing.assert_close(ops.stats_value(sums, backward=True).sum(1).float(),
+                                   ops.stats_value(want, backward=True).sum(1).float(), rtol=3e-4, atol=0.5)

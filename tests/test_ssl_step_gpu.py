@@ -286,8 +286,8 @@ def test_teacher_sees_the_same_batchnorm_statistics_with_and_without_stream_over
 
 def test_plan_replay_matches_the_eager_step():
     """SSLStep.record_plan(): the recorded launch table replayed by rgda_plan_run (plus its host actions) against the
-    same steps run eagerly -- same losses, BatchNorm buffers and weights up to the run-to-run noise of atomic summation
-    order, new inputs and learning rates are picked up."""
+    same steps run eagerly -- the same losses, BatchNorm buffers and weights, new inputs and learning rates are picked
+    up."""
     from regda_amd.ssl import SSLStep
     from regda_amd.synthetic import make_batch
     rt = 'resnet17t'
@@ -320,21 +320,16 @@ def test_plan_replay_matches_the_eager_step():
     m_e, st_e, out_e, host_e = run(False)
     m_p, st_p, out_p, host_p = run(True)
     assert st_p._plan is not None and st_e._plan is None
-    # the source loss is a smooth function of the weights; the target loss counts thresholded pseudo labels, whose number
-    # moves by several per cent between two EAGER runs already (BatchNorm statistics are summed with atomics)
-    # (the two trajectories also drift apart step by step: 3 % on the first steps, 8 % after five SGD updates)
-    for i, (oe, op) in enumerate(zip(out_e, out_p)):
-        assert op[0] == pytest.approx(oe[0], rel=3e-2 if i < 2 else 8e-2) and op[1] == pytest.approx(oe[1], rel=0.3)
-        assert op[2] == pytest.approx(oe[2], rel=0.3)
+    # same kernels, same streams, order-independent reductions (tests/test_determinism_gpu.py): the replayed steps
+    # reproduce the eager ones bit for bit
+    assert out_e == out_p
     # a replay is a real training step: losses move from step to step and differ between the two batches
     assert len({round(o[0], 4) for o in out_p}) == len(out_p)
-    d_e, d_p = m_e.flat_p - sd_flat(m_e, sd), m_p.flat_p - sd_flat(m_p, sd)
-    cos = (d_e @ d_p / (d_e.norm() * d_p.norm())).item()
-    assert cos > 0.95 and d_p.norm().item() == pytest.approx(d_e.norm().item(), rel=0.08)
+    d_p = m_p.flat_p - sd_flat(m_p, sd)
+    assert d_p.norm().item() > 0
     assert int(m_p.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == 2 * len(seq)
-    assert (m_p.flat_buf - m_e.flat_buf).norm().item() < 2e-2 * m_e.flat_buf.norm().item()
-    sh = (st_p.teacher.flat_p - st_e.teacher.flat_p).norm() / st_e.teacher.flat_p.norm()
-    assert sh.item() < 1e-3
+    assert torch.equal(m_p.flat_p, m_e.flat_p) and torch.equal(m_p.flat_buf, m_e.flat_buf)
+    assert torch.equal(st_p.teacher.flat_p, st_e.teacher.flat_p)
     # (host time of a replayed step vs an eager one is reported by bench.py: host_enqueue_ms_per_step; no wall-clock
     # thresholds in the parity suite)
 

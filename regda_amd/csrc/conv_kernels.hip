@@ -53,6 +53,16 @@ struct ConvArgs {
     int ev_relu;
 };
 
+// Per-workgroup timestamps and K-loop ablation switches exist in tuning builds only (`make TUNING=1`): in the product
+// library the conditions below are compile-time constants and the instrumented branches are not generated.
+#ifdef RGDA_TUNING
+#define TDBG(a) ((a).dbg)
+#define TSKIP(a) ((a).skip)
+#else
+#define TDBG(a) ((unsigned long long*)nullptr)
+#define TSKIP(a) 0
+#endif
+
 static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // block b runs on XCD b%8: give every XCD a contiguous range of logical tiles (bijective form)
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
@@ -111,7 +121,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             }
         }
     __syncthreads();
-    if (a.dbg && t == 0) a.dbg[(16384 + blockIdx.x) * 4 + 0] = __builtin_readcyclecounter();
+    if (TDBG(a) && t == 0) TDBG(a)[(16384 + blockIdx.x) * 4 + 0] = __builtin_readcyclecounter();
     constexpr int VPR = BC / 8;              // 16-byte vectors per C row
     constexpr int RPP = NT / VPR;            // rows per pass
     const int cv = t % VPR, rr = t / VPR;
@@ -202,7 +212,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             *(u16x8*)(a.y + (size_t)m * a.ldy + co) = val;
         }
     }
-    if (a.dbg && t == 0) a.dbg[(16384 + blockIdx.x) * 4 + 1] = __builtin_readcyclecounter();
+    if (TDBG(a) && t == 0) TDBG(a)[(16384 + blockIdx.x) * 4 + 1] = __builtin_readcyclecounter();
     if (a.stats && flush) {
         // lanes with equal cv inside a wave: strides VPR, 2*VPR, ... < 64
 #pragma unroll
@@ -220,7 +230,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             }
         }
         __syncthreads();
-        if (a.dbg && t == 0) a.dbg[(16384 + blockIdx.x) * 4 + 2] = __builtin_readcyclecounter();
+        if (TDBG(a) && t == 0) TDBG(a)[(16384 + blockIdx.x) * 4 + 2] = __builtin_readcyclecounter();
         if (t < 2 * BC) {
             int which = t / BC, c = t % BC;
             float tot = 0.f;
@@ -229,8 +239,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
             if (c0 + c < a.Cout) {
                 rgda_stat_t* dst = &a.stats[(((size_t)(m0 / a.rows_per_group) * NREP + replica) * 2 + which) * a.Cout + c0 + c];
 #ifdef RGDA_TUNING      // timing experiments (wrong results): 16 = no statistics atomics, 32 = fp32 atomics on the same words
-                if (a.skip & 16) {}
-                else if (a.skip & 32) atomicAdd((float*)dst, tot);
+                if (TSKIP(a) & 16) {}
+                else if (TSKIP(a) & 32) atomicAdd((float*)dst, tot);
                 else
 #endif
                 stat_add(dst, tot, a.bn_x ? RGDA_STAT_FRAC_BWD : RGDA_STAT_FRAC_FWD);
@@ -342,7 +352,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 
     const int KT = taps * (a.Cin >> 6);
     unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, twait = 0, tbar = 0;
-    if (a.dbg) tq0 = __builtin_readcyclecounter();
+    if (TDBG(a)) tq0 = __builtin_readcyclecounter();
     const int lrow = lane & 31, lk = lane >> 5;
     int stage = 0;
     if constexpr (PIPE) {
@@ -358,7 +368,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         if (2 < KT) { advance(); issue(2); }
         { const int younger = min(KT - 1, 2); if (younger == 2) WAIT_VMCNT(2 * LD); else if (younger == 1) WAIT_VMCNT(LD); else WAIT_VMCNT(0); }
         __builtin_amdgcn_s_barrier();
-        if (a.dbg) tq1 = __builtin_readcyclecounter();
+        if (TDBG(a)) tq1 = __builtin_readcyclecounter();
         bf16x8 fa[4][FI], fb[4][FJ];
         auto read_half = [&](int st, int h) {
             const unsigned char* wb = smem + st * TILE;
@@ -414,23 +424,23 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         // tile kt has landed once only the loads of the (up to STAGES-2) younger tiles are outstanding
         const int younger = min(KT - 1 - kt, STAGES - 2);
         unsigned long long tw0 = 0;
-        if (a.dbg) tw0 = __builtin_readcyclecounter();
+        if (TDBG(a)) tw0 = __builtin_readcyclecounter();
         if (younger >= 2) WAIT_VMCNT(2 * LD); else if (younger == 1) WAIT_VMCNT(LD); else WAIT_VMCNT(0);
-        if (a.dbg) { unsigned long long tw1 = __builtin_readcyclecounter(); twait += tw1 - tw0; tw0 = tw1; }
+        if (TDBG(a)) { unsigned long long tw1 = __builtin_readcyclecounter(); twait += tw1 - tw0; tw0 = tw1; }
         __builtin_amdgcn_s_barrier();
-        if (a.dbg) tbar += __builtin_readcyclecounter() - tw0;
-        if (a.dbg && kt == 0) tq1 = __builtin_readcyclecounter();
-        const bool more = kt + STAGES - 1 < KT && !(a.skip & 1);
-        if (more && !(a.skip & 4)) {
+        if (TDBG(a)) tbar += __builtin_readcyclecounter() - tw0;
+        if (TDBG(a) && kt == 0) tq1 = __builtin_readcyclecounter();
+        const bool more = kt + STAGES - 1 < KT && !(TSKIP(a) & 1);
+        if (more && !(TSKIP(a) & 4)) {
             advance();
             issue(stage >= 1 ? stage - 1 : STAGES - 1);      // (kt + STAGES - 1) % STAGES
         }
-        if (a.skip & 2) { stage = (stage == STAGES - 1) ? 0 : stage + 1; continue; }
+        if (TSKIP(a) & 2) { stage = (stage == STAGES - 1) ? 0 : stage + 1; continue; }
         const unsigned char* wb = smem + stage * TILE;
         const unsigned char* xb = wb + BC * 128;
         // all fragments of the K tile are fetched up front (4 k-steps x (FI+FJ) x 16 B per lane), then the MFMAs
         // run back to back: the LDS latency is paid once per K tile instead of once per k-step
-        if (!(a.skip & 8) || kt == 0) {       // (tuning: bit 8 keeps the first tile's fragments -> MFMA without LDS reads)
+        if (!(TSKIP(a) & 8) || kt == 0) {       // (tuning: bit 8 keeps the first tile's fragments -> MFMA without LDS reads)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -452,7 +462,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < FJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
-        if (more && (a.skip & 4)) {          // tuning: DMA issued behind the MFMAs instead of in front of the LDS reads
+        if (more && (TSKIP(a) & 4)) {          // tuning: DMA issued behind the MFMAs instead of in front of the LDS reads
             advance();
             issue(stage >= 1 ? stage - 1 : STAGES - 1);
         }
@@ -460,17 +470,17 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
     }
     }
     __syncthreads();
-    if (a.dbg) tq2 = __builtin_readcyclecounter();
+    if (TDBG(a)) tq2 = __builtin_readcyclecounter();
 
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
     conv_epilogue<BC, BP, WC, WP>(a, acc, smem, m0, c0, s, q, true, blockIdx.x & (NREP - 1));
-    if (a.dbg && t == 0) {
+    if (TDBG(a) && t == 0) {
         unsigned long long tq3 = __builtin_readcyclecounter();
-        a.dbg[blockIdx.x * 4 + 0] = tq0; a.dbg[blockIdx.x * 4 + 1] = tq1;
-        a.dbg[blockIdx.x * 4 + 2] = tq2; a.dbg[blockIdx.x * 4 + 3] = tq3;
-        a.dbg[(gridDim.x + blockIdx.x) * 4 + 0] = twait; a.dbg[(gridDim.x + blockIdx.x) * 4 + 1] = tbar;
+        TDBG(a)[blockIdx.x * 4 + 0] = tq0; TDBG(a)[blockIdx.x * 4 + 1] = tq1;
+        TDBG(a)[blockIdx.x * 4 + 2] = tq2; TDBG(a)[blockIdx.x * 4 + 3] = tq3;
+        TDBG(a)[(gridDim.x + blockIdx.x) * 4 + 0] = twait; TDBG(a)[(gridDim.x + blockIdx.x) * 4 + 1] = tbar;
     }
 #endif
 }
@@ -982,7 +992,7 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
-    if (a.dbg) tq0 = __builtin_readcyclecounter();
+    if (TDBG(a)) tq0 = __builtin_readcyclecounter();
     if (kt_beg < kt_end) {
         // transposing-read lane geometry: 16-lane group g reads a [4 k][16 col] block
         const int g = lane >> 4, la = lane & 15;
@@ -1030,7 +1040,7 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
                 if (kt_beg + s0 < kt_end) issue(kt_beg + s0, s0);
             wait_tiles_in_flight<LD>(min(2, kt_end - 1 - kt_beg));
             __builtin_amdgcn_s_barrier();
-            if (a.dbg) tq1 = __builtin_readcyclecounter();
+            if (TDBG(a)) tq1 = __builtin_readcyclecounter();
             read_half(0, 0);
             for (int kt = kt_beg; kt + 1 < kt_end; ++kt) {
                 const int nxt = (stage == 2) ? 0 : stage + 1;
@@ -1055,7 +1065,7 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
             for (int kt = kt_beg; kt < kt_end; ++kt) {
                 wait_tiles_in_flight<LD>(min(STAGES - 2, kt_end - 1 - kt));
                 __builtin_amdgcn_s_barrier();
-                if (a.dbg && kt == kt_beg) tq1 = __builtin_readcyclecounter();
+                if (TDBG(a) && kt == kt_beg) tq1 = __builtin_readcyclecounter();
                 if (kt + STAGES - 1 < kt_end) issue(kt + STAGES - 1, stage >= 1 ? stage - 1 : STAGES - 1);
                 read_half(stage, 0);
                 read_half(stage, 1);
@@ -1069,7 +1079,7 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
     // ordered sum of all partials), so the result does not depend on any arrival order.  The add itself is still the
     // fire-and-forget fp32 atomic (a plain read-modify-write is a dependent memory round trip per element: +3 ms/step).
     // 32-bit element offsets off one base (a layer's dW is far below 2^31 elements): no 64-bit multiplies here.
-    if (a.dbg) tq2 = __builtin_readcyclecounter();
+    if (TDBG(a)) tq2 = __builtin_readcyclecounter();
     if (a.splits > 1 && a.ws_part) {
         __syncthreads();                   // every wave is done with the LDS ring
         f32x16 (&flat)[FI * FJ] = *reinterpret_cast<f32x16 (*)[FI * FJ]>(&acc[0][0]);
@@ -1100,9 +1110,9 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
                 }
             }
         }
-    if (a.dbg && t == 0) {
-        a.dbg[blockIdx.x * 4 + 0] = tq0; a.dbg[blockIdx.x * 4 + 1] = tq1;
-        a.dbg[blockIdx.x * 4 + 2] = tq2; a.dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+    if (TDBG(a) && t == 0) {
+        TDBG(a)[blockIdx.x * 4 + 0] = tq0; TDBG(a)[blockIdx.x * 4 + 1] = tq1;
+        TDBG(a)[blockIdx.x * 4 + 2] = tq2; TDBG(a)[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
     }
 #endif
 }

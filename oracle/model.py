@@ -105,6 +105,19 @@ def _rb(x):
     return x + (x.to(torch.bfloat16).float() - x).detach()
 
 
+class _RoundBoth(torch.autograd.Function):
+    """Round to bf16 in the forward pass AND round the gradient that flows back through this point to bf16: the HIP path
+    keeps the activation gradients (data-gradient outputs, BatchNorm-backward outputs) in bf16 as well."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
 def aspp_head(x, weights, biases, dilations=ASPP_DILATIONS):
     """Classifier_Module.forward (Encoder.py:80-84): sum of Conv2d(3x3, padding = dilation = d, bias)(x)."""
     out = None
@@ -137,7 +150,8 @@ def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_
             taps[name] = t
         return t
 
-    rb = _rb if emulate_bf16 else (lambda t: t)
+    # emulate_bf16 = 'grad': the activation gradients are rounded at the same points too (tests/golden/derive_tolerances.py)
+    rb = (_RoundBoth.apply if emulate_bf16 == 'grad' else _rb) if emulate_bf16 else (lambda t: t)
     aspp = 'layer5.conv2d_list.0.weight' in sd
     if emulate_bf16:
         sd = {k: (_rb(v) if (v.dim() == 4 and 'conv_last.4' not in k) else v) for k, v in sd.items()}

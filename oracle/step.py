@@ -14,9 +14,13 @@ class CpuStep:
     def __init__(self, sd, prototypes, resnet_type='resnet101', class_num=6, ignore_label=-1,
                  lr=1e-2, momentum=0.9, weight_decay=5e-4, max_norm=32.0,
                  cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996,
-                 refine_temp=2.0, sam_refine=True, balancer_s=None, balancer_t=None):
+                 refine_temp=2.0, sam_refine=True, balancer_s=None, balancer_t=None, emulate_bf16=False):
         # balancer_s / balancer_t: labelpath.ClassBalanceState (--bcs / --bct, train_ssl_reg.py:125-158) or None
         self.balancer_s, self.balancer_t = balancer_s, balancer_t
+        # emulate_bf16: the network rounds to bf16 where the HIP path stores bf16 (oracle/model.py: forward); fp32
+        # accumulation, fp32 label path and optimizer.  tests/golden/derive_tolerances.py uses the difference between the
+        # two modes as the rounding-noise scale the GPU tolerances are stated in.
+        self.emulate_bf16 = emulate_bf16
         self.sd = {k: v.clone() for k, v in sd.items()}
         self.names = model.param_names(self.sd)
         for k in self.names:
@@ -35,11 +39,11 @@ class CpuStep:
         t0 = time.time()
         sd = self.sd
         ns = {}
-        s1, s2, feat_s = model.forward(sd, images_s, True, drop_masks_s, self.rt, ns)
+        s1, s2, feat_s = model.forward(sd, images_s, True, drop_masks_s, self.rt, ns, emulate_bf16=self.emulate_bf16)
         for k, v in ns.items():
             sd[k] = v
         ns = {}
-        t1, t2, feat_t = model.forward(sd, images_t, True, drop_masks_t, self.rt, ns)
+        t1, t2, feat_t = model.forward(sd, images_t, True, drop_masks_t, self.rt, ns, emulate_bf16=self.emulate_bf16)
         for k, v in ns.items():
             sd[k] = v
         t_fwd = time.time()

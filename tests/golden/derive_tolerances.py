@@ -1,0 +1,173 @@
+"""Where the step-level tolerances of the GPU tests come from: a rounding model, not GPU measurements.
+
+The HIP path stores activations / conv operands in bf16 and accumulates in fp32.  oracle/model.py
+can round at exactly those points -- and the activation gradients at the same points on the way back
+(`emulate_bf16='grad'`); everything else of the oracle step stays fp32.  For every
+step-level fixture of the GPU suite this script runs the CPU oracle step twice -- plain fp32 and bf16-emulating -- and
+records N = |bf16-emulating - fp32| for each compared quantity: the change that bf16 storage ALONE makes to the
+reference's numbers on that fixture, on the CPU.
+
+Rule (tests/test_ssl_step_gpu.py: `tol()`): a correct bf16 implementation is another realisation of the same rounding
+noise (it rounds at the same places, but to different neighbours: other summation orders inside the fp32 accumulators,
+bf16 statistics of rounded instead of unrounded values, a re-associated head convolution), so against the fp32 oracle
+it may deviate by about N, and by up to sqrt(2) N from the emulation.  Tolerance = 3 N, with a floor of 1e-3 relative
+for scalars -- three "rounding-noise units".  One derived bound: the LENGTH of the gradient, a vector whose direction
+carries rounding noise of angle theta (cos theta = N_cos, 0.90 on ResNet-101: the net is chaotic), is uncertain to
+(1 - cos theta) / 2 -- a rotation by theta changes a projection by 1 - cos theta -- so the gradient-norm tolerance is
+max(3 N_norm, (1 - N_cos) / 2): N_norm alone is one draw of a quantity that small.  No number measured on the GPU enters.
+
+Writes tests/golden/bf16_tolerances.json.  Run in the build container:  python tests/golden/derive_tolerances.py
+(CPU only; needs nothing from /root/reference: the fixtures are committed)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import labelpath as olp  # noqa: E402
+from oracle import model as omodel  # noqa: E402
+from oracle.step import CpuStep  # noqa: E402
+from regda_amd.synthetic import make_batch  # noqa: E402
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-30)
+
+
+def cosine(a, b):
+    a, b = a.flatten().double(), b.flatten().double()
+    return float(a @ b / (a.norm() * b.norm() + 1e-300))
+
+
+def noise(ref, emu, grad_names):
+    """N per quantity between two CpuStep.step results (ref: fp32, emu: bf16-emulating)."""
+    out = dict(loss_source=rel(emu['loss_source'], ref['loss_source']), loss_target=rel(emu['loss_target'], ref['loss_target']),
+               loss_target_abs=abs(emu['loss_target'] - ref['loss_target']),
+               grad_norm=rel(emu['grad_norm'], ref['grad_norm']),
+               hard_mismatch=float((emu['hard'] != ref['hard']).float().mean()),
+               soft_mean_abs=float((emu['soft'] - ref['soft']).abs().mean()))
+    keep = [k for k in ref['grads'] if 'ppm.0.' not in k]       # the degenerate scale-1 branch is rounding noise in the reference itself
+    out['grad_cos_global'] = cosine(torch.cat([emu['grads'][k].flatten() for k in keep]), torch.cat([ref['grads'][k].flatten() for k in keep]))
+    out['grad_cos'] = {k: cosine(emu['grads'][k], ref['grads'][k]) for k in grad_names}
+    out['grad_norm_ratio'] = {k: float(emu['grads'][k].norm() / (ref['grads'][k].norm() + 1e-30)) for k in grad_names}
+    return out
+
+
+def shallow_fixture(balancers):
+    """tests/test_ssl_step_gpu.py::test_fused_step_matches_oracle_step / ..._with_class_balancing...: resnet17t, seed 6,
+    batch seed 11, 4 + 4 images of 128 x 128, all-ones dropout masks, lr 1e-3."""
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=6)
+    b = make_batch(b=4, size=128, seed=11, device='cpu')
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(1))
+    ones = torch.ones(4, 512)
+    res, steps = [], (2 if balancers else 1)
+    for emu in (False, True):
+        kw = {}
+        if balancers:
+            cb_s, cb_t = olp.ClassBalanceState(6, -1, 0.5, 0.5), olp.ClassBalanceState(6, -1, 0.5, 0.5)
+            cb_s.freq = torch.tensor([0.5, 0.2, 0.1, 0.1, 0.05, 0.05])
+            cb_t.freq = torch.tensor([0.05, 0.05, 0.1, 0.1, 0.2, 0.5])
+            kw = dict(balancer_s=cb_s, balancer_t=cb_t)
+        cpu = CpuStep(sd, protos, resnet_type=rt, lr=1e-3, emulate_bf16=('grad' if emu else False), **kw)
+        outs = [cpu.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], (ones, ones), (ones, ones))
+                for _ in range(steps)]
+        res.append((outs, cpu))
+    (ref, cref), (emu, cemu) = res
+    names = ['encoder.resnet.conv1.weight']
+    n = [noise(r, e, names) for r, e in zip(ref, emu)]
+    worst = {k: (min if 'cos' in k else max)(x[k] for x in n) for k in n[0] if not isinstance(n[0][k], dict)}
+    worst['grad_cos'] = {k: min(x['grad_cos'][k] for x in n) for k in names}
+    worst['grad_norm_ratio_dev'] = {k: max(abs(x['grad_norm_ratio'][k] - 1) for x in n) for k in names}
+    worst['protos_rel'] = float((cemu.prototypes - cref.prototypes).norm() / cref.prototypes.norm())
+    k = 'encoder.resnet.bn1.running_mean'
+    worst['bn1_running_mean_abs'] = float((cemu.sd[k] - cref.sd[k]).abs().max())
+    d_ref, d_emu = cref.sd[names[0]].detach() - sd[names[0]], cemu.sd[names[0]].detach() - sd[names[0]]
+    worst['stem_update_cos'] = cosine(d_emu, d_ref)
+    worst['stem_update_norm_dev'] = abs(float(d_emu.norm() / d_ref.norm()) - 1)
+    if balancers:
+        worst['freq_t_abs'] = float((cemu.balancer_t.freq - cref.balancer_t.freq).abs().max())
+    return worst
+
+
+def resnet101_fixture():
+    """tests/test_ssl_step_gpu.py::test_resnet101_step_vs_reference_minted_step: the inputs of model_small.npz."""
+    g = np.load(os.path.join(HERE, 'model_small.npz'))
+    sd = omodel.init_state_dict('resnet101', 6, seed=1)
+    xs, xt = torch.from_numpy(g['xs']), torch.from_numpy(g['xt'])
+    lab = torch.from_numpy(g['lab_s'].astype(np.int64))
+    soft_t = torch.from_numpy(g['soft_t'])
+    regs = torch.from_numpy(g['regs'].astype(np.int64))
+    ms = (torch.from_numpy(g['m5'][0]), torch.from_numpy(g['m6'][0]))
+    mt = (torch.from_numpy(g['m5'][1]), torch.from_numpy(g['m6'][1]))
+    names = ['encoder.resnet.conv1.weight', 'encoder.resnet.bn1.weight', 'encoder.resnet.bn1.bias', 'layer5.conv_last.4.weight',
+             'layer5.conv_last.4.bias', 'layer6.conv_last.1.weight', 'encoder.resnet.layer4.2.bn3.bias', 'layer6.ppm.3.2.bias',
+             'encoder.resnet.layer3.10.conv2.weight', 'layer5.conv_last.0.weight']
+    res = []
+    for emu in (False, True):
+        cpu = CpuStep(sd, torch.from_numpy(g['protos']), resnet_type='resnet101', lr=1e-2, emulate_bf16=('grad' if emu else False))
+        res.append((cpu.step(xs, lab, xt, soft_t, regs, ms, mt), cpu))
+    (ref, cref), (emu, cemu) = res
+    # the fp32 oracle step reproduces the reference-minted numbers (the oracle is pinned)
+    assert rel(ref['loss_source'], float(g['loss_s'])) < 1e-4 and rel(ref['grad_norm'], float(g['grad_norm'])) < 1e-3
+    n = noise(ref, emu, names)
+    out = {k: v for k, v in n.items() if not isinstance(v, dict)}
+    out['grad_cos_min'] = min(n['grad_cos'].values())
+    out['grad_cos'] = n['grad_cos']
+    out['grad_norm_ratio_dev_max'] = max(abs(v - 1) for v in n['grad_norm_ratio'].values())
+    out['protos_rel'] = float((cemu.prototypes - cref.prototypes).norm() / cref.prototypes.norm())
+    return out
+
+
+def model_fixture(rt, sd, xs, lab, masks):
+    """tests/test_model_gpu.py::_run_case: one train-mode forward + loss + backward of the network alone."""
+    names = omodel.param_names(sd)
+    keep = [k for k in names if 'ppm.0.' not in k]          # degenerate branch, see oracle.model.init_state_dict
+    res = []
+    for emu in (False, 'grad'):
+        sdr = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+        r1, r2, rf = omodel.forward(sdr, xs, True, masks, rt, {}, None, emulate_bf16=emu)
+        loss = olp.loss_calc([r1, r2], lab, -1)
+        g = torch.autograd.grad(loss, [sdr[k] for k in names])
+        flat = torch.cat([t.reshape(-1) for k, t in zip(names, g) if k in keep])
+        res.append((r1.detach(), r2.detach(), rf.detach(), float(loss), flat))
+    (a1, a2, af, al, ag), (b1, b2, bf, bl, bg) = res
+    l2 = lambda x, y: float((x - y).norm() / (y.norm() + 1e-12))
+    return dict(x1=l2(b1, a1), x2=l2(b2, a2), feat=l2(bf, af), loss=rel(bl, al), grad_cos=cosine(bg, ag),
+                grad_norm=abs(float(bg.norm() / ag.norm()) - 1))
+
+
+def shallow_model_fixture():
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=1)
+    gen = torch.Generator().manual_seed(3)
+    xs = torch.randn(4, 3, 128, 128, generator=gen)
+    masks = ((torch.rand(4, 512, generator=gen) > 0.1).to(torch.uint8), (torch.rand(4, 512, generator=gen) > 0.1).to(torch.uint8))
+    lab = torch.from_numpy(np.kron(np.random.default_rng(0).integers(-1, 6, size=(4, 8, 8)), np.ones((16, 16), np.int64)))
+    return model_fixture(rt, sd, xs, lab, masks)
+
+
+def resnet101_model_fixture():
+    g = np.load(os.path.join(HERE, 'model_small.npz'))
+    sd = omodel.init_state_dict('resnet101', 6, seed=1)
+    masks = (torch.from_numpy(g['m5'][0]), torch.from_numpy(g['m6'][0]))
+    return model_fixture('resnet101', sd, torch.from_numpy(g['xs']), torch.from_numpy(g['lab_s'].astype(np.int64)), masks)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out = {'rule': 'tolerance = max(3 * N, floor); N = |bf16-emulating oracle - fp32 oracle| on the fixture (CPU); '
+                   'cosines: 1 - tol_cos = 3 * (1 - N_cos)',
+           'factor': 3.0,
+           'shallow_step': shallow_fixture(False),
+           'shallow_step_class_balancing': shallow_fixture(True),
+           'resnet101_step': resnet101_fixture(),
+           'shallow_model': shallow_model_fixture(),
+           'resnet101_model': resnet101_model_fixture()}
+    with open(os.path.join(HERE, 'bf16_tolerances.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))

@@ -3,10 +3,11 @@
 Tolerance statement (DESIGN.md "Parity"): activations are stored in bf16, accumulation is fp32.  A
 randomly initialised 101-layer BN network is chaotic -- rounding only the conv weights to bf16 moves the
 fp32 oracle's logits by ~2 % and its gradients by ~25 % (measured) -- so
-  * forward (logits, feat) is compared in relative L2 norm: < 3 % against the bf16-EMULATING oracle on
-    the shallow topology, < 8 % on ResNet-101, and < 10 % against the plain fp32 oracle / reference golden;
-  * the loss within 1.5 %; the global gradient norm within 4 %; the global gradient direction by
-    cosine similarity (> 0.98 shallow / > 0.9 ResNet-101);
+  * forward (logits, feat), loss, global gradient norm and direction are bounded in units of the fixture's bf16
+    ROUNDING NOISE N = |bf16-emulating oracle - fp32 oracle|, computed on the CPU (tests/golden/derive_tolerances.py ->
+    bf16_tolerances.json; shallow topology: 2.3-2.9 % of the logits, ResNet-101: 5.2-7.0 %): 3 N against the plain
+    fp32 oracle / the reference golden (another realisation of the same noise), 1.5 N against the bf16-EMULATING
+    oracle (same rounding points: correlated realisations);
   * per-layer backward wiring is checked tightly by re-running every layer's backward in torch from
     the tensors the HIP path itself saved (test_layerwise_backward_consistency).
 Integer outputs of the label path given identical inputs stay bit-exact (tests/test_label_gpu.py)."""
@@ -23,6 +24,18 @@ from oracle import model as omodel
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+# rounding-noise units of each fixture (tests/golden/derive_tolerances.py, CPU): N = |bf16-emulating oracle - fp32 oracle|
+_TOL = json.load(open(os.path.join(GOLD, 'bf16_tolerances.json')))
+
+
+def tolN(fixture, key, units, floor=1e-3):
+    return max(units * _TOL[fixture][key], floor)
+
+
+def tol_gn(fixture, units):
+    """Gradient norm: `units` N, or the length uncertainty (1 - cos theta) / 2 of a vector whose direction carries
+    rounding noise of angle theta (tests/golden/derive_tolerances.py)."""
+    return max(units * _TOL[fixture]['grad_norm'], 0.5 * (1.0 - _TOL[fixture]['grad_cos']))
 
 
 def build(rt):
@@ -92,13 +105,13 @@ def test_shallow_topology_forward_backward():
     xs = torch.randn(4, 3, 128, 128, generator=gen)
     masks = ((torch.rand(4, 512, generator=gen) > 0.1).to(torch.uint8), (torch.rand(4, 512, generator=gen) > 0.1).to(torch.uint8))
     lab = torch.from_numpy(np.kron(np.random.default_rng(0).integers(-1, 6, size=(4, 8, 8)), np.ones((16, 16), np.int64)))
-    r = _run_case(m, sd, rt, xs, lab, masks, emulate=True)
-    assert r['x1'] < 0.03 and r['x2'] < 0.03 and r['feat'] < 0.03, r
-    assert r['loss'][0] == pytest.approx(r['loss'][1], rel=0.015), r
-    assert r['cos'] > 0.98 and r['gn'][0] == pytest.approx(r['gn'][1], rel=0.04), r
-    r = _run_case(m, sd, rt, xs, lab, masks, emulate=False)
-    assert r['x1'] < 0.06 and r['x2'] < 0.06 and r['feat'] < 0.05, r
-    assert r['loss'][0] == pytest.approx(r['loss'][1], rel=0.015) and r['cos'] > 0.97, r
+    F_ = 'shallow_model'
+    for emulate, u in ((True, 1.5), (False, 3.0)):
+        r = _run_case(m, sd, rt, xs, lab, masks, emulate=emulate)
+        print('\n[shallow model vs %s oracle]' % ('emulating' if emulate else 'fp32'), r)
+        assert r['x1'] < tolN(F_, 'x1', u) and r['x2'] < tolN(F_, 'x2', u) and r['feat'] < tolN(F_, 'feat', u), r
+        assert r['loss'][0] == pytest.approx(r['loss'][1], rel=tolN(F_, 'loss', u, floor=2e-3)), r
+        assert r['cos'] > 1 - u * (1 - _TOL[F_]['grad_cos']) and r['gn'][0] == pytest.approx(r['gn'][1], rel=tol_gn(F_, u)), r
 
 
 def test_resnet101_forward_backward_vs_oracle(r101, gold):
@@ -108,9 +121,11 @@ def test_resnet101_forward_backward_vs_oracle(r101, gold):
     masks = (torch.from_numpy(g['m5'][0]), torch.from_numpy(g['m6'][0]))
     lab = torch.from_numpy(g['lab_s'].astype(np.int64))
     r = _run_case(m, sd, 'resnet101', xs, lab, masks, emulate=True)
-    assert r['x1'] < 0.08 and r['x2'] < 0.08 and r['feat'] < 0.08, r
-    assert r['loss'][0] == pytest.approx(r['loss'][1], rel=0.015), r
-    assert r['cos'] > 0.9 and r['gn'][0] == pytest.approx(r['gn'][1], rel=0.04), r
+    print('\n[resnet101 model vs emulating oracle]', r)
+    F_, u = 'resnet101_model', 1.5
+    assert r['x1'] < tolN(F_, 'x1', u) and r['x2'] < tolN(F_, 'x2', u) and r['feat'] < tolN(F_, 'feat', u), r
+    assert r['loss'][0] == pytest.approx(r['loss'][1], rel=tolN(F_, 'loss', u)), r
+    assert r['cos'] > 1 - u * (1 - _TOL[F_]['grad_cos']) and r['gn'][0] == pytest.approx(r['gn'][1], rel=tol_gn(F_, u)), r
 
 
 def test_resnet101_vs_reference_golden(r101, gold):

@@ -319,3 +319,27 @@ def test_sam_region_map_assembly(gold):
         assert out.dtype == np.int32 and np.array_equal(out, g[f'regions{i}']), i
     k = g['masks0'].shape[0]
     assert (g['regions0'] != 1).all() and (g['regions0'] == k // 2 + 1).any()      # below / exactly at the threshold
+
+
+def test_bf16_tolerance_table_is_what_the_rounding_model_gives():
+    """tests/golden/bf16_tolerances.json (the rounding-noise units N the GPU suite states its step- and model-level
+    tolerances in) is the output of tests/golden/derive_tolerances.py: recompute the shallow-topology fixtures here on
+    the CPU.  N is itself the outcome of a chaotic amplification (another thread count re-associates the fp32 sums), so
+    the check is agreement within a factor 1.5, key by key."""
+    import importlib.util
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    spec = importlib.util.spec_from_file_location('derive_tolerances', os.path.join(here, 'derive_tolerances.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    table = json.load(open(os.path.join(here, 'bf16_tolerances.json')))
+    assert table['factor'] == 3.0
+    for name, fn in (('shallow_model', mod.shallow_model_fixture), ('shallow_step', lambda: mod.shallow_fixture(False))):
+        got = fn()
+        for k, v in table[name].items():
+            if isinstance(v, dict):
+                continue
+            w = got[k]
+            if 'cos' in k:
+                v, w = 1.0 - v, 1.0 - w
+            assert w <= 1.5 * v + 1e-6 and v <= 1.5 * w + 1e-6, (name, k, v, w)

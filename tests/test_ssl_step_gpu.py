@@ -10,6 +10,28 @@ from oracle.step import CpuStep
 
 pytestmark = pytest.mark.gpu
 
+# Step-level tolerances are stated in units of the bf16 ROUNDING NOISE of each fixture, N = |bf16-emulating oracle - fp32
+# oracle| computed on the CPU by tests/golden/derive_tolerances.py (committed: tests/golden/bf16_tolerances.json):
+# tolerance = max(3 N, floor).  No number measured on the GPU enters.
+import json
+import os
+_TOL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bf16_tolerances.json')))
+
+
+def tol(fixture, key, floor=1e-3):
+    v = _TOL[fixture][key]
+    return max(_TOL['factor'] * v, floor)
+
+
+def tol_cos(fixture, key):
+    return 1.0 - _TOL['factor'] * (1.0 - _TOL[fixture][key])
+
+
+def tol_gn(fixture):
+    """Gradient-norm tolerance: 3 N, or the length uncertainty (1 - cos theta) / 2 of a vector whose direction carries
+    rounding noise of angle theta (derive_tolerances.py)."""
+    return max(tol(fixture, 'grad_norm'), 0.5 * (1.0 - _TOL[fixture]['grad_cos_global']))
+
 
 def build(rt):
     from regda_amd.models.Encoder import Deeplabv2
@@ -34,30 +56,37 @@ def test_fused_step_matches_oracle_step():
     st = SSLStep(m, protos)
     g = {k: v.cuda() for k, v in b.items()}
     ls, lt, gn = st.step(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'], 1e-3)
-    # losses / gradient norm (stated tolerance: bf16 network)
-    assert ls.item() == pytest.approx(ref['loss_source'], rel=0.02)
-    assert lt.item() == pytest.approx(ref['loss_target'], rel=0.05, abs=0.02)
-    assert gn.sqrt().item() == pytest.approx(ref['grad_norm'], rel=0.06)
+    # losses / gradient norm: three rounding-noise units of this fixture (tol(), top of the file)
+    F = 'shallow_step'
+    hard = st.last_hard.cpu().numpy()
+    print('\n[shallow step vs oracle] loss_s %.4g loss_t %.4g grad_norm %.4g hard mismatch %.4g  (tolerances %.3g %.3g %.3g %.3g)' % (
+        abs(ls.item() / ref['loss_source'] - 1), abs(lt.item() / ref['loss_target'] - 1), abs(gn.sqrt().item() / ref['grad_norm'] - 1),
+        (hard != ref['hard'].numpy()).mean(), tol(F, 'loss_source'), tol(F, 'loss_target'), tol_gn(F), tol(F, 'hard_mismatch')))
+    assert ls.item() == pytest.approx(ref['loss_source'], rel=tol(F, 'loss_source'))
+    assert lt.item() == pytest.approx(ref['loss_target'], rel=tol(F, 'loss_target'), abs=tol(F, 'loss_target_abs'))
+    assert gn.sqrt().item() == pytest.approx(ref['grad_norm'], rel=tol_gn(F))
     # pseudo labels: the integer path is exact GIVEN the same soft input; end to end the bf16 logits move a few
     # borderline pixels across the threshold
-    hard = st.last_hard.cpu().numpy()
-    assert (hard != ref['hard'].numpy()).mean() < 0.03
+    assert (hard != ref['hard'].numpy()).mean() < tol(F, 'hard_mismatch')
     regs = b['regs_t'].squeeze(1).numpy()
     assert np.array_equal(hard[regs == 0], olab.homogenize(hard, regs, 0.5, 6, -1)[regs == 0])
     assert st.lrh_flag() == 0
     # prototypes and the SGD update
-    assert ((st.prototypes.cpu() - cpu.prototypes).norm() / cpu.prototypes.norm()).item() < 2e-3
+    assert ((st.prototypes.cpu() - cpu.prototypes).norm() / cpu.prototypes.norm()).item() < tol(F, 'protos_rel', floor=1e-4)
     named = dict(m.named_parameters())
     k = 'encoder.resnet.conv1.weight'
     d_ref = cpu.sd[k].detach() - sd[k]
     d_got = named[k].detach().cpu() - sd[k]
     cos = (d_ref.flatten() @ d_got.flatten() / (d_ref.norm() * d_got.norm())).item()
     # the stem is the far end of the backward chain: the most amplified bf16 noise
-    assert cos > 0.93 and d_got.norm().item() == pytest.approx(d_ref.norm().item(), rel=0.1)
+    print('[shallow step vs oracle] stem update cos %.4f (bound %.4f) norm dev %.4g (bound %.3g)' % (
+        cos, tol_cos(F, 'stem_update_cos'), abs(d_got.norm().item() / d_ref.norm().item() - 1), tol(F, 'stem_update_norm_dev', floor=5e-3)))
+    assert cos > tol_cos(F, 'stem_update_cos')
+    assert d_got.norm().item() == pytest.approx(d_ref.norm().item(), rel=tol(F, 'stem_update_norm_dev', floor=5e-3))
     # BN buffers were updated twice (src, tgt) in one fused pass
     assert int(m.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == 2
     assert ((m.state_dict()['encoder.resnet.bn1.running_mean'].cpu() - cpu.sd['encoder.resnet.bn1.running_mean']).abs().max()
-            < 5e-3)
+            < tol(F, 'bn1_running_mean_abs', floor=2e-4))
 
 
 def test_online_ema_teacher_and_reference_style_loop():
@@ -122,12 +151,11 @@ def test_step_runs_at_other_batch_and_tile_sizes(rt, b, size):
 
 def test_resnet101_step_vs_reference_minted_step(gold, capsys):
     """The HIP SSLStep on ResNet-101 against the REFERENCE's own composed step (tests/golden/model_small.npz: minted by
-    make_goldens.gold_model from tools/train_ssl_reg.py:198-241 on the imported reference model, fp32).  Stated
-    tolerances (bf16 storage / fp32 accumulation through 101 layers; measured on MI355X: losses
-    0.9 % / 0.1 %, gradient norm 0.2 %, soft labels 8e-4 mean-abs, 0.27 % of the pseudo labels differ end to end,
-    prototypes 1e-4, gradient cosines 0.88 .. 0.9999): losses 2.5 %, gradient norm 2.5 %, refined soft labels 4e-3
-    mean-abs, end-to-end pseudo-label mismatch rate < 1.5 % (reported), prototypes 1e-3, selected gradients by
-    cosine > 0.8 and norm ratio within 15 %."""
+    make_goldens.gold_model from tools/train_ssl_reg.py:198-241 on the imported reference model, fp32).  Tolerances:
+    three rounding-noise units of this fixture (tests/golden/bf16_tolerances.json, "resnet101_step": what bf16 storage
+    alone does to the fp32 oracle on the CPU -- losses 1.2 % / 0.2 %, gradient norm 0.7 %, 0.35 % of the pseudo labels,
+    soft labels 9e-4 mean-abs, gradient cosines down to 0.88 at the stem).  The integer chain is exact on the HIP path's
+    own soft labels."""
     from regda_amd.ssl import SSLStep
     g = gold('model_small.npz')
     sd = omodel.init_state_dict('resnet101', 6, seed=1)
@@ -176,16 +204,17 @@ def test_resnet101_step_vs_reference_minted_step(gold, capsys):
     # the integer chain is exact given the HIP path's own soft labels
     mine = olab.homogenize(olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1), g['regs'].astype(np.int64).squeeze(1), 0.5, 6, -1)
     assert np.array_equal(mine, hard)
-    assert rep['loss_s'][0] == pytest.approx(rep['loss_s'][1], rel=0.025)
-    assert rep['loss_t'][0] == pytest.approx(rep['loss_t'][1], rel=0.025, abs=0.01)
-    assert rep['grad_norm'][0] == pytest.approx(rep['grad_norm'][1], rel=0.025)
-    assert rep['soft2_mean_abs'] < 4e-3
-    assert rep['hard2_mismatch'] < 0.015 and rep['hard_selected_mismatch'] < 0.015
-    assert rep['protos_rel'] < 1e-3
+    F = 'resnet101_step'
+    assert rep['loss_s'][0] == pytest.approx(rep['loss_s'][1], rel=tol(F, 'loss_source'))
+    assert rep['loss_t'][0] == pytest.approx(rep['loss_t'][1], rel=tol(F, 'loss_target'), abs=tol(F, 'loss_target_abs'))
+    assert rep['grad_norm'][0] == pytest.approx(rep['grad_norm'][1], rel=tol_gn(F))
+    assert rep['soft2_mean_abs'] < tol(F, 'soft_mean_abs')
+    assert rep['hard2_mismatch'] < tol(F, 'hard_mismatch') and rep['hard_selected_mismatch'] < tol(F, 'hard_mismatch')
+    assert rep['protos_rel'] < tol(F, 'protos_rel', floor=1e-4)
     for name, (c, r) in cos.items():
         if 'ppm.0.' in name:            # the degenerate scale-1 branch: rounding noise in the reference itself
             continue
-        assert c > 0.8 and 0.85 < r < 1.15, (name, c, r)
+        assert c > tol_cos(F, 'grad_cos_min') and abs(r - 1) < tol(F, 'grad_norm_ratio_dev_max'), (name, c, r)
     assert st.lrh_flag() == 0
     assert int(m.state_dict()['encoder.resnet.bn1.num_batches_tracked']) == 2
 
@@ -427,13 +456,14 @@ def test_fused_step_with_class_balancing_matches_oracle_step():
         else:
             outs.append(vals(st.step(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'], 1e-3)))
         for (ls, lt, gn), ref in zip(outs, refs):
-            assert ls == pytest.approx(ref['loss_source'], rel=0.03), use_plan
-            assert lt == pytest.approx(ref['loss_target'], rel=0.08, abs=0.02), use_plan
-            assert gn ** 0.5 == pytest.approx(ref['grad_norm'], rel=0.08), use_plan
+            FB = 'shallow_step_class_balancing'
+            assert ls == pytest.approx(ref['loss_source'], rel=tol(FB, 'loss_source')), use_plan
+            assert lt == pytest.approx(ref['loss_target'], rel=tol(FB, 'loss_target'), abs=tol(FB, 'loss_target_abs')), use_plan
+            assert gn ** 0.5 == pytest.approx(ref['grad_norm'], rel=tol_gn(FB)), use_plan
         # four EMA updates each (two heads x two steps); the source labels are identical, the target pseudo labels
         # differ in a few borderline pixels
         torch.testing.assert_close(bs.freq.cpu(), cb_s.freq, rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(bt.freq.cpu(), cb_t.freq, rtol=2e-2, atol=2e-4)
+        torch.testing.assert_close(bt.freq.cpu(), cb_t.freq, rtol=0, atol=tol('shallow_step_class_balancing', 'freq_t_abs', floor=2e-4))
         if use_plan:            # a replay updates the balancers again
             fq = bs.freq.clone()
             st.step(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'], 1e-3)

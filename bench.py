@@ -487,6 +487,7 @@ def main():
             roof = {'bound': 'hbm', 'achieved': d['gbps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                     'frac': d['gbps'] / HBM_PEAK_GBPS}
         res['roofline'] = {**roof, 'kernel': dom, 'traffic': traffic,
+                           'traffic_source': 'profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE per launch from the separate rocprofv3 --pmc passes of `scripts/tune.sh profiles` (a counter pass cannot run inside this process); null if the file is absent',
                            'flop_per_byte': intensity, 'mfma_frac': d['tflops'] / MFMA_PEAK_TFLOPS,
                            'hbm_frac': d['gbps'] / HBM_PEAK_GBPS,
                            'launches_per_step': d['launches'], 'avg_launch_us': d['avg_us'],

@@ -229,7 +229,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
                 red[(wave * 2 + 1) * BC + cv * 8 + e] = q[e];
             }
         }
-        __syncthreads();
+        // LDS only: `__syncthreads()` would also wait for this thread's ROW STORES above to be acknowledged by memory
+        // (vmcnt counts stores on gfx9), ~1000 cycles the statistics do not depend on
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (TDBG(a) && t == 0) TDBG(a)[(16384 + blockIdx.x) * 4 + 2] = __builtin_readcyclecounter();
         if (t < 2 * BC) {
             int which = t / BC, c = t % BC;
@@ -403,6 +406,9 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
             const int nxt = (stage == 2) ? 0 : stage + 1;
             read_half(stage, 1);
             mfma_half(0);
+#ifdef RGDA_TUNING      // timing experiment (racy: wrong results): 64 = do not wait for the fragment reads before the barrier
+            if (!(TSKIP(a) & 64))
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this tile's k-step 2-3 fragments are in registers
             if (kt + 2 < KT) WAIT_VMCNT(LD); else WAIT_VMCNT(0);        // tile kt+1 landed (kt+2 may still fly)
             __builtin_amdgcn_s_barrier();

@@ -8,7 +8,8 @@
 #     bash scripts/tune.sh tests [pytest args] the whole -m gpu suite, log in gpurun_out/pytest_gpu.log
 #     [ARMS=..] [TUNING=1] [BARGS=..] [REPS=3] bash scripts/tune.sh ab
 #                                              interleaved A/B/.. of the whole step on ONE box (box-to-box spread is
-#                                              +-2 %): an arm is "dir[:ENV=v[,ENV2=v]]"; default arms ".ab_base ."
+#                                              +-2 %): an arm is "dir[:ENV=v[,ENV2=v]]" (LIB=path = another build of
+#                                              the library for that arm); default arms ".ab_base ."
 #     bash scripts/tune.sh kstep [bench args]  kernel time of ONE serial step by kernel name (+ per-launch list)
 #     bash scripts/tune.sh klist [bench args]  every launch of one overlapped step in start order (gaps, streams)
 #     bash scripts/tune.sh profiles rNN        regenerate everything profiles/ holds for a round into gpurun_out/
@@ -42,6 +43,10 @@ ab)
   [ -n "${TUNING:-}" ] && cp regda_amd/csrc/tuning/librgda_hip.so regda_amd/csrc/librgda_hip.so
   for rep in $(seq 1 ${REPS:-3}); do for arm in ${ARMS:-.ab_base .}; do
     dir=${arm%%:*}; envs=""; [ "$arm" != "$dir" ] && envs=$(echo ${arm#*:} | tr ',' ' ')
+    # LIB=<path to another build of librgda_hip.so> in an arm's environment: that library is put in place for the run
+    [ -f $dir/regda_amd/csrc/librgda_hip.so.arm0 ] || cp $dir/regda_amd/csrc/librgda_hip.so $dir/regda_amd/csrc/librgda_hip.so.arm0
+    lib=$dir/regda_amd/csrc/librgda_hip.so.arm0; for e in $envs; do case $e in LIB=*) lib=${e#LIB=} ;; esac; done
+    cp $lib $dir/regda_amd/csrc/librgda_hip.so
     ( cd $dir; env $envs python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-h2d ${BARGS:-} 2>/dev/null | last_json "$arm" )
   done; done ;;
 kstep)

@@ -24,7 +24,7 @@ GFLOP_PER_PAIR_STUDENT = 1087.0     # (fwd + dgrad + wgra
 GFLOP_PER_PAIR_TEACHER = 181.17     # + one eval forward of the EMA teacher on the target image
 MFMA_PEAK_TFLOPS = 2500.0       # bf16 dense, MI355X_MICROARCH.md
 # what the matrix pipes sustain on N(0,1) bf16 operands with no data movement at all (2440 on all-zero operands):
-# measured, scripts/dev/dev_mfma_ceiling.py -> profiles/r02_mfma_ceiling.txt.  Reported next to the nominal peak only.
+# measured, scripts/dev/mfma_ceiling.py -> profiles/r02_mfma_ceiling.txt.  Reported next to the nominal peak only.
 MFMA_SUSTAINED_TFLOPS = 1810.0
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 achievable)
 

@@ -1130,8 +1130,13 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
 //   the nine taps read the halo tile at nine shifted row offsets: 25 KB per 4.7 MFLOP = 188 FLOP per byte pulled
 //   from L2 (the generic kernel: 64), and the dY tile is read once instead of nine times.
 // ======================================================================================
-template <int WT, int D>
-__global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradGroup g) {
+// Occupancy: nine 32 x 32 accumulators are 144 VGPRs; left alone the compiler takes 400 registers (double-buffered
+// fragments), i.e. ONE wave per SIMD, and the matrix pipe idles whenever that wave waits for LDS (27-34 % MFMA busy).
+// Capped at 256 registers (two waves per SIMD, no spills to speak of) and with a 2-stage ring wherever two rings fit
+// the 160 KB of a CU, two workgroups share a CU and one's LDS / barrier waits hide under the other's MFMAs:
+// layer-3 group launches 366 -> 291 us, -0.22 ms per step in an interleaved A/B (round 3).
+template <int WT, int D, int STAGES = 3>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wgrad3x3_kernel(WgradGroup g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int R = 64 / WT;                       // image rows per K tile
     constexpr int HR = R + 2 * D, HC = WT + 2 * D;   // halo tile (pixels)
@@ -1139,7 +1144,7 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradGroup g) {
     constexpr int TA = 64 * 128, TB = NHP * 128, TILE = TA + TB;
     constexpr int LA = 2, LB = NHP / 32;             // LDS-DMA instructions per wave per tile (8 rows each)
     constexpr int LD = LA + LB;
-    constexpr int STAGES = 3;
+    static_assert(STAGES == 2 || STAGES == 3, "ring of 2 (two workgroups per CU) or 3 stages");
     __shared__ __attribute__((aligned(256))) unsigned char smem[STAGES * TILE];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -1207,7 +1212,7 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradGroup g) {
 
     if (kt_beg < kt_end) {
         issue(kt_beg, 0);
-        if (kt_beg + 1 < kt_end) issue(kt_beg + 1, 1);
+        if (STAGES == 3 && kt_beg + 1 < kt_end) issue(kt_beg + 1, 1);
         const int g = lane >> 4, la = lane & 15;
         const int klane = (g >> 1) * 8 + (la >> 2);                    // pixel of this lane inside a 16-pixel k step
         const int cbyte = ((g & 1) * 16 + (la & 3) * 4) * 2;           // column byte inside the wave's 32 columns
@@ -1225,9 +1230,9 @@ __global__ void __launch_bounds__(256) conv_wgrad3x3_kernel(WgradGroup g) {
         // with 9 MFMAs per 20 transposing reads the compiler's own interleaving already hides the LDS latency)
         int stage = 0;
         for (int kt = kt_beg; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end) WAIT_VMCNT(LD); else WAIT_VMCNT(0);
+            if (STAGES == 3 && kt + 1 < kt_end) WAIT_VMCNT(LD); else WAIT_VMCNT(0);
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < kt_end) issue(kt + 2, stage >= 1 ? stage - 1 : STAGES - 1);
+            if (kt + STAGES - 1 < kt_end) issue(kt + STAGES - 1, stage >= 1 ? stage - 1 : STAGES - 1);
             const unsigned char* ab = smem + stage * TILE;
             const unsigned char* bb = ab + TA;
 #pragma unroll
@@ -1344,12 +1349,14 @@ static inline size_t wgrad_slice_floats(int kind) {
 // K splits of the layers of one launch (g.a[0..n)); 1 without a workspace.  One split count S for the launch (a layer
 // with few K tiles gets fewer: never fewer than 16 K tiles per split), chosen by a round model of the launch: its
 // workgroups run in ceil(workgroups / capacity) rounds (capacity = 256, one workgroup per CU, for the 144 KB tiles;
-// 512 for the small ones) of ceil(K tiles / S) tile steps each, plus 8 + 2 S tile steps when S > 1: the partial tiles'
+// 512 for the others) of ceil(K tiles / S) tile steps each, plus 8 + 2 S tile steps when S > 1: the partial tiles'
 // trip through the workspace and the last workgroup's walk over the S partials.  (Splitting "until the chip is full" -- the rule before ABI 4 -- made
 // 336 workgroups out of 112 tiles: two rounds of 86 steps where S = 2 gives one round of 128.)
 // Returns the bytes of partial tiles the launch needs behind the counters.
 static size_t wgrad_plan_splits(int kind, WgradGroup& g, bool have_ws) {
-    const int capacity = (kind >= WK_F64_1 || kind == WK_G256_128) ? 256 : 512;
+    // workgroups the chip holds at once: one per CU for the 144 KB generic tile and the dilated 64-wide tap-fused kernel,
+    // two per CU for everything else (the tap-fused kernels run 2-stage rings of 48-72 KB)
+    const int capacity = (kind == WK_G256_128 || kind == WK_F64_2) ? 256 : 512;
     int minkt = 16;
     if (const char* e = TUNE_ENV("RGDA_WGRAD_MINKT")) minkt = atoi(e);                     // tuning experiments only
     int best = 1;
@@ -1425,12 +1432,12 @@ static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipS
         case WK_G64_128: conv_wgrad_kernel<64, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
         case WK_G64_64: conv_wgrad_kernel<64, 64><<<items, 256, 0, st>>>(g); break;
         case WK_G256_128: conv_wgrad_kernel<256, 128, 4, 2><<<items, 512, 0, st>>>(g); break;
-        case WK_F64_1: conv_wgrad3x3_kernel<64, 1><<<items, 256, 0, st>>>(g); break;
-        case WK_F64_2: conv_wgrad3x3_kernel<64, 2><<<items, 256, 0, st>>>(g); break;
-        case WK_F32_1: conv_wgrad3x3_kernel<32, 1><<<items, 256, 0, st>>>(g); break;
-        case WK_F32_2: conv_wgrad3x3_kernel<32, 2><<<items, 256, 0, st>>>(g); break;
-        case WK_F16_1: conv_wgrad3x3_kernel<16, 1><<<items, 256, 0, st>>>(g); break;
-        default: conv_wgrad3x3_kernel<16, 2><<<items, 256, 0, st>>>(g); break;
+        case WK_F64_1: conv_wgrad3x3_kernel<64, 1, 2><<<items, 256, 0, st>>>(g); break;       // 72 KB: two workgroups per CU
+        case WK_F64_2: conv_wgrad3x3_kernel<64, 2, 3><<<items, 256, 0, st>>>(g); break;       // 52 KB per stage: one per CU either way
+        case WK_F32_1: conv_wgrad3x3_kernel<32, 1, 2><<<items, 256, 0, st>>>(g); break;       // 56 KB
+        case WK_F32_2: conv_wgrad3x3_kernel<32, 2, 2><<<items, 256, 0, st>>>(g); break;       // 72 KB
+        case WK_F16_1: conv_wgrad3x3_kernel<16, 1, 3><<<items, 256, 0, st>>>(g); break;       // 72 KB
+        default: conv_wgrad3x3_kernel<16, 2, 2><<<items, 256, 0, st>>>(g); break;              // 56 KB
     }
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;

@@ -1135,8 +1135,8 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
 // Capped at 256 registers (two waves per SIMD, no spills to speak of) and with a 2-stage ring wherever two rings fit
 // the 160 KB of a CU, two workgroups share a CU and one's LDS / barrier waits hide under the other's MFMAs:
 // layer-3 group launches 366 -> 291 us, -0.22 ms per step in an interleaved A/B (round 3).
-template <int WT, int D, int STAGES = 3>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wgrad3x3_kernel(WgradGroup g) {
+template <int WT, int D, int STAGES>
+static __device__ __forceinline__ void conv_wgrad3x3_body(const WgradGroup& g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int R = 64 / WT;                       // image rows per K tile
     constexpr int HR = R + 2 * D, HC = WT + 2 * D;   // halo tile (pixels)
@@ -1270,6 +1270,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
     }
 #endif
+}
+template <int WT, int D, int STAGES = 3>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wgrad3x3_kernel(WgradGroup g) {
+    conv_wgrad3x3_body<WT, D, STAGES>(g);
+}
+// the dilated 64-wide variant: 52 KB per ring stage, one workgroup per CU whatever the register count
+template <int WT, int D, int STAGES = 3>
+__global__ void __launch_bounds__(256) conv_wgrad3x3_wide_kernel(WgradGroup g) {
+    conv_wgrad3x3_body<WT, D, STAGES>(g);
 }
 
 static int ilog2_exact(int v) {
@@ -1433,7 +1442,7 @@ static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipS
         case WK_G64_64: conv_wgrad_kernel<64, 64><<<items, 256, 0, st>>>(g); break;
         case WK_G256_128: conv_wgrad_kernel<256, 128, 4, 2><<<items, 512, 0, st>>>(g); break;
         case WK_F64_1: conv_wgrad3x3_kernel<64, 1, 2><<<items, 256, 0, st>>>(g); break;       // 72 KB: two workgroups per CU
-        case WK_F64_2: conv_wgrad3x3_kernel<64, 2, 3><<<items, 256, 0, st>>>(g); break;       // 52 KB per stage: one per CU either way
+        case WK_F64_2: conv_wgrad3x3_wide_kernel<64, 2, 3><<<items, 256, 0, st>>>(g); break;  // 52 KB per stage: one per CU either way
         case WK_F32_1: conv_wgrad3x3_kernel<32, 1, 2><<<items, 256, 0, st>>>(g); break;       // 56 KB
         case WK_F32_2: conv_wgrad3x3_kernel<32, 2, 2><<<items, 256, 0, st>>>(g); break;       // 72 KB
         case WK_F16_1: conv_wgrad3x3_kernel<16, 1, 3><<<items, 256, 0, st>>>(g); break;       // 72 KB

@@ -37,7 +37,7 @@ extern "C" {
  * depend on the order in which workgroups retire: two runs of the same step are bit-identical (fp32 atomics made the
  * batch statistics differ in the last bits from run to run, which moved thresholded pseudo labels).
  *   forward  (sum y, sum y^2 of conv outputs):  FRAC = 26 -> resolution 1.5e-8 per partial (below BatchNorm's eps by
- *            three orders of magnitude after the division by the row count), |total| < 1.4e11
+ *            three orders of magnitude after the division by the row count), |total| < 1.4e11 (a partial is clamped at 2^61 fixed-point units)
  *   backward (sum g', sum g' xhat):             FRAC = 40 -> resolution 9e-13 per partial, |total| < 8.4e6
  * Partials outside the range are clamped, non-finite partials add nothing (the non-finite ELEMENTS still propagate
  * through the element-wise passes and the loss). */

@@ -63,9 +63,15 @@ static __device__ __forceinline__ float wave_max(float v) {
 // ---- order-independent per-channel accumulators (include/rgda_hip.h: rgda_stat_t, 64-bit fixed point).
 // A workgroup's partial sum (reduced in a fixed order inside the workgroup) -> round(v * 2^frac) -> integer atomic.
 static __device__ __forceinline__ long long stat_fix(float v, int frac) {
-    const double d = (double)v * (double)(1ll << frac);         // exact (a power-of-two scale)
-    if (!(fabs(d) < 0x1p62)) return (d == d && fabs(d) != __builtin_inf()) ? (d > 0 ? (1ll << 62) : -(1ll << 62)) : 0ll;
-    return __double2ll_rn(d);
+    // round(v * 2^frac) as a 64-bit integer without fp64 or the software float -> int64 routine (40+ instructions at the
+    // tail of every convolution workgroup): the scaling by a power of two is exact in fp32; x = hi * 2^31 + lo with
+    // hi = trunc(x / 2^31) and the remainder lo (same sign, |lo| < 2^31, exactly representable: it is the low part of a
+    // 24-bit mantissa), each converted by a native 32-bit instruction.
+    float x = ldexpf(v, frac);
+    if (!(fabsf(x) < 0x1p61f)) x = (v == v && fabsf(v) != __builtin_inff()) ? copysignf(0x1p61f, v) : 0.f;   // clamp; NaN / Inf add nothing
+    const float hi = truncf(x * 0x1p-31f);
+    const float lo = x - hi * 0x1p31f;
+    return ((long long)__float2int_rz(hi) << 31) + (long long)__float2int_rn(lo);
 }
 static __device__ __forceinline__ void stat_add(rgda_stat_t* p, float v, int frac) {
     atomicAdd((unsigned long long*)p, (unsigned long long)stat_fix(v, frac));

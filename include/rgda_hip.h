@@ -229,6 +229,16 @@ int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, void* ws, siz
 int rgda_stem_im2col(const float* img, void* col, int N, int H, int W, int Ho, int Wo, int Kp,
                      rgda_stream_t stream);
 
+/* The same convolution in ONE kernel straight from the NCHW f32 image (no patch matrix): y PxC bf16 [N*Ho*Wo][ldy],
+ * wgt bf16 [64][192] (k = (kh*7+kw)*3+c, zero padded), epilogue as rgda_conv2d (per-group BatchNorm statistics) or
+ * rgda_conv2d_bneval (inference BatchNorm + ReLU).  Wo % 64 must be 0 (RGDA_ERR_UNSUPPORTED otherwise: use
+ * rgda_stem_im2col + rgda_conv2d).  The image batch is ONE tensor: the row groups are consecutive blocks of images. */
+int rgda_stem_conv(const float* img, const void* wgt, void* y, int ldy, rgda_stat_t* stats, int stat_groups, int N,
+                   int H, int W, int Ho, int Wo, rgda_stream_t stream);
+int rgda_stem_conv_bneval(const float* img, const void* wgt, void* y, int ldy, const float* running_mean,
+                          const float* running_var, const float* gamma, const float* beta, float eps, int relu,
+                          int N, int H, int W, int Ho, int Wo, rgda_stream_t stream);
+
 /* BatchNorm2d (train) on PxC bf16, nn.BatchNorm2d defaults (eps 1e-5, momentum .1):
  *  finalize: stats rgda_stat_t[REPLICAS][2][C] (sum,sumsq over M rows, FRAC_FWD) -> mean/invstd f32[2][C] in `mi`,
  *            running_mean/var/num_batches_tracked update.  If stats==NULL, eval mode:

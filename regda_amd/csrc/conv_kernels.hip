@@ -758,6 +758,164 @@ extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* 
                          stride, pad, dil, mode, &b, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels; regda/_resnets.py:150-151) straight from the NCHW
+// fp32 image.  As an implicit GEMM it has K = 147 (padded to 192) and the 1x1 route -- rgda_stem_im2col + rgda_conv2d
+// -- writes and re-reads a 403 MB patch matrix for 16 images of 512 x 512 (146 + 135 us at the head of the forward
+// chain).  Here a workgroup owns 64 consecutive pixels of `rpw` consecutive output rows: the weights [64][192] stay in
+// LDS, every row stages the 7 x 133 x 3 image patch it touches (bf16), builds ITS 64 x 192 patch tile in LDS in the
+// swizzled layout the MFMA fragment reads expect, multiplies (12 MFMAs per wave) and leaves through the common
+// epilogue (bf16 rows, BatchNorm statistics or inference BatchNorm + ReLU).  The training forward still needs the
+// patch matrix for the weight gradient; it is written by rgda_stem_im2col on another stream, off the critical path.
+// Requires Wo % 64 == 0 (the 1x1 route serves everything else).  8 images of 512 x 512: 66 us against 66 + 58 us for
+// im2col + 1x1 convolution; on the whole step (where the teacher's stem runs beside the student's) -0.06 ms.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+stem_conv_kernel(ConvArgs a, const float* __restrict__ img, int rpw) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BC = 64, BP = 64, WC = 2, WP = 2, NW = 4, KP = 192, KT = KP / 64;
+    constexpr int SW = 2 * BP + 5;                      // staged image columns: wi = 2 * wo0 - 3 .. 2 * (wo0 + 63) + 3
+    constexpr int CSTR = BC * 2 + 16;
+    constexpr int EPI = BP * CSTR + NW * BC * 2 * 4;    // the epilogue image aliases the patch tile
+    constexpr int TILE = KT * 64 * 128;                 // 24 KB: [K tile][64 rows][128 B]
+    constexpr int NP = (21 * SW + 255) / 256;           // image values a thread stages per row (11)
+    static_assert(EPI <= TILE, "epilogue image must fit the patch tile");
+    // 30 KB of LDS, 212 registers: two workgroups per CU whose phases (stage / build / multiply / store) overlap.  (Capped
+    // at 168 / 128 registers for three / four per CU the kernel spills and is 2x slower: 66 -> 137-140 us per 8 images.)
+    __shared__ __attribute__((aligned(256))) unsigned char smem[TILE + 3 * 7 * (SW + 1) * 2 + 64];
+    unsigned char* sx = smem;
+    bf16_t* patch = (bf16_t*)(smem + TILE);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WC, wp = wave / WC;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int H = a.H, W = a.W, Ho = a.Ho, Wo = a.Wo;
+    const int wtiles = Wo / BP, rblocks = Ho / rpw;
+    const int wo0 = (blockIdx.x % wtiles) * BP;
+    const int ho0 = ((blockIdx.x / wtiles) % rblocks) * rpw, n = blockIdx.x / (wtiles * rblocks);
+
+    // the wave's 32 weight rows stay in REGISTERS for all rows (12 fragments of 16 B per lane, straight from memory)
+    bf16x8 fa[KT][4];
+    {
+        const bf16_t* wrow = a.w + (size_t)(wc * 32 + lrow) * KP;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fa[kt][kk] = *(const bf16x8*)(wrow + kt * 64 + (kk * 2 + lk) * 8);
+    }
+    // thread = (column vector v of the patch tile, pixel lane): its eight patch offsets are fixed
+    const int v = t % (KP / 8), pl = t / (KP / 8);      // 24 vectors x 10 pixel lanes (16 threads idle)
+    int off[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = v * 8 + e;
+        const int tap = k / 3, c = k % 3, kh = tap / 7, kw = tap % 7;
+        off[e] = (k < 147) ? (c * 7 + kh) * (SW + 1) + kw : -1;
+    }
+    // image values of one output row: element i of the thread = staged index t + 256 i -> (row = c * 7 + kh, x).  The
+    // element's image offset for the first row and its kh are fixed; a row step moves every offset by 2 W.
+    float pv[NP];
+    int po[NP];                                         // offset relative to the image's (c = 0, row 2 ho0 - 3) | kh << 28, or -1
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = t + 256 * i, row = idx / SW, x = idx % SW;
+        const int c = row / 7, kh = row % 7;
+        const int wi = wo0 * 2 - 3 + x;
+        po[i] = (idx < 21 * SW && wi >= 0 && wi < W) ? (((c * H + kh) * W + wi) | (kh << 28)) : -1;
+    }
+    auto fetch = [&](int ho) {
+        const float* base = img + ((size_t)n * 3 * H + (ho * 2 - 3)) * W;      // may point above the image: guarded below
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const unsigned hi = (unsigned)(ho * 2 - 3 + (po[i] >> 28));
+            pv[i] = (po[i] >= 0 && hi < (unsigned)H) ? base[po[i] & 0x0fffffff] : 0.f;
+        }
+    };
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    fetch(ho0);
+    for (int r = 0; r < rpw; ++r) {
+        const int ho = ho0 + r;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = t + 256 * i;
+            if (idx < 21 * SW) patch[(idx / SW) * (SW + 1) + idx % SW] = f2bf(pv[i]);
+        }
+        __syncthreads();                                // patch complete; the previous epilogue is done with the tile
+        if (r + 1 < rpw) fetch(ho + 1);                 // the next row's image values fly under build / multiply / store
+        if (pl < 256 / (KP / 8)) {
+            for (int px = pl; px < BP; px += 256 / (KP / 8)) {
+                u16x8 out;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) out[e] = (off[e] < 0) ? (bf16_t)0 : patch[off[e] + 2 * px];
+                *(u16x8*)(sx + (v >> 3) * 8192 + px * 128 + (((v & 7) ^ ((px >> 1) & 7)) << 4)) = out;
+            }
+        }
+        __syncthreads();
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+        const int rb = wp * 32 + lrow;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 fb = *(const bf16x8*)(sx + kt * 8192 + rb * 128 + (((kk * 2 + lk) ^ ((rb >> 1) & 7)) << 4));
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kt][kk], fb, acc[0][0], 0, 0, 0);
+            }
+        __syncthreads();                                // every wave has read its fragments: the tile becomes the C image
+        const int m0 = (n * Ho + ho) * Wo + wo0;
+        conv_epilogue<BC, BP, WC, WP>(a, acc, sx, m0, 0, s, q, r + 1 == rpw, blockIdx.x & (NREP - 1));
+        __syncthreads();                                // (the epilogue's last LDS reads precede the next build)
+    }
+#endif
+}
+
+static int stem_conv_launch(const float* img, const void* wgt, void* y, int ldy, rgda_stat_t* stats, int stat_groups,
+                            const BnEvalFuse* bne, int N, int H, int W, int Ho, int Wo, rgda_stream_t stream) {
+    if (!img || !wgt || !y || N <= 0 || H <= 0 || W <= 0 || (ldy & 7) || ldy < 64) return RGDA_ERR_ARG;
+    if (Ho != (H + 6 - 7) / 2 + 1 || Wo != (W + 6 - 7) / 2 + 1) return RGDA_ERR_ARG;
+    if (Wo % 64) return RGDA_ERR_UNSUPPORTED;           // the im2col + 1x1 route serves these
+    if (stat_groups < 1) stat_groups = 1;
+    if ((N % stat_groups) || (bne && stats)) return RGDA_ERR_ARG;
+    const long long M = (long long)N * Ho * Wo;
+    if (M > 0x7fffffffLL) return RGDA_ERR_ARG;
+    ConvArgs a;
+    a.x = nullptr; a.w = (const bf16_t*)wgt; a.y = (bf16_t*)y; a.res = nullptr; a.stats = stats; a.res_mask = nullptr;
+    a.ldx = 0; a.ldy = ldy; a.ldres = 0;
+    a.N = N; a.H = H; a.W = W; a.Cin = 3; a.Ho = Ho; a.Wo = Wo; a.Cout = 64; a.KH = 7; a.KW = 7;
+    a.stride = 2; a.pad = 3; a.dil = 1; a.mode = 0;
+    a.M = (int)M; a.tiles_c = 1; a.tiles_p = 0;
+    a.rows_per_group = (int)(M / stat_groups);
+    a.howo_shift = a.wo_shift = -1; a.dbg = nullptr; a.tpw = 0; a.skip = 0;
+    a.bn_y = a.bn_x = nullptr; a.bn_mask = nullptr; a.bn_mi = a.bn_nscale = nullptr; a.bn_ldy = a.bn_ldx = a.bn_rpi = a.bn_relu = 0;
+    a.ev_rm = a.ev_rv = a.ev_gamma = a.ev_beta = nullptr; a.ev_eps = 0.f; a.ev_relu = 0;
+    if (bne) {
+        if (!bne->rm || !bne->rv || !bne->gamma || !bne->beta) return RGDA_ERR_ARG;
+        a.ev_rm = bne->rm; a.ev_rv = bne->rv; a.ev_gamma = bne->gamma; a.ev_beta = bne->beta; a.ev_eps = bne->eps; a.ev_relu = bne->relu;
+    }
+    int rpw = 8;
+    while (rpw > 1 && (Ho % rpw)) rpw >>= 1;
+    const long long blocks = (long long)N * (Ho / rpw) * (Wo / 64);
+    if (blocks > 0x7fffffffLL) return RGDA_ERR_ARG;
+    stem_conv_kernel<<<(int)blocks, 256, 0, to_stream(stream)>>>(a, img, rpw);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+extern "C" int rgda_stem_conv(const float* img, const void* wgt, void* y, int ldy, rgda_stat_t* stats, int stat_groups,
+                              int N, int H, int W, int Ho, int Wo, rgda_stream_t stream) {
+    return stem_conv_launch(img, wgt, y, ldy, stats, stat_groups, nullptr, N, H, W, Ho, Wo, stream);
+}
+
+extern "C" int rgda_stem_conv_bneval(const float* img, const void* wgt, void* y, int ldy, const float* running_mean,
+                                     const float* running_var, const float* gamma, const float* beta, float eps, int relu,
+                                     int N, int H, int W, int Ho, int Wo, rgda_stream_t stream) {
+    BnEvalFuse e = {running_mean, running_var, gamma, beta, eps, relu};
+    return stem_conv_launch(img, wgt, y, ldy, nullptr, 1, &e, N, H, W, Ho, Wo, stream);
+}
+
 // ======================================================================================
 // weight gradient
 // ======================================================================================

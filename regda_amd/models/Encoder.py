@@ -289,6 +289,7 @@ class Deeplabv2(nn.Module):
         self.factored_ppm = True
         self.parallel_heads = True       # training forward: the second head on its own stream
         self.early_last_flush = True     # layer1's weight gradients start before the stem's backward
+        self.fused_stem = True           # conv1 straight from the image where the map width allows it (rgda_stem_conv)
         self.parallel_ds = True          # downsample branches on the head stream
         self._head_stream = None
         self._mat_cache = {}
@@ -922,6 +923,43 @@ class Deeplabv2(nn.Module):
                            dx_res, None, res_mask=dx_res_mask)
         return dx, gm
 
+    def _stem_fwd(self, T, xs, Ng, H, W, H1, W1, main_stream):
+        """conv1 + bn1 + ReLU from the fp32 images in one convolution kernel per BatchNorm group (rgda_stem_conv: no patch
+        matrix on the forward chain).  Training still needs the patch matrix -- the weight gradient's operand -- so
+        rgda_stem_im2col writes it on the head stream, next to the forward; -> (activation, event after the im2col)."""
+        dev = self.device
+        conv, bn = self.convs['encoder.resnet.conv1'], self.bns['encoder.resnet.bn1']
+        G = len(xs)
+        N, M = Ng * G, Ng * G * H1 * W1
+        y = torch.empty(M, 64, dtype=BF, device=dev)
+        if T is None:
+            for gi, xg in enumerate(xs):
+                ops.stem_conv_bneval(xg, self.stem_wb, y[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], bn.rm, bn.rv, bn.gamma,
+                                     bn.beta, True, Ng, H, W, H1, W1)
+            return y, None
+        col = torch.empty(M, STEM_KP, dtype=BF, device=dev)
+        side = None
+        if self.parallel_heads:
+            if self._head_stream is None:
+                self._head_stream = torch.cuda.Stream(device=dev)
+            side = self._head_stream
+            plan.wait_event(side, plan.record_event(main_stream))       # the images are ready on the main stream
+        with (ops.use_stream(side) if side is not None else contextlib.nullcontext()):
+            for gi, xg in enumerate(xs):
+                ops.stem_im2col(xg, col[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], Ng, H, W, H1, W1)
+            col_ready = plan.record_event(side) if side is not None else None
+        c = torch.empty(M, 64, dtype=BF, device=dev)
+        stats = T['stats_pool'].take(G * NREP * 2 * 64)
+        st = stats.view(G, -1)
+        for gi, xg in enumerate(xs):
+            ops.stem_conv(xg, self.stem_wb, c[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], st[gi], Ng, H, W, H1, W1)
+        mi = torch.empty(G, 2, 64, device=dev)
+        rmask = (torch.empty(M, 8, dtype=torch.uint8, device=dev) if (self.relu_sign_mask and 64 >= self.relu_sign_mask) else None)
+        ops.bn_train_apply(c, stats, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, y, M, 64, True, None, None, H1 * W1, groups=G,
+                           relu_mask=rmask)
+        T['stem'] = (col, c, y, mi, (N, H, W, H1, W1), None, rmask)
+        return y, col_ready
+
     # ------------------------------------------------------------------ forward plan
     def _forward_plan(self, x, T):
         """x: one NCHW image batch, or a list of equally shaped batches that run through the network together
@@ -935,11 +973,15 @@ class Deeplabv2(nn.Module):
         C = self.convs
         B = self.bns
         H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-        col = torch.empty(N * H1 * W1, STEM_KP, dtype=BF, device=dev)
-        for gi, xg in enumerate(xs):
-            ops.stem_im2col(xg, col[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], Ng, H, W, H1, W1)
-        a0, _, _ = self._cbr_fwd(T, 'stem', C['encoder.resnet.conv1'], B['encoder.resnet.bn1'], col, N, H, W, True,
-                                 wb=self.stem_wb, geom=(H1, W1))
+        col_ready = None
+        if W1 % 64 == 0 and self.fused_stem:
+            a0, col_ready = self._stem_fwd(T, xs, Ng, H, W, H1, W1, main_stream)
+        else:
+            col = torch.empty(N * H1 * W1, STEM_KP, dtype=BF, device=dev)
+            for gi, xg in enumerate(xs):
+                ops.stem_im2col(xg, col[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], Ng, H, W, H1, W1)
+            a0, _, _ = self._cbr_fwd(T, 'stem', C['encoder.resnet.conv1'], B['encoder.resnet.bn1'], col, N, H, W, True,
+                                     wb=self.stem_wb, geom=(H1, W1))
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         y = torch.empty(N * H2 * W2, 64, dtype=BF, device=dev)
         idx = torch.empty(N * H2 * W2, 64, dtype=torch.uint8, device=dev)
@@ -982,6 +1024,8 @@ class Deeplabv2(nn.Module):
         feat = torch.empty(N, 2048, h, w, device=dev) if T is not None else None   # eval returns probabilities only
         imi = torch.empty(N, 2, 2048, device=dev)
         ops.instnorm_fwd(y, xn, None, feat, imi, N, HW, 2048)
+        if col_ready is not None:           # the stem's patch matrix (written beside the forward) is backward's operand
+            plan.wait_event(main_stream, col_ready)
         def wait_head_weights():                                   # head weight slices rebuilt on another stream
             if self._hw_ready is not None:
                 main_stream.wait_event(self._hw_ready)

@@ -321,6 +321,18 @@ def conv2d_wgrad_grouped(items):
     L.call('rgda_conv2d_wgrad_grouped', ap, len(items), ws.data_ptr(), ws.numel(), _stream())
 
 
+def stem_conv(img, wb, y, stats, N, H, W, Ho, Wo, stat_groups=1):
+    """The 7x7 / stride-2 stem straight from the NCHW fp32 image (rgda_stem_conv; Wo % 64 == 0): y [N*Ho*Wo, 64(view)]
+    bf16, wb the padded bf16 stem weights [64, 1, 192], stats as for conv2d."""
+    lib().call('rgda_stem_conv', img.data_ptr(), wb.data_ptr(), y.data_ptr(), _ld(y), _stat(stats), stat_groups, N, H, W, Ho, Wo,
+               _stream())
+
+
+def stem_conv_bneval(img, wb, y, rm, rv, gamma, beta, relu, N, H, W, Ho, Wo, eps=1e-5):
+    lib().call('rgda_stem_conv_bneval', img.data_ptr(), wb.data_ptr(), y.data_ptr(), _ld(y), rm.data_ptr(), rv.data_ptr(),
+               gamma.data_ptr(), beta.data_ptr(), eps, int(relu), N, H, W, Ho, Wo, _stream())
+
+
 def stem_im2col(img, col, N, H, W, Ho, Wo):
     lib().call('rgda_stem_im2col', img.data_ptr(), col.data_ptr(), N, H, W, Ho, Wo, col.shape[1], _stream())
 

@@ -169,6 +169,51 @@ def test_stem_im2col_and_gemm(ops):
     assert relerr(from_pxc(y, N, Ho, Wo), ref) < 1e-2
 
 
+@pytest.mark.parametrize('N,H,W,groups', [(2, 40, 128, 1), (4, 128, 256, 2), (2, 18, 384, 2)])
+def test_fused_stem_conv_equals_the_im2col_route(ops, N, H, W, groups):
+    """rgda_stem_conv (the 7x7 / stride-2 stem straight from the image, Wo % 64 == 0) against (a) F.conv2d on the
+    bf16-rounded operands and (b) the rgda_stem_im2col + rgda_conv2d route: the same bf16 products summed in another
+    order inside the fp32 accumulator (outputs agree to one bf16 rounding, statistics to 1e-4); the inference-BatchNorm
+    form against rgda_conv2d_bneval; odd heights / row blocks, per-group statistics; other widths are refused."""
+    g = torch.Generator().manual_seed(31)
+    img = torch.randn(N, 3, H, W, generator=g)
+    w = rbf(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    M = N * Ho * Wo
+    wp = torch.zeros(64, 192, dtype=BF, device='cuda')
+    ops.pad_cast_bf16(w.permute(0, 2, 3, 1).reshape(64, 147).contiguous().cuda(), wp, 64, 147, 192)
+    wb = wp.reshape(64, 1, 192)
+    imgc = img.cuda()
+    # the fused kernel takes one image batch per statistics group (the step has one tensor per domain)
+    y = torch.empty(M, 64, dtype=BF, device='cuda')
+    st = ops.new_stats(groups, 8, 2, 64)
+    Ng, Mg = N // groups, M // groups
+    for gi in range(groups):
+        ops.stem_conv(imgc[gi * Ng:(gi + 1) * Ng].contiguous(), wb, y[gi * Mg:(gi + 1) * Mg], st[gi], Ng, H, W, Ho, Wo)
+    ref = F.conv2d(rbf(img), w, None, 2, 3)
+    assert relerr(from_pxc(y, N, Ho, Wo), ref) < 1e-2
+    col = torch.empty(M, 192, dtype=BF, device='cuda')
+    ops.stem_im2col(imgc, col, N, H, W, Ho, Wo)
+    y2 = torch.empty(M, 64, dtype=BF, device='cuda')
+    st2 = ops.new_stats(groups, 8, 2, 64)
+    ops.conv2d(col, wb, y2, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1, 0, None, st2, groups)
+    assert rel_l2(y, y2.float()) < 2e-3 and (y.float() - y2.float()).abs().max().item() <= 2.0 ** -7 * y2.float().abs().max().item()
+    a, b = ops.stats_value(st).sum(1), ops.stats_value(st2).sum(1)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-3 * float(b.abs().max()))
+    yg = y.float().view(groups, Mg, 64)
+    torch.testing.assert_close(a[:, 0].float(), yg.sum(1), rtol=1e-4, atol=0.5)      # statistics of the stored (rounded) rows
+    torch.testing.assert_close(a[:, 1].float(), (yg * yg).sum(1), rtol=1e-4, atol=0.5)
+    # inference form
+    rm, rv = torch.randn(64, generator=g).cuda() * 0.1, (torch.rand(64, generator=g) + 0.5).cuda()
+    gam, bet = (torch.rand(64, generator=g) + 0.5).cuda(), torch.randn(64, generator=g).cuda() * 0.1
+    e1, e2 = torch.empty(M, 64, dtype=BF, device='cuda'), torch.empty(M, 64, dtype=BF, device='cuda')
+    ops.stem_conv_bneval(imgc, wb, e1, rm, rv, gam, bet, True, N, H, W, Ho, Wo)
+    ops.conv2d_bneval(col, wb, e2, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1, rm, rv, gam, bet, True)
+    assert rel_l2(e1, e2.float()) < 3e-3 and float(e1.float().min()) >= 0.0
+    with pytest.raises(ValueError):
+        ops.stem_conv(imgc[:, :, :, :96].contiguous(), wb, y, None, N, H, 96, Ho, 48)
+
+
 @pytest.mark.parametrize('N,H,W', [(2, 32, 48), (1, 38, 270), (3, 16, 130)])
 def test_stem_im2col_columns_exact(ops, N, H, W):
     """Every column vector, bit-exact: col[(n,ho,wo)][(kh*7+kw)*3 + c] = bf16(img[n, c, 2ho-3+kh, 2wo-3+kw]) or 0

@@ -119,8 +119,8 @@ def conv_flops_probe(step_fn, park_ms=150.0):
                  H % (64 // min(W, 64)) == 0 and dil in (1, 2))
         if fused:
             wt = min(W, 64)     # ring stages as rgda_conv2d_wgrad_grouped picks them (two workgroups per CU where two rings fit)
-            if (wt, dil) == (64, 2):
-                return 'conv_wgrad3x3_wide_kernel<64, 2, 3>'
+            if (wt, dil) in ((64, 1), (64, 2), (32, 2)):
+                return 'conv_wgrad3x3_wide_kernel<%d, %d, 3>' % (wt, dil)
             return 'conv_wgrad3x3_kernel<%d, %d, %d>' % (wt, dil, 3 if (wt, dil) == (16, 1) else 2)
         bco, bci = (64 if co <= 64 else 128), (64 if ci <= 64 else 128)
         if bci == 128 and co >= 256 and co % 256 == 0:

@@ -944,65 +944,102 @@ struct WgradArgs {
 // 2.5 ms per step.)  NACC = f32x16 accumulators per thread, NT = threads per workgroup.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define RGDA_AUX_SC1 16     /* cache-policy operand of the raw buffer builtins: bit 4 = sc1 (device scope) on gfx94x/95x */
+// Many splits (a 64 x 64 result over 262 144 pixels wants hundreds of workgroups) are combined on TWO levels so that no
+// workgroup walks hundreds of partials: splits form groups of RGDA_SPLIT_GROUP consecutive splits, the last arriver of
+// a group sums the group's partials in split order and leaves ONE level-2 partial, the last group to finish sums the
+// level-2 partials in group order.  The association ((p0 + .. + p7) + (p8 + .. + p15) + ...) is fixed by the split
+// numbers alone.  Workspace per tile: splits + groups slices, 1 + groups counters (all left zero).
+#define RGDA_SPLIT_GROUP 8
+static inline __host__ __device__ int split_groups(int splits) { return splits > 2 * RGDA_SPLIT_GROUP ? (splits + RGDA_SPLIT_GROUP - 1) / RGDA_SPLIT_GROUP : 1; }
+static inline __host__ __device__ int split_slots(int splits) { const int g = split_groups(splits); return splits + (g > 1 ? g : 0); }
+
+// Register discipline: the tap-fused kernels are capped at 256 registers with 144 of them accumulators, and a SPILL inside
+// their K loop breaks the counted `s_waitcnt vmcnt(N)` the LDS-DMA ring is ordered by (a scratch access is one more
+// vector-memory operation in flight: seen as racy 1e-3 errors in multi-layer launches when this function staged 36
+// vectors).  So the partials are accumulated straight into the (dead) accumulators, 12 staging vectors at a time.
 template <int NACC, int NT>
 static __device__ __forceinline__ bool split_k_combine(const WgradArgs& a, int tile, int split, f32x16 (&acc)[NACC],
                                                        unsigned char* smem) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int t = threadIdx.x;
     constexpr int SLICE_B = NACC * 16 * NT * 4;                        // bytes per partial tile
+    const int S = a.splits, NG = split_groups(S), slots = split_slots(S);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.ws_part + (size_t)tile * a.splits * (SLICE_B / 4)), 0, a.splits * SLICE_B, 0x00020000);
-#pragma unroll
-    for (int q = 0; q < NACC; ++q)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const u32x4 v = {__float_as_uint(acc[q][4 * g]), __float_as_uint(acc[q][4 * g + 1]),
-                             __float_as_uint(acc[q][4 * g + 2]), __float_as_uint(acc[q][4 * g + 3])};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((q * 4 + g) * NT + t) * 16, split * SLICE_B, RGDA_AUX_SC1);
-        }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's partial values have reached memory ...
-    __syncthreads();                                        // ... every thread's have, before the arrival is counted
+        (void*)(a.ws_part + (size_t)tile * slots * (SLICE_B / 4)), 0, slots * SLICE_B, 0x00020000);
+    int* cnt = a.ws_cnt + tile * (NG + 1);                            // [0]: level 2, [1 + g]: level-1 group g
     int* flag = (int*)smem;
-    if (t == 0) *flag = atomicAdd(a.ws_cnt + tile, 1);
-    __syncthreads();
-    const bool last = (*flag == a.splits - 1);
-    if (!last) return false;
-    // in chunks of <= 4 accumulators: all 16 loads of a split are in flight together (one memory round trip per split
-    // and chunk; an element-by-element loop is a dependent round trip per 16 bytes), the adds keep split order
-    constexpr int CH = (NACC <= 4) ? NACC : ((NACC % 3 == 0) ? 3 : 4);
-    static_assert(NACC % CH == 0, "accumulator count must divide into chunks");
+    // leave the accumulators in slice `slot`, make them visible device-wide, count the arrival: -> arrivals before this one
+    auto publish = [&](int slot, int* counter) {
 #pragma unroll
-    for (int q0 = 0; q0 < NACC; q0 += CH) {
-        f32x4 sum[CH * 4];
+        for (int q = 0; q < NACC; ++q)
 #pragma unroll
-        for (int i = 0; i < CH * 4; ++i) sum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < a.splits; sp += 2) {                    // fixed order, whoever arrived first
-            u32x4 v[CH * 4], w[CH * 4];                               // two splits per round trip
-            const bool two = sp + 1 < a.splits;
+            for (int g = 0; g < 4; ++g) {
+                const u32x4 v = {__float_as_uint(acc[q][4 * g]), __float_as_uint(acc[q][4 * g + 1]),
+                                 __float_as_uint(acc[q][4 * g + 2]), __float_as_uint(acc[q][4 * g + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((q * 4 + g) * NT + t) * 16, slot * SLICE_B, RGDA_AUX_SC1);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial values have reached memory ...
+        __syncthreads();                                    // ... every thread's have, before the arrival is counted
+        if (t == 0) *flag = atomicAdd(counter, 1);
+        __syncthreads();
+        const int before = *flag;
+        __syncthreads();                                    // (the flag word is reused by a second publish)
+        return before;
+    };
+    // acc = slices [first, first + count) added in that order, in chunks of <= 4 accumulators whose 12-16 loads of a
+    // slice are in flight together (an element-by-element loop is a dependent memory round trip per 16 bytes); kernels
+    // with few accumulators fetch two slices per round trip
+    auto gather = [&](int first, int count) {
+        constexpr int CH = (NACC <= 4) ? NACC : ((NACC % 3 == 0) ? 3 : 4);
+        constexpr bool PAIR = NACC <= 4;
+        static_assert(NACC % CH == 0, "accumulator count must divide into chunks");
 #pragma unroll
-            for (int i = 0; i < CH * 4; ++i)
-                v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((q0 * 4 + i) * NT + t) * 16, sp * SLICE_B, RGDA_AUX_SC1);
-            if (two) {
+        for (int q0 = 0; q0 < NACC; q0 += CH) {
+#pragma unroll
+            for (int q = q0; q < q0 + CH; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+            for (int sp = first; sp < first + count; sp += (PAIR ? 2 : 1)) {
+                u32x4 v[CH * 4], w[PAIR ? CH * 4 : 1];
+                const bool two = PAIR && sp + 1 < first + count;
 #pragma unroll
                 for (int i = 0; i < CH * 4; ++i)
-                    w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((q0 * 4 + i) * NT + t) * 16, (sp + 1) * SLICE_B, RGDA_AUX_SC1);
-            }
+                    v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((q0 * 4 + i) * NT + t) * 16, sp * SLICE_B, RGDA_AUX_SC1);
+                if constexpr (PAIR) {
+                    if (two) {
 #pragma unroll
-            for (int i = 0; i < CH * 4; ++i)
-                sum[i] += f32x4{__uint_as_float(v[i][0]), __uint_as_float(v[i][1]), __uint_as_float(v[i][2]), __uint_as_float(v[i][3])};
-            if (two) {
+                        for (int i = 0; i < CH * 4; ++i)
+                            w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ((q0 * 4 + i) * NT + t) * 16, (sp + 1) * SLICE_B, RGDA_AUX_SC1);
+                    }
+                }
 #pragma unroll
-                for (int i = 0; i < CH * 4; ++i)
-                    sum[i] += f32x4{__uint_as_float(w[i][0]), __uint_as_float(w[i][1]), __uint_as_float(w[i][2]), __uint_as_float(w[i][3])};
+                for (int i = 0; i < CH * 4; ++i) {
+                    const int q = q0 + i / 4, g = i % 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q][4 * g + e] += __uint_as_float(v[i][e]);
+                }
+                if constexpr (PAIR) {
+                    if (two) {
+#pragma unroll
+                        for (int i = 0; i < CH * 4; ++i) {
+                            const int q = q0 + i / 4, g = i % 4;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[q][4 * g + e] += __uint_as_float(w[i][e]);
+                        }
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int i = 0; i < CH * 4; ++i) {
-            const int q = q0 + i / 4, g = i % 4;
-            acc[q][4 * g] = sum[i][0]; acc[q][4 * g + 1] = sum[i][1]; acc[q][4 * g + 2] = sum[i][2]; acc[q][4 * g + 3] = sum[i][3];
-        }
-    }
-    if (t == 0) a.ws_cnt[tile] = 0;        // ready for the next launch (nobody else looks at this counter any more)
+    };
+    const int G1 = (NG > 1) ? RGDA_SPLIT_GROUP : S;
+    const int grp = split / G1, gfirst = grp * G1, gsize = min(G1, S - gfirst);
+    if (publish(split, cnt + 1 + grp) != gsize - 1) return false;
+    gather(gfirst, gsize);
+    if (t == 0) cnt[1 + grp] = 0;          // ready for the next launch (nobody else looks at this counter any more)
+    if (NG == 1) return true;
+    if (publish(S + grp, cnt) != NG - 1) return false;
+    gather(S, NG);
+    if (t == 0) cnt[0] = 0;
     return true;
 #else
     return false;
@@ -1433,7 +1470,8 @@ template <int WT, int D, int STAGES = 3>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_wgrad3x3_kernel(WgradGroup g) {
     conv_wgrad3x3_body<WT, D, STAGES>(g);
 }
-// the dilated 64-wide variant: 52 KB per ring stage, one workgroup per CU whatever the register count
+// the variants that do not fit 256 registers without spilling (a spill inside the K loop would break the counted vmcnt
+// waits: tests/test_host_logic.py checks the compiler's report) or two rings per CU: one wave per SIMD, 3-stage ring
 template <int WT, int D, int STAGES = 3>
 __global__ void __launch_bounds__(256) conv_wgrad3x3_wide_kernel(WgradGroup g) {
     conv_wgrad3x3_body<WT, D, STAGES>(g);
@@ -1516,14 +1554,15 @@ static inline size_t wgrad_slice_floats(int kind) {
 // K splits of the layers of one launch (g.a[0..n)); 1 without a workspace.  One split count S for the launch (a layer
 // with few K tiles gets fewer: never fewer than 16 K tiles per split), chosen by a round model of the launch: its
 // workgroups run in ceil(workgroups / capacity) rounds (capacity = 256, one workgroup per CU, for the 144 KB tiles;
-// 512 for the others) of ceil(K tiles / S) tile steps each, plus 8 + 2 S tile steps when S > 1: the partial tiles'
-// trip through the workspace and the last workgroup's walk over the S partials.  (Splitting "until the chip is full" -- the rule before ABI 4 -- made
+// 512 for the others) of ceil(K tiles / S) tile steps each, plus 8 + 2 x (partials one workgroup sums) tile steps when
+// S > 1: the partial tiles' trip through the workspace and the last arrivers' walks (S partials on one level, 8 + S / 8
+// on two, split_k_combine).  (Splitting "until the chip is full" -- the rule before ABI 4 -- made
 // 336 workgroups out of 112 tiles: two rounds of 86 steps where S = 2 gives one round of 128.)
 // Returns the bytes of partial tiles the launch needs behind the counters.
 static size_t wgrad_plan_splits(int kind, WgradGroup& g, bool have_ws) {
     // workgroups the chip holds at once: one per CU for the 144 KB generic tile and the dilated 64-wide tap-fused kernel,
     // two per CU for everything else (the tap-fused kernels run 2-stage rings of 48-72 KB)
-    const int capacity = (kind == WK_G256_128 || kind == WK_F64_2) ? 256 : 512;
+    const int capacity = (kind == WK_G256_128 || kind == WK_F64_1 || kind == WK_F64_2 || kind == WK_F32_2) ? 256 : 512;
     int minkt = 16;
     if (const char* e = TUNE_ENV("RGDA_WGRAD_MINKT")) minkt = atoi(e);                     // tuning experiments only
     int best = 1;
@@ -1535,7 +1574,7 @@ static size_t wgrad_plan_splits(int kind, WgradGroup& g, bool have_ws) {
         best = cdiv(capacity, total);
     } else if (have_ws) {
         long long best_cost = -1;
-        for (int S = 1; S <= 128; S += (S < 16 ? 1 : 4)) {
+        for (int S = 1; S <= 512; S += (S < 16 ? 1 : 8)) {
             long long wgs = 0, steps = 0;
             for (int l = 0; l < g.n; ++l) {
                 const int KT = wgrad_ktiles(g.a[l]);
@@ -1546,7 +1585,8 @@ static size_t wgrad_plan_splits(int kind, WgradGroup& g, bool have_ws) {
                 wgs += (long long)wgrad_tiles(g.a[l]) * cdiv(KT, per);
                 if (per > steps) steps = per;
             }
-            const long long cost = (long long)cdiv(wgs, capacity) * (steps + (S > 1 ? 8 + 2 * S : 0));
+            const int walk = split_groups(S) > 1 ? RGDA_SPLIT_GROUP + split_groups(S) + 8 : S;   // partials one workgroup sums
+            const long long cost = (long long)cdiv(wgs, capacity) * (steps + (S > 1 ? 8 + 2 * walk : 0));
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = S; }
         }
     }
@@ -1567,8 +1607,8 @@ static size_t wgrad_plan_splits(int kind, WgradGroup& g, bool have_ws) {
         a.ws_part = (float*)(uintptr_t)floats;
         a.ws_cnt = (int*)(uintptr_t)tiles_before;
         if (a.splits > 1) {
-            floats += (size_t)wgrad_tiles(a) * a.splits * wgrad_slice_floats(kind);
-            tiles_before += wgrad_tiles(a);
+            floats += (size_t)wgrad_tiles(a) * split_slots(a.splits) * wgrad_slice_floats(kind);
+            tiles_before += wgrad_tiles(a) * (split_groups(a.splits) + 1);      // counters of this layer
         }
     }
     for (int l = g.n; l <= RGDA_WGRAD_MAXG; ++l) g.first[l] = items;
@@ -1577,10 +1617,10 @@ static size_t wgrad_plan_splits(int kind, WgradGroup& g, bool have_ws) {
 
 static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipStream_t st) {
     const size_t need = wgrad_plan_splits(kind, g, ws != nullptr);
-    int tiles_split = 0;
+    int counters = 0;
     for (int l = 0; l < g.n; ++l)
-        if (g.a[l].splits > 1) tiles_split += wgrad_tiles(g.a[l]);
-    if (need && (ws_bytes < RGDA_WGRAD_WS_COUNTERS + need || (size_t)tiles_split * 4 > RGDA_WGRAD_WS_COUNTERS)) return RGDA_ERR_WORKSPACE;
+        if (g.a[l].splits > 1) counters += wgrad_tiles(g.a[l]) * (split_groups(g.a[l].splits) + 1);
+    if (need && (ws_bytes < RGDA_WGRAD_WS_COUNTERS + need || (size_t)counters * 4 > RGDA_WGRAD_WS_COUNTERS)) return RGDA_ERR_WORKSPACE;
     for (int l = 0; l < g.n; ++l) {
         WgradArgs& a = g.a[l];
         a.ws_part = (float*)((char*)ws + RGDA_WGRAD_WS_COUNTERS) + (size_t)(uintptr_t)a.ws_part;
@@ -1599,10 +1639,10 @@ static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipS
         case WK_G64_128: conv_wgrad_kernel<64, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
         case WK_G64_64: conv_wgrad_kernel<64, 64><<<items, 256, 0, st>>>(g); break;
         case WK_G256_128: conv_wgrad_kernel<256, 128, 4, 2><<<items, 512, 0, st>>>(g); break;
-        case WK_F64_1: conv_wgrad3x3_kernel<64, 1, 2><<<items, 256, 0, st>>>(g); break;       // 72 KB: two workgroups per CU
+        case WK_F64_1: conv_wgrad3x3_wide_kernel<64, 1, 3><<<items, 256, 0, st>>>(g); break;  // (capped at 256 registers it spills)
         case WK_F64_2: conv_wgrad3x3_wide_kernel<64, 2, 3><<<items, 256, 0, st>>>(g); break;  // 52 KB per stage: one per CU either way
         case WK_F32_1: conv_wgrad3x3_kernel<32, 1, 2><<<items, 256, 0, st>>>(g); break;       // 56 KB
-        case WK_F32_2: conv_wgrad3x3_kernel<32, 2, 2><<<items, 256, 0, st>>>(g); break;       // 72 KB
+        case WK_F32_2: conv_wgrad3x3_wide_kernel<32, 2, 3><<<items, 256, 0, st>>>(g); break;  // (capped at 256 registers it spills)
         case WK_F16_1: conv_wgrad3x3_kernel<16, 1, 3><<<items, 256, 0, st>>>(g); break;       // 72 KB
         default: conv_wgrad3x3_kernel<16, 2, 2><<<items, 256, 0, st>>>(g); break;              // 56 KB
     }

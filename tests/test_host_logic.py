@@ -134,3 +134,25 @@ def test_ema_mirror_semantics(gold):
     np.testing.assert_allclose(lin.weight.detach().numpy(), g['shadow'], rtol=1e-6)
     ema.restore()
     np.testing.assert_allclose(lin.weight.detach().numpy(), g['w1'], rtol=1e-6)
+
+
+def test_no_register_spills_in_the_dma_ring_kernels():
+    """The convolution / weight-gradient kernels order their LDS-DMA rings with COUNTED `s_waitcnt vmcnt(N)`: a register
+    spill inside such a loop is one more vector-memory operation in flight and silently breaks the count (seen as racy
+    1e-3 errors when a register-capped kernel spilled).  The compiler's own report must show no spill for any of them."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'regda_amd', 'csrc', 'conv_kernels.hip')
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'conv.s')
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics',
+                               '-S', '--cuda-device-only', '-o', out, src], stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    meta = txt[txt.index('amdhsa.kernels:'):]
+    kernels = re.findall(r'\.name:\s+(\S+).*?\.vgpr_spill_count:\s+(\d+)', meta, flags=re.S)
+    assert len(kernels) >= 25
+    spilled = [(n, int(c)) for n, c in kernels if int(c) and ('conv_igemm' in n or 'conv_wgrad' in n or 'conv3x3_c64' in n)]
+    assert not spilled, spilled

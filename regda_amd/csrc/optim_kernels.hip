@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(256) weight_transpose_kernel(const float* __re
 }
 
 // all derived bf16 weight layouts of a model in ONE launch: table[n][8] int64 =
-//   {src f32*, dst bf16*, Co, T, Ci, first_block, src_ld, mode}
+//   {src*, dst bf16*, Co, T, Ci, first_block, src_ld, mode}; src is f32, or bf16 when mode has bit 4 (16) set -- the bf16
+//   mirror of the master weights, written by the optimizer kernel with the same rounding: half the bytes to read
 // src element (co, tap, ci) lives at src[(co*T + tap)*src_ld + ci] (src_ld = Ci for a whole tensor, larger for a
 // channel slice of a wider one); mode 0: dst[ci][tap][co] (data-gradient operand), mode 1: dst[tap][co][ci]
 // (nine 1x1 filters stacked), mode 2: dst[co][tap][ci] (plain slice).  A row owns ceil(Ci/32)*ceil(Co/32)*T
@@ -162,10 +163,12 @@ __global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const lon
     }
     const long long* e = table + lo * 8;
     const float* w = (const float*)e[0];
+    const bf16_t* wh = (const bf16_t*)e[0];
     bf16_t* wt = (bf16_t*)e[1];
     const int Co = (int)e[2], T = (int)e[3], Ci = (int)e[4];
     const long long sld = e[6];
-    const int mode = (int)e[7];
+    const int mode = (int)e[7] & 15;
+    const bool src16 = ((int)e[7] & 16) != 0;
     int rel = (int)(b - e[5]);
     const int nci = (Ci + TS - 1) / TS, nco = (Co + TS - 1) / TS;
     const int bx = rel % nci; rel /= nci;
@@ -173,13 +176,21 @@ __global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const lon
     const int tap = rel / nco;
     const int co0 = by * TS, ci0 = bx * TS;
     // fast path: 16-byte reads (4 floats along ci), 8-byte writes (4 bf16 along the destination's contiguous index)
-    const bool vec = !(Ci & 3) && !(sld & 3) && !((size_t)w & 15) && !((size_t)wt & 7) && (mode != 0 || !(Co & 3));
+    const bool vec = !(Ci & 3) && !(sld & 3) && !((size_t)w & (src16 ? 7 : 15)) && !((size_t)wt & 7) && (mode != 0 || !(Co & 3));
     if (vec) {
         const int q = threadIdx.x & 15, rq = threadIdx.x >> 4;          // 16 quads per row, 16 rows per pass
         for (int r = rq; r < TS; r += 16) {
             const int co = co0 + r, ci = ci0 + q * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < Co && ci < Ci) v = *(const float4*)(w + ((size_t)co * T + tap) * sld + ci);
+            if (co < Co && ci < Ci) {
+                if (src16) {
+                    const uint2 h = *(const uint2*)(wh + ((size_t)co * T + tap) * sld + ci);
+                    v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u),
+                                    __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+                } else {
+                    v = *(const float4*)(w + ((size_t)co * T + tap) * sld + ci);
+                }
+            }
             tile[r][q * 4 + 0] = v.x; tile[r][q * 4 + 1] = v.y; tile[r][q * 4 + 2] = v.z; tile[r][q * 4 + 3] = v.w;
         }
         __syncthreads();
@@ -205,7 +216,8 @@ __global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const lon
     constexpr int RS = 256 / TS;            // rows per pass
     for (int r = ty; r < TS; r += RS) {
         int co = co0 + r, ci = ci0 + tx;
-        tile[r][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + tap) * sld + ci] : 0.f;
+        const size_t si = ((size_t)co * T + tap) * sld + ci;
+        tile[r][tx] = (co < Co && ci < Ci) ? (src16 ? bf2f(wh[si]) : w[si]) : 0.f;
     }
     __syncthreads();
     if (mode == 0) {

@@ -417,7 +417,7 @@ class Deeplabv2(nn.Module):
         for c in self.convs.values():
             if c.wtb is not None:
                 T = c.k * c.k
-                rows.append([c.w.data_ptr(), c.wtb.data_ptr(), c.co, T, c.ci, blk, c.ci, 0])
+                rows.append([self._mirror_ptr(c.w.data_ptr()), c.wtb.data_ptr(), c.co, T, c.ci, blk, c.ci, 0 | 16])
                 blk += _layout_blocks(c.co, c.ci, T)
         self._wt_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._wt_blocks = blk
@@ -462,17 +462,18 @@ class Deeplabv2(nn.Module):
         def table(kinds):
             rows, blk = [], 0
             for head, hw in self.head_w.items():
-                wsrc = self.convs[f'{head}.conv_last.0'].w          # fp32 master, [512][9][4096]
+                # source: the bf16 mirror of the master [512][9][4096] (mode bit 4; same rounding, half the bytes)
+                wsrc = self._mirror_ptr(self.convs[f'{head}.conv_last.0'].w.data_ptr())
                 if 'fwd' in kinds:
-                    rows.append([wsrc.data_ptr(), hw['wfeat'].data_ptr(), 512, 9, 2048, blk, 4096, 2])
+                    rows.append([wsrc, hw['wfeat'].data_ptr(), 512, 9, 2048, blk, 4096, 2 | 16])
                     blk += _layout_blocks(512, 2048, 9)
                 for i in range(len(POOL_SCALES)):
-                    src = wsrc.data_ptr() + 4 * (2048 + 512 * i)
+                    src = wsrc + 2 * (2048 + 512 * i)
                     if 'fwd' in kinds:
-                        rows.append([src, hw['wz'][i].data_ptr(), 512, 9, 512, blk, 4096, 1])
+                        rows.append([src, hw['wz'][i].data_ptr(), 512, 9, 512, blk, 4096, 1 | 16])
                         blk += _layout_blocks(512, 512, 9)
                     if 'bwd' in kinds:
-                        rows.append([src, hw['wzt'][i].data_ptr(), 512, 9, 512, blk, 4096, 0])
+                        rows.append([src, hw['wzt'][i].data_ptr(), 512, 9, 512, blk, 4096, 0 | 16])
                         blk += _layout_blocks(512, 512, 9)
             return torch.tensor(rows, dtype=torch.int64, device=dev), blk
         self._hw_fwd_table, self._hw_fwd_blocks = table(('fwd',))
@@ -493,7 +494,7 @@ class Deeplabv2(nn.Module):
                            for i in range(len(ASPP_DILATIONS))]
         rows, blk = [], 0
         for j, c in enumerate(self.aspp_convs):          # mode 2: fp32 master slice -> bf16, same layout
-            rows.append([c.w.data_ptr(), self.aspp_wz.data_ptr() + 2 * j * C * 9 * 2048, C, 9, 2048, blk, 2048, 2])
+            rows.append([self._mirror_ptr(c.w.data_ptr()), self.aspp_wz.data_ptr() + 2 * j * C * 9 * 2048, C, 9, 2048, blk, 2048, 2 | 16])
             blk += _layout_blocks(C, 2048, 9)
         self._hw_fwd_table, self._hw_fwd_blocks = torch.tensor(rows, dtype=torch.int64, device=dev), blk
 
@@ -522,8 +523,12 @@ class Deeplabv2(nn.Module):
             for b in self.bns.values():
                 b.rv.fill_(1.0)
 
+    def _mirror_ptr(self, master_ptr):
+        """Address in the bf16 mirror (flat_pb) of the element that lives at `master_ptr` in the fp32 master (flat_p)."""
+        return self.flat_pb.data_ptr() + (master_ptr - self.flat_p.data_ptr()) // 2
+
     def sync_weights(self):
-        """Refresh the bf16 mirror and the transposed copies from the fp32 master weights."""
+        """Refresh the bf16 mirror and, from it, the transposed copies."""
         ops.cast_bf16(self.flat_p, self.flat_pb)
         self.sync_derived_weights()
         self._synced_version = self.flat_p._version

@@ -107,3 +107,24 @@ def test_pseudo_label_masks_are_reproducible_on_resnet101_with_offline_soft_labe
     assert_identical(r1, r2, 'resnet101 eager vs eager')
     hard = r1[0][-1]['hard']
     assert hard.shape == (2, 128, 128) and hard.min().item() >= -1 and hard.max().item() < 6
+
+
+def test_full_size_config1_steps_are_bit_identical():
+    """BASELINE config[1] at full size (ResNet-101, 8 + 8 images of 512 x 512, online EMA teacher, three streams): two
+    runs of two steps, eager and recorded, give the same bits.  At this size the weight gradients of the stem and of
+    layer 1 split K hundreds of ways (two-level combine), every convolution tile shape is in play and the step runs as it
+    does in bench.py."""
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet101'
+    sd = omodel.init_state_dict(rt, 6, seed=15)
+    for k in ('layer5.conv_last.4.weight', 'layer6.conv_last.4.weight'):
+        sd[k] = sd[k] * 40.0                       # confident classifiers: pseudo labels pass the thresholds (as in bench.py)
+    b = make_batch(b=8, size=512, seed=51, with_soft=False)
+    seq, lrs = [b, b], [1e-3, 1e-3]
+    r1 = run_steps(rt, sd, seq, lrs, ema=0.999)
+    r2 = run_steps(rt, sd, seq, lrs, ema=0.999)
+    assert_identical(r1, r2, 'full size, eager vs eager')
+    r3 = run_steps(rt, sd, seq, lrs, ema=0.999, plan_from=1)
+    assert_identical(r1, r3, 'full size, eager vs recorded plan')
+    labelled = (r1[0][-1]['hard'] >= 0).float().mean().item()
+    assert 0.05 < labelled < 1.0, labelled

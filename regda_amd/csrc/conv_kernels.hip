@@ -492,6 +492,152 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / "same" convolutions with a long K on 32-wide maps (the heads' 2048 -> 512, layer 4's 512 -> 512 with
+// dilation 1 / 2; forward and data gradient): 128 x 256 tiles like conv_igemm_kernel<128, 256, ...>, but the pixel operand
+// is loaded ONCE per 64-channel slab as the tile's halo -- (8 + 2 D) x (32 + 2 D) pixels -- and the nine taps read it at
+// nine shifted row offsets.  Per slab a workgroup pulls 9 x 16 KB of weights + one 43.5 KB halo (54 KB for D = 2) instead
+// of 9 x 48 KB: these launches are bound by the L2 -> LDS stream (with the pixel pieces made out-of-range, i.e. no
+// traffic, the head convolution runs 339 -> 248 us; section 4.4), so they get the bytes they no longer move back.
+//   LDS: two halo buffers (slab s + 1 lands while slab s is multiplied; its pieces are issued one per tap step) + a
+//   3-stage ring of weight tiles = 144 KB (D = 1) / 160 KB (D = 2); one barrier per tap step; the counted vmcnt wait
+//   lets exactly the pieces of the previous step stay in flight.
+template <int D>
+__global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BC = 128, BP = 256, WC = 2, WP = 4, NW = 8, FI = 2, FJ = 2;
+    constexpr int TR = 8, TC = 32;                          // pixel tile: 8 image rows x the 32 columns of the map
+    constexpr int HR = TR + 2 * D, HC = TC + 2 * D, NH = HR * HC;
+    constexpr int PXW = (NH + 63) / 64;                     // halo pieces (8 rows of 128 B) per wave and slab
+    constexpr int XS = PXW * 64 * 128, WS = BC * 128;       // bytes of a halo buffer / a weight stage
+    constexpr int CSTR = BC * 2 + 16, EPI = BP * CSTR + NW * BC * 2 * 4;
+    constexpr int SMEM = 2 * XS + 3 * WS;
+    static_assert(EPI <= SMEM && SMEM <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM];
+    unsigned char* const sxb = smem;
+    unsigned char* const swb = smem + 2 * XS;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WC, wp = wave / WC;
+    const int lrow = lane & 31, lk = lane >> 5, lrow8 = lane >> 3, lslot = lane & 7;
+    const int logical = xcd_remap(blockIdx.x, a.tiles_c * a.tiles_p);
+    const int c0 = (logical % a.tiles_c) * BC;
+    const int pt = logical / a.tiles_c, tpi = a.H / TR;
+    const int n = pt / tpi, y0 = (pt % tpi) * TR;
+    const int m0 = pt * BP;
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (int)((size_t)a.Cout * 9 * a.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2), 0x00020000);
+    int wvo[2], hvo[PXW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (i * NW + wave) * 8 + lrow8, co = c0 + r;
+        wvo[i] = (co < a.Cout) ? (co * 9 * a.Cin * 2 + (lslot ^ ((r >> 1) & 7)) * 16) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) {
+        const int h = (i * NW + wave) * 8 + lrow8;
+        const int y = y0 - D + h / HC, x = h % HC - D;
+        const bool ok = h < NH && y >= 0 && y < a.H && x >= 0 && x < TC;
+        hvo[i] = ok ? (((n * a.H + y) * TC + x) * a.ldx * 2 + (lslot ^ ((h >> 1) & 7)) * 16) : OOB;
+    }
+    auto issue_w = [&](int q, int stage) {
+        const int tap = q % 9, sl = q / 9;
+        const int so = (tap * a.Cin + sl * 64) * 2;
+        unsigned char* wb = swb + stage * WS + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * NW * 1024), 16, wvo[i], so, 0, 0);
+    };
+    auto issue_h = [&](int sl, int i) {
+        unsigned char* xb = sxb + (sl & 1) * XS + wave * 1024 + i * NW * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(xb), 16, hvo[i], sl * 128, 0, 0);
+    };
+
+    f32x16 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int S = a.Cin >> 6, KT = 9 * S;
+    int hb[FJ];                                             // halo row of this lane's pixel (tap 0,0) per pixel block
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) hb[j] = (wp * 2 + j) * HC + lrow;
+    int wr[FI];                                             // weight-tile row byte offset and its swizzle key
+#pragma unroll
+    for (int i = 0; i < FI; ++i) wr[i] = wc * 64 + i * 32 + lrow;
+    // one half (two of the four 16-wide K slices) of a tap step's fragments
+    auto read_half = [&](const unsigned char* wb, const unsigned char* xb, int tp, int half, bf16x8 (&fa)[2][FI],
+                         bf16x8 (&fb)[2][FJ]) {
+        const int kh = tp / 3, kw = tp % 3;
+        const int toff = (a.mode ? (2 - kh) : kh) * D * HC + (a.mode ? (2 - kw) : kw) * D;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int kk = half * 2 + k2;
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+                fa[k2][i] = *(const bf16x8*)(wb + wr[i] * 128 + (((kk * 2 + lk) ^ ((wr[i] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const int hr = hb[j] + toff;                // (the compiler hoists the nine taps' addresses out of the
+                                                            // slab loop: ~190 registers, no spill; recomputing them per
+                                                            // tap measured 5 % slower)
+                fb[k2][j] = *(const bf16x8*)(xb + hr * 128 + (((kk * 2 + lk) ^ ((hr >> 1) & 7)) << 4));
+            }
+        }
+    };
+    auto mfma_half = [&](bf16x8 (&fa)[2][FI], bf16x8 (&fb)[2][FJ]) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k2][i], fb[k2][j], acc[i][j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) issue_h(0, i);
+    issue_w(0, 0);
+    issue_w(1, 1);
+    int pend = 2, wstage = 0;
+    bf16x8 fa0[2][FI], fb0[2][FJ], fa1[2][FI], fb1[2][FJ];
+    for (int sl = 0; sl < S; ++sl) {
+        const bool more = sl + 1 < S;
+        const unsigned char* xb = sxb + (sl & 1) * XS;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int q = sl * 9 + tp;
+            switch (pend) {
+                case 0: WAIT_VMCNT(0); break;
+                case 1: WAIT_VMCNT(1); break;
+                case 2: WAIT_VMCNT(2); break;
+                default: WAIT_VMCNT(3); break;
+            }
+            __builtin_amdgcn_s_barrier();
+            pend = 0;
+            if (q + 2 < KT) { issue_w(q + 2, wstage >= 1 ? wstage - 1 : 2); pend += 2; }
+            if (more && tp < PXW) { issue_h(sl + 1, tp); pend += 1; }
+            const unsigned char* wb = swb + wstage * WS;
+            read_half(wb, xb, tp, 0, fa0, fb0);
+            read_half(wb, xb, tp, 1, fa1, fb1);
+            mfma_half(fa0, fb0);
+            mfma_half(fa1, fb1);
+            wstage = (wstage == 2) ? 0 : wstage + 1;
+        }
+    }
+    __syncthreads();
+    float s[8], q8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q8[e] = 0.f; }
+    conv_epilogue<BC, BP, WC, WP>(a, acc, smem, m0, c0, s, q8, true, blockIdx.x & (NREP - 1));
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // layer1's 3x3 convolutions: 64 -> 64 channels, stride 1, on 128-wide maps (forward, data gradient, teacher).
 // With K = 576 and a 64 x 64 tile the implicit-GEMM kernel above spends its time loading operands: 4096 workgroups
 // each pull all 72 KB of weights plus nine shifted copies of their pixels from L2 (600 MB into LDS for 67 MB of
@@ -608,6 +754,19 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
 // byte, 8 waves); large-M layers run 128 x 128 tiles with 8 waves and a 2-stage ring (64 KiB: two workgroups =
 // 16 waves per CU); everything else 128 x 64 tiles with 4 waves, two workgroups per CU.  `stages` 82 / 83 mean
 // 8-wave workgroups with 2 / 3 stages.  rows_per_group != 0: a tile may not straddle two statistics groups.
+// the cases conv3x3_halo_kernel serves: 3x3 / stride 1 / pad = dilation 1 or 2 on 32-wide maps whose height is a multiple
+// of 8, long K (where the 128 x 256 tile would be picked), enough tiles to fill the chip, tiles inside one statistics group
+static bool conv_use_halo(long long M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho,
+                          int Wo, int rows_per_group) {
+    if (const char* e = TUNE_ENV("RGDA_HALO")) { if (!atoi(e)) return false; }           // tuning experiments only
+    if (kh != 3 || kw != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return false;
+    if (W != 32 || Wo != 32 || Ho != H || (H & 7)) return false;
+    if ((long long)9 * Cin < 4096 || (Cin & 63)) return false;
+    if ((M / 256) * cdiv(Cout, 128) < 240) return false;
+    if (rows_per_group % 256) return false;
+    return true;
+}
+
 static int pick_tile(long long M, int Cout, long long ktot, int rows_per_group, int& bc, int& bp, int& stages) {
     bc = (Cout <= 64) ? 64 : 128;
     bp = 64;
@@ -699,6 +858,16 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
                 return RGDA_OK;
             }
         }
+    }
+    // long-K 3x3 convolutions on 32-wide maps (heads, layer 4): the halo kernel (tiles of 8 image rows = 256 pixels)
+    if (conv_use_halo(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, a.rows_per_group)) {
+        a.tiles_c = cdiv(Cout, 128);
+        a.tiles_p = (int)(M / 256);
+        const int grid = a.tiles_c * a.tiles_p;
+        if (dil == 1) conv3x3_halo_kernel<1><<<grid, 512, 0, st>>>(a);
+        else conv3x3_halo_kernel<2><<<grid, 512, 0, st>>>(a);
+        RGDA_CHECK_LAUNCH();
+        return RGDA_OK;
     }
     int bc, bp, stages;
     if (pick_tile(M, Cout, (long long)kh * kw * Cin, (stats && stat_groups > 1) ? a.rows_per_group : 0, bc, bp, stages))

@@ -49,6 +49,11 @@ CASES = [
     (16, 32, 32, 128, 512, 3, 1, 1, 1),
     (8, 32, 32, 128, 512, 3, 1, 2, 2),
     (7, 16, 32, 192, 1024, 3, 1, 1, 1),
+    # long-K 3x3 on 32-wide maps (layer 4 / the heads at reduced size): the halo kernel, dilation 1 and 2, forward and data
+    # gradient; 5 tiles per image + ragged Cout (forward only)
+    (16, 32, 32, 512, 512, 3, 1, 1, 1),
+    (16, 32, 32, 512, 512, 3, 1, 2, 2),
+    (8, 40, 32, 512, 1032, 3, 1, 2, 2),
     # layer1 geometry (64 -> 64 on 128-wide maps): the weights-resident rolling-window kernel, 2 and 5 rows per workgroup
     (4, 128, 128, 64, 64, 3, 1, 1, 1),
     (10, 128, 128, 64, 64, 3, 1, 1, 1),

@@ -90,6 +90,160 @@ static __device__ __forceinline__ void src_coord(int mode, int base, int t, int 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// ---- the row pass of the epilogue: bf16 C tile [pixel][cout] in LDS -> 16-byte row pieces in memory, one variant per
+// fused epilogue.  Every thread owns one 8-channel vector of BP / RPP rows; the LDS reads and the global loads of up to
+// four rows are issued together (the pass is latency- and instruction-bound: ~40 % of a small-K 1x1 workgroup's life
+// went here when it was one generic loop with a load -> wait -> store chain per row), the arithmetic is two-wide
+// (v_pk_*_f32) on bf16 pairs unpacked with a shift / a mask.
+enum { EPI_PLAIN = 0, EPI_STATS, EPI_RES, EPI_RES_STATS, EPI_EV, EPI_BNX };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f32x2 bf2f_pair(unsigned u) {
+    f32x2 r;
+    r.x = __uint_as_float(u << 16);
+    r.y = __uint_as_float(u & 0xffff0000u);
+    return r;
+}
+static __device__ __forceinline__ unsigned pack2bf(f32x2 v) { return pack2bf(v.x, v.y); }
+
+template <int BC, int BP, int NT, int KIND>
+static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const unsigned char* smem, int m0, int c0,
+                                                     float (&s)[8], float (&q)[8]) {
+    constexpr int CSTR = BC * 2 + 16;
+    constexpr int VPR = BC / 8, RPP = NT / VPR, NIT = BP / RPP;
+    constexpr int CH = NIT < 4 ? NIT : 4;                  // rows in flight per thread
+    static_assert(NIT % CH == 0, "row passes");
+    const int t = threadIdx.x;
+    const int cv = t % VPR, rr = t / VPR;
+    const int co = c0 + cv * 8;
+    const bool cok = co < a.Cout;
+    f32x2 k0[4], k1[4];                                     // EV: scale, shift;  BNX: invstd, mean
+    f32x2 s2[4], q2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        k0[e] = f32x2{0.f, 0.f}; k1[e] = f32x2{0.f, 0.f};
+        s2[e] = f32x2{s[2 * e], s[2 * e + 1]}; q2[e] = f32x2{q[2 * e], q[2 * e + 1]};
+    }
+    if (KIND == EPI_BNX && cok) {
+        const float* mi = a.bn_mi + (size_t)(m0 / a.rows_per_group) * 2 * a.Cout + co;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            k1[e] = f32x2{mi[2 * e], mi[2 * e + 1]};
+            k0[e] = f32x2{mi[a.Cout + 2 * e], mi[a.Cout + 2 * e + 1]};
+        }
+    }
+    if (KIND == EPI_EV && cok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sc = a.ev_gamma[co + e] / sqrtf(a.ev_rv[co + e] + a.ev_eps);
+            k0[e >> 1][e & 1] = sc;
+            k1[e >> 1][e & 1] = a.ev_beta[co + e] - a.ev_rm[co + e] * sc;
+        }
+    }
+    const bool has_res = (KIND == EPI_RES || KIND == EPI_RES_STATS) || ((KIND == EPI_EV || KIND == EPI_BNX) && a.res);
+    const bool res_gate = (KIND != EPI_EV) && has_res && a.res_mask;
+    constexpr bool STATS = KIND == EPI_STATS || KIND == EPI_RES_STATS;
+#pragma unroll
+    for (int p0 = 0; p0 < NIT; p0 += CH) {
+        uint4 val[CH], rv[CH], xv[CH], yv[CH];
+        unsigned rmb[CH], bmb[CH];
+        bool ok[CH];
+        // ---- everything this chunk reads, issued back to back
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int row = rr + (p0 + i) * RPP;
+            const int m = m0 + row;
+            ok[i] = cok && m < a.M;
+            val[i] = *(const uint4*)(smem + row * CSTR + cv * 16);
+            rv[i] = uint4{0u, 0u, 0u, 0u}; xv[i] = rv[i]; yv[i] = rv[i]; rmb[i] = 0xffu; bmb[i] = 0xffu;
+            if (ok[i]) {
+                if (has_res) {
+                    rv[i] = *(const uint4*)(a.res + (size_t)m * a.ldres + co);
+                    if (res_gate) rmb[i] = a.res_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
+                }
+                if (KIND == EPI_BNX) {
+                    xv[i] = *(const uint4*)(a.bn_x + (size_t)m * a.bn_ldx + co);
+                    if (a.bn_relu) {
+                        if (a.bn_mask) bmb[i] = a.bn_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
+                        else yv[i] = *(const uint4*)(a.bn_y + (size_t)m * a.bn_ldy + co);
+                    }
+                }
+            }
+        }
+        // ---- arithmetic + the row store
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int m = m0 + rr + (p0 + i) * RPP;
+            const unsigned vw[4] = {val[i].x, val[i].y, val[i].z, val[i].w};
+            const unsigned rw[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+            unsigned ow[4];
+            if (KIND == EPI_PLAIN || KIND == EPI_STATS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ow[e] = vw[e];
+            } else if (KIND == EPI_EV) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x2 f = bf2f_pair(vw[e]) * k0[e] + k1[e];
+                    if (has_res) f += bf2f_pair(rw[e]);
+                    if (a.ev_relu) { f.x = fmaxf(f.x, 0.f); f.y = fmaxf(f.y, 0.f); }
+                    ow[e] = pack2bf(f);
+                }
+            } else {                                        // residual (gated by the ReLU mask of the layer it crossed)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned r = rw[e];
+                    if (res_gate) {
+                        const unsigned b0 = (rmb[i] >> (2 * e)) & 1u, b1 = (rmb[i] >> (2 * e + 1)) & 1u;
+                        r &= (b0 ? 0x0000ffffu : 0u) | (b1 ? 0xffff0000u : 0u);
+                    }
+                    ow[e] = has_res ? pack2bf(bf2f_pair(vw[e]) + bf2f_pair(r)) : vw[e];
+                }
+            }
+            if (ok[i]) {
+                if (STATS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2 f = bf2f_pair(ow[e]);
+                        s2[e] += f;
+                        q2[e] += f * f;
+                    }
+                }
+                if (KIND == EPI_BNX) {
+                    const unsigned xw[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+                    const unsigned yw[4] = {yv[i].x, yv[i].y, yv[i].z, yv[i].w};
+                    f32x2 ns[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ns[e] = f32x2{1.f, 1.f};
+                    if (a.bn_nscale) {
+                        const float* np = a.bn_nscale + (size_t)(m / a.bn_rpi) * a.Cout + co;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ns[e] = f32x2{np[2 * e], np[2 * e + 1]};
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f32x2 g = bf2f_pair(ow[e]);
+                        if (a.bn_relu) {
+                            if (a.bn_mask) {
+                                g.x = ((bmb[i] >> (2 * e)) & 1u) ? g.x : 0.f;
+                                g.y = ((bmb[i] >> (2 * e + 1)) & 1u) ? g.y : 0.f;
+                            } else {
+                                const f32x2 yy = bf2f_pair(yw[e]);
+                                g.x = (yy.x > 0.f) ? g.x : 0.f;
+                                g.y = (yy.y > 0.f) ? g.y : 0.f;
+                            }
+                        }
+                        if (a.bn_nscale) g *= ns[e];
+                        s2[e] += g;
+                        q2[e] += g * ((bf2f_pair(xw[e]) - k1[e]) * k0[e]);
+                    }
+                }
+                if (!(TSKIP(a) & 128)) *(uint4*)(a.y + (size_t)m * a.ldy + co) = uint4{ow[0], ow[1], ow[2], ow[3]};
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[2 * e] = s2[e].x; s[2 * e + 1] = s2[e].y; q[2 * e] = q2[e].x; q[2 * e + 1] = q2[e].y; }
+}
+
 // ---- epilogue shared by the convolution kernels: accumulators -> bf16 C tile [pixel][cout] in LDS (`smem`, BP * CSTR
 // bytes + the reduction scratch behind it) -> 16-byte rows to memory, with the fused residual / inference BatchNorm /
 // BatchNorm statistics / BatchNorm-backward sums.  s, q: the per-channel sums of this thread's channel vector,
@@ -123,95 +277,15 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
     __syncthreads();
     if (TDBG(a) && t == 0) TDBG(a)[(16384 + blockIdx.x) * 4 + 0] = __builtin_readcyclecounter();
     constexpr int VPR = BC / 8;              // 16-byte vectors per C row
-    constexpr int RPP = NT / VPR;            // rows per pass
-    const int cv = t % VPR, rr = t / VPR;
-    const int co = c0 + cv * 8;
-    const bool cok = co < a.Cout;
-    float bmean[8], bistd[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { bmean[e] = 0.f; bistd[e] = 0.f; }
-    if (a.bn_x && cok) {
-        const float* mi = a.bn_mi + (size_t)(m0 / a.rows_per_group) * 2 * a.Cout;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { bmean[e] = mi[co + e]; bistd[e] = mi[a.Cout + co + e]; }
-    }
-    if (a.ev_rm && cok) {       // reuse the two register arrays: bistd = scale, bmean = shift
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float sc = a.ev_gamma[co + e] / sqrtf(a.ev_rv[co + e] + a.ev_eps);
-            bistd[e] = sc;
-            bmean[e] = a.ev_beta[co + e] - a.ev_rm[co + e] * sc;
-        }
-    }
-#pragma unroll 2
-    for (int p = 0; p < BP / RPP; ++p) {
-        int row = rr + p * RPP;
-        int m = m0 + row;
-        if (m < a.M && cok) {
-            u16x8 val = *(const u16x8*)(smem + row * CSTR + cv * 16);
-            if (a.ev_rm) {
-                float f[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = bf2f(val[e]) * bistd[e] + bmean[e];
-                if (a.res) {
-                    u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += bf2f(rv[e]);
-                }
-                if (a.ev_relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    unsigned pk = pack2bf(f[e], f[e + 1]);
-                    val[e] = (bf16_t)(pk & 0xffffu);
-                    val[e + 1] = (bf16_t)(pk >> 16);
-                }
-            } else if (a.res) {
-                u16x8 rv = *(const u16x8*)(a.res + (size_t)m * a.ldres + co);
-                if (a.res_mask) {       // residual = upstream gradient gated by the ReLU of the layer it passed through
-                    const unsigned mb = a.res_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rv[e] = ((mb >> e) & 1u) ? rv[e] : (bf16_t)0;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    unsigned pk = pack2bf(bf2f(val[e]) + bf2f(rv[e]), bf2f(val[e + 1]) + bf2f(rv[e + 1]));
-                    val[e] = (bf16_t)(pk & 0xffffu);
-                    val[e + 1] = (bf16_t)(pk >> 16);
-                }
-            }
-            if (a.bn_x) {
-                u16x8 xv = *(const u16x8*)(a.bn_x + (size_t)m * a.bn_ldx + co);
-                float gf[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gf[e] = bf2f(val[e]);
-                if (a.bn_relu) {
-                    if (a.bn_mask) {
-                        const unsigned mb = a.bn_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) gf[e] = ((mb >> e) & 1u) ? gf[e] : 0.f;
-                    } else {
-                        u16x8 yv = *(const u16x8*)(a.bn_y + (size_t)m * a.bn_ldy + co);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) gf[e] = (bf2f(yv[e]) > 0.f) ? gf[e] : 0.f;
-                    }
-                }
-                if (a.bn_nscale) {
-                    const float* ns = a.bn_nscale + (size_t)(m / a.bn_rpi) * a.Cout + co;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) gf[e] *= ns[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { s[e] += gf[e]; q[e] += gf[e] * ((bf2f(xv[e]) - bmean[e]) * bistd[e]); }
-            } else if (a.stats) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { float f = bf2f(val[e]); s[e] += f; q[e] += f * f; }
-            }
-            *(u16x8*)(a.y + (size_t)m * a.ldy + co) = val;
-        }
-    }
+    const int cv = t % VPR;
+    // the row pass, specialised per fused variant (uniform branches; each variant is one straight block)
+    if (a.ev_rm) epilogue_rows<BC, BP, NT, EPI_EV>(a, smem, m0, c0, s, q);
+    else if (a.bn_x) epilogue_rows<BC, BP, NT, EPI_BNX>(a, smem, m0, c0, s, q);
+    else if (a.res) {
+        if (a.stats) epilogue_rows<BC, BP, NT, EPI_RES_STATS>(a, smem, m0, c0, s, q);
+        else epilogue_rows<BC, BP, NT, EPI_RES>(a, smem, m0, c0, s, q);
+    } else if (a.stats) epilogue_rows<BC, BP, NT, EPI_STATS>(a, smem, m0, c0, s, q);
+    else epilogue_rows<BC, BP, NT, EPI_PLAIN>(a, smem, m0, c0, s, q);
     if (TDBG(a) && t == 0) TDBG(a)[(16384 + blockIdx.x) * 4 + 1] = __builtin_readcyclecounter();
     if (a.stats && flush) {
         // lanes with equal cv inside a wave: strides VPR, 2*VPR, ... < 64

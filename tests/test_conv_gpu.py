@@ -680,6 +680,10 @@ STREAM = [  # N, H, W, Cin, Cout
     (8, 128, 128, 256, 64),        # layer1 conv1: BC = 64, four K slabs
     (4, 64, 64, 128, 1024),        # eight channel tiles, two K slabs
     (6, 128, 128, 64, 128),        # tiles_p = 768: uneven tiles per workgroup
+    # conv1x1_resident_kernel (pixel operand resident in LDS, epilogue under the next channel tile's K loop):
+    (16, 32, 32, 256, 1024),       # layer3 conv3 / conv1's data gradient: four K tiles, 2 x 4 channel tiles per pixel tile
+    (16, 64, 64, 128, 512),        # layer2: two K tiles, one workgroup per pixel tile
+    (8, 32, 32, 256, 1024),        # the teacher's batch: two channel tiles per workgroup
 ]
 
 
@@ -715,11 +719,14 @@ def test_large_1x1_conv_plain_residual_and_statistics(ops, N, H, W, Ci, Co):
     assert float(ybig[:, Co:].abs().max()) == 0.0
 
 
-def test_large_1x1_conv_fused_bn_backward_sums_and_masks(ops):
-    """The data-gradient form at layer1 size: residual gated by a sign mask + the consumer BatchNorm's backward sums,
-    against the unfused kernels (rgda_bn_bwd_reduce on the stored gradient)."""
+@pytest.mark.parametrize('N,H,W,Cb,Cf,use_mask', [(4, 128, 128, 64, 256, False), (16, 32, 32, 256, 1024, False),
+                                                  (16, 32, 32, 256, 1024, True), (16, 64, 64, 128, 512, True)])
+def test_large_1x1_conv_fused_bn_backward_sums_and_masks(ops, N, H, W, Cb, Cf, use_mask):
+    """The data-gradient form at layer1 / layer3 / layer2 size (the latter two: conv1x1_resident_kernel): residual gated by
+    a sign mask + the consumer BatchNorm's backward sums (ReLU from y or from its sign mask), against the unfused kernels
+    (rgda_bn_bwd_reduce on the stored gradient)."""
     g = torch.Generator().manual_seed(77)
-    N, H, W, Cb, Cf, groups = 4, 128, 128, 64, 256, 2          # forward conv Cf -> Cb (1x1); its data gradient Cb -> Cf
+    groups = 2                                                 # forward conv Cf -> Cb (1x1); its data gradient Cb -> Cf
     M = N * H * W
     dy = torch.randn(M, Cb, generator=g).to(BF).cuda()
     wt = (torch.randn(Cf, 1, Cb, generator=g) * 0.1).to(BF).cuda()
@@ -731,7 +738,9 @@ def test_large_1x1_conv_fused_bn_backward_sums_and_masks(ops):
     mi = torch.stack([torch.randn(groups, Cf, generator=g) * 0.1, torch.rand(groups, Cf, generator=g) + 0.5], 1).cuda().contiguous()
     dx = torch.empty(M, Cf, dtype=BF, device='cuda')
     sums = ops.new_stats(groups, 8, 2, Cf)
-    ops.conv2d_bnbwd(dy, wt, dx, N, H, W, H, W, 1, 1, 1, 0, 1, 1, res, sums, groups, cy, cx, mi, True, res_mask=rmask)
+    ymask = ((cy > 0).reshape(M, Cf // 8, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8, device='cuda')).sum(-1).to(torch.uint8)
+    ops.conv2d_bnbwd(dy, wt, dx, N, H, W, H, W, 1, 1, 1, 0, 1, 1, res, sums, groups, None if use_mask else cy, cx, mi, True,
+                     res_mask=rmask, relu_mask=ymask if use_mask else None)
     gated = torch.where(keep.cuda(), res, torch.zeros_like(res))
     ref = dy.float() @ wt.float().view(Cf, Cb).t() + gated.float()
     assert relerr(dx.float().cpu(), ref.cpu()) < 8e-3
@@ -741,10 +750,10 @@ def test_large_1x1_conv_fused_bn_backward_sums_and_masks(ops):
                                ops.stats_value(want, backward=True).sum(1).float().cpu(), rtol=2e-4, atol=0.5)
 
 
-def test_large_1x1_conv_inference_batchnorm(ops):
-    """The EMA teacher's unit at layer1 size: conv + eval-mode BN + residual + ReLU in one kernel."""
+@pytest.mark.parametrize('N,H,W,Ci,Co', [(4, 128, 128, 64, 256), (8, 32, 32, 256, 1024), (8, 64, 64, 128, 512)])
+def test_large_1x1_conv_inference_batchnorm(ops, N, H, W, Ci, Co):
+    """The EMA teacher's unit at layer1 / layer3 / layer2 size: conv + eval-mode BN + residual + ReLU in one kernel."""
     g = torch.Generator().manual_seed(78)
-    N, H, W, Ci, Co = 4, 128, 128, 64, 256
     M = N * H * W
     x = torch.randn(M, Ci, generator=g).to(BF).cuda()
     w = (torch.randn(Co, 1, Ci, generator=g) * 0.1).to(BF).cuda()

@@ -160,6 +160,15 @@ def conv_flops_probe(step_fn, park_ms=150.0):
     c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     c0.record(); torch.cuda._sleep(1_000_000); c1.record(); torch.cuda.synchronize()
     cycles_per_ms = 1_000_000 / max(c0.elapsed_time(c1), 1e-3)
+    # An event pair also brackets the two event packets themselves (a few microseconds on this runtime): measure that
+    # on empty brackets queued behind the same kind of park and take it out of every launch's bracket, so that the
+    # per-launch averages are kernel durations -- what `rocprofv3 --kernel-trace --stats` reports (profiles/).
+    torch.cuda._sleep(int(5 * cycles_per_ms))
+    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a0, a1 in empty:
+        a0.record(); a1.record()
+    torch.cuda.synchronize()
+    bracket_ms = sorted(a0.elapsed_time(a1) for a0, a1 in empty)[len(empty) // 2]
     try:
         torch.cuda._sleep(int(park_ms * cycles_per_ms))
         step_fn()
@@ -171,7 +180,7 @@ def conv_flops_probe(step_fn, park_ms=150.0):
     c3 = [0.0, 0.0]                                # FLOPs / ms of the 3x3 convolutions (forward, data and weight gradient)
     for r in rec:
         name, fl, e0, e1, shp, nl, by, fl3 = r     # nl = kernel launches inside the bracket, by = algorithmic bytes
-        dt = e0.elapsed_time(e1)
+        dt = max(e0.elapsed_time(e1) - bracket_ms, 1e-4)
         c3[0] += fl3; c3[1] += dt * fl3 / max(fl, 1.0)      # a mixed weight-gradient bucket is split by FLOPs
         k = kern.setdefault(name, [0.0, 0.0, 0, 0.0])
         k[0] += fl; k[1] += dt; k[2] += nl; k[3] += by
@@ -184,6 +193,7 @@ def conv_flops_probe(step_fn, park_ms=150.0):
     out = {k: dict(gflop=v[0] / 1e9, ms=v[1], launches=v[2], tflops=v[0] / 1e9 / max(v[1], 1e-9),
                    avg_us=v[1] / v[2] * 1e3, algorithmic_mb=v[3] / 1e6, gbps=v[3] / 1e6 / max(v[1], 1e-9))
            for k, v in kern.items()}
+    out['__bracket_us__'] = bracket_ms * 1e3
     out['__conv3x3__'] = dict(gflop=c3[0] / 1e9, ms=c3[1], tflops=c3[0] / 1e9 / max(c3[1], 1e-9))
     return out
 
@@ -474,6 +484,7 @@ def main():
         side, step.wgrad_stream = step.wgrad_stream, None     # ... and one stream, so a launch's events bracket only itself
         kern = conv_flops_probe(one)
         c3 = kern.pop('__conv3x3__')
+        bracket_us = kern.pop('__bracket_us__')
         step.wgrad_stream = side
         # the dominant kernel = the conv instantiation with the most GPU time in the step
         dom = max(kern, key=lambda k: kern[k]['ms'])
@@ -497,6 +508,7 @@ def main():
                            'flop_per_byte': intensity, 'mfma_frac': d['tflops'] / MFMA_PEAK_TFLOPS,
                            'hbm_frac': d['gbps'] / HBM_PEAK_GBPS,
                            'launches_per_step': d['launches'], 'avg_launch_us': d['avg_us'],
+                           'event_bracket_us_subtracted': bracket_us,
                            'gflop_per_launch': d['gflop'] / d['launches'],
                            'algorithmic_mb_per_launch': d['algorithmic_mb'] / d['launches'],
                            'all_conv_kernels': {'achieved': gf / ms, 'frac': gf / ms / MFMA_PEAK_TFLOPS,

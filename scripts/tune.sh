@@ -96,7 +96,6 @@ profiles)
   # ---- the bench lines
   timeout 900 python bench.py --phases > gpurun_out/${tag}_bench_1gpu.json 2> gpurun_out/${tag}_bench_1gpu.err
   grep ' ms  ' gpurun_out/${tag}_bench_1gpu.err > gpurun_out/${tag}_step_phases.txt
-  python bench.py --no-h2d --no-cpu-baseline --no-roofline 2>/dev/null | grep '"metric"' > gpurun_out/${tag}_bench_resident_inputs.json
   { echo "box: $(hostname)  date: $(date -u +%FT%TZ)  commit: ${GRAFT_COMMIT:-see profiles/README.md}"; rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1; } > gpurun_out/${tag}_provenance.txt
   cut -c1-900 gpurun_out/${tag}_bench_1gpu.json; cat gpurun_out/${tag}_step_phases.txt ;;
 *)

@@ -335,6 +335,15 @@ int rgda_sgd_step(float* p, const float* g, float* v, float* shadow, void* p_bf1
                   float weight_decay, float max_norm, float gscale, float ema_decay,
                   int first_step, rgda_stream_t stream);
 
+/* The stem's weight gradient straight from the NCHW f32 image (no patch matrix): dw f32 [64][147], k = (kh*7+kw)*3+c,
+ * += sum_p dy[p][co] * bf16(patch(p)[k]) (the products rgda_stem_im2col + rgda_conv2d_wgrad form, summed in a fixed order:
+ * reproducible).  dy bf16 [N*Ho*Wo][lddy].  ws: rgda_stem_wgrad_workspace(N, H, W) bytes (0 = this geometry is not
+ * served), 16-byte aligned; calls that share it must be ordered on one stream.  Wo % 64 must be 0
+ * (RGDA_ERR_UNSUPPORTED otherwise).  Replaces the tail of regda/_resnets.py:150-151's backward. */
+size_t rgda_stem_wgrad_workspace(int N, int H, int W);
+int rgda_stem_wgrad(const float* img, const void* dy, int lddy, float* dw, void* ws, size_t ws_bytes, int N, int H,
+                    int W, int Ho, int Wo, rgda_stream_t stream);
+
 /* w [Co][T][Ci] f32 -> wt [Ci][T][Co] bf16 (weights for the data-gradient pass). */
 int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, rgda_stream_t stream);
 /* every derived bf16 weight layout of a model in one launch: device table[n][8] int64 = {src f32*, dst bf16*,

@@ -1147,6 +1147,189 @@ static int stem_conv_launch(const float* img, const void* wgt, void* y, int ldy,
     return RGDA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The stem's weight gradient straight from the image: dw[co][k] += sum_p dy[p][co] * patch(p)[k], k = (kh*7+kw)*3+c.
+// The patch-matrix route (rgda_stem_im2col + a 1x1 weight gradient) writes and re-reads 403 MB for 16 images of
+// 512 x 512 (186 + 184 us of kernel time per step) to feed 20 GFLOP.  Here a workgroup owns a 64-pixel column block of
+// `rpw` output rows of one image: per row it stages the image patch (as stem_conv_kernel does), builds the 64 x 192
+// patch tile in LDS -- [pixel][k] in the layout the transposing LDS reads of the weight-gradient kernels expect --, copies
+// the row's 64 x 64 gradient tile next to it and multiplies: dy^T (64 co x 64 pixels) x patch (64 pixels x 192) with
+// ds_read_b64_tr_b16 fragments for both operands, 12 MFMAs per wave (wave = 32 channels x 96 columns), accumulating over
+// its rows in registers.  Its partial [64][192] goes to the workspace; stem_wgrad_reduce_kernel adds the partials in
+// workgroup order (reproducible) into dw [64][147].
+__global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, int lddy,
+                                                         float* __restrict__ part, int H, int W, int Ho, int Wo, int rpw) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BP = 64, KP = 192;
+    constexpr int SW = 2 * BP + 5;
+    constexpr int PT = 3 * 64 * 128;                    // patch tile: [k tile of 64][64 pixels][128 B]
+    constexpr int DT = 64 * 128;                        // gradient tile: [64 pixels][64 channels]
+    constexpr int NP = (21 * SW + 255) / 256;
+    __shared__ __attribute__((aligned(256))) unsigned char smem[PT + DT + 3 * 7 * (SW + 1) * 2 + 64];
+    unsigned char* const sp = smem;
+    unsigned char* const sd = smem + PT;
+    bf16_t* const patch = (bf16_t*)(smem + PT + DT);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wi = wave & 1, wj = wave >> 1;             // 32 output channels x 96 patch columns per wave
+    const int wtiles = Wo / BP, rblocks = Ho / rpw;
+    const int wo0 = (blockIdx.x % wtiles) * BP;
+    const int ho0 = ((blockIdx.x / wtiles) % rblocks) * rpw, n = blockIdx.x / (wtiles * rblocks);
+
+    // patch-tile builder: thread = (column vector v of 8 k values, pixel lane), as in stem_conv_kernel
+    const int v = t % (KP / 8), pl = t / (KP / 8);
+    int off[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = v * 8 + e;
+        const int tap = k / 3, c = k % 3, kh = tap / 7, kw = tap % 7;
+        off[e] = (k < 147) ? (c * 7 + kh) * (SW + 1) + kw : -1;
+    }
+    float pv[NP];
+    int po[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = t + 256 * i, row = idx / SW, x = idx % SW;
+        const int c = row / 7, kh = row % 7;
+        const int wcol = wo0 * 2 - 3 + x;
+        po[i] = (idx < 21 * SW && wcol >= 0 && wcol < W) ? (((c * H + kh) * W + wcol) | (kh << 28)) : -1;
+    }
+    // gradient tile: thread = (pixel, 32-byte quarter of its 64 channels)
+    const int dpx = t >> 2, dq = t & 3;
+    uint4 dv0, dv1;
+    auto fetch = [&](int ho) {
+        const float* base = img + ((size_t)n * 3 * H + (ho * 2 - 3)) * W;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const unsigned hi = (unsigned)(ho * 2 - 3 + (po[i] >> 28));
+            pv[i] = (po[i] >= 0 && hi < (unsigned)H) ? base[po[i] & 0x0fffffff] : 0.f;
+        }
+        const bf16_t* dp = dy + ((size_t)(n * Ho + ho) * Wo + wo0 + dpx) * lddy + dq * 16;
+        dv0 = *(const uint4*)dp;
+        dv1 = *(const uint4*)(dp + 8);
+    };
+    // transposing-read lane geometry (conv_wgrad_kernel): 16-lane group g reads a [4 k][16 col] block
+    const int g = lane >> 4, la = lane & 15;
+    const int krow = (g >> 1) * 8 + (la >> 2);
+    const int kcol2 = ((g & 1) * 16 + (la & 3) * 4) * 2;
+    auto tr_pair = [&](const unsigned char* base, int byte, int r0) {      // 128-byte rows, 64-byte granules ^ ((row >> 1) & 1)
+        const int r1 = r0 + 4;
+        const unsigned char* p0 = base + r0 * 128 + ((((byte >> 6) ^ ((r0 >> 1) & 1)) << 6) | (byte & 63));
+        const unsigned char* p1 = base + r1 * 128 + ((((byte >> 6) ^ ((r1 >> 1) & 1)) << 6) | (byte & 63));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+        u16x8 v8 = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                    (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+        return __builtin_bit_cast(bf16x8, v8);
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    fetch(ho0);
+    for (int r = 0; r < rpw; ++r) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = t + 256 * i;
+            if (idx < 21 * SW) patch[(idx / SW) * (SW + 1) + idx % SW] = f2bf(pv[i]);
+        }
+        {
+            const int f = (dpx >> 1) & 1, s0 = dq * 2, s1 = dq * 2 + 1;
+            *(uint4*)(sd + dpx * 128 + ((((s0 >> 2) ^ f) << 6) | ((s0 & 3) << 4))) = dv0;
+            *(uint4*)(sd + dpx * 128 + ((((s1 >> 2) ^ f) << 6) | ((s1 & 3) << 4))) = dv1;
+        }
+        __syncthreads();                                // patch + gradient tile complete; the previous row's MFMAs are done
+        if (r + 1 < rpw) fetch(ho0 + r + 1);
+        if (pl < 256 / (KP / 8)) {
+            for (int px = pl; px < BP; px += 256 / (KP / 8)) {
+                u16x8 out;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) out[e] = (off[e] < 0) ? (bf16_t)0 : patch[off[e] + 2 * px];
+                const int sl = v & 7;
+                *(u16x8*)(sp + (v >> 3) * 8192 + px * 128 + ((((sl >> 2) ^ ((px >> 1) & 1)) << 6) | ((sl & 3) << 4))) = out;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int r0 = kk * 16 + krow;
+            const bf16x8 af = tr_pair(sd, wi * 64 + kcol2, r0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int b = wj * 3 + j;                // 32-column block of the 192 patch columns
+                const bf16x8 bf = tr_pair(sp + (b >> 1) * 8192, (b & 1) * 64 + kcol2, r0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                // fragments read: the tiles may be rebuilt
+    }
+    float* out = part + (size_t)blockIdx.x * 64 * KP;
+    const int lrow = lane & 31, lk = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                out[(wi * 32 + 8 * g4 + 4 * lk + e) * KP + (wj * 3 + j) * 32 + lrow] = acc[j][4 * g4 + e];
+#endif
+}
+
+// dw[co][k] += sum over the workgroups' partials [nwg][64][192], k < 147: 32 outputs x 8 slices per workgroup, every slice
+// adds its partials (wg = slice, slice + 8, ...) in order, the slices are added in order
+__global__ void __launch_bounds__(256) stem_wgrad_reduce_kernel(const float* __restrict__ part, int nwg, float* __restrict__ dw) {
+    __shared__ float red[8][32];
+    const int o = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+    float a0 = 0.f, a1 = 0.f;
+    if (o < 64 * 147) {
+        const float* p = part + (size_t)(o / 147) * 192 + o % 147;
+        int wg = sl;
+        for (; wg + 8 < nwg; wg += 16) { a0 += p[(size_t)wg * 64 * 192]; a1 += p[(size_t)(wg + 8) * 64 * 192]; }
+        if (wg < nwg) a0 += p[(size_t)wg * 64 * 192];
+    }
+    red[sl][threadIdx.x & 31] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < 32 && o < 64 * 147) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tot += red[i][threadIdx.x];
+        dw[o] += tot;
+    }
+}
+
+static int stem_wgrad_rows(int N, int Ho, int Wo) {
+    int rpw = 32;
+    while (rpw > 1 && ((Ho % rpw) || (long long)N * (Ho / rpw) * (Wo / 64) < 512)) rpw >>= 1;
+    return rpw;
+}
+
+extern "C" size_t rgda_stem_wgrad_workspace(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    if (Wo % 64) return 0;
+    return (size_t)N * (Ho / stem_wgrad_rows(N, Ho, Wo)) * (Wo / 64) * 64 * 192 * sizeof(float);
+}
+
+extern "C" int rgda_stem_wgrad(const float* img, const void* dy, int lddy, float* dw, void* ws, size_t ws_bytes, int N,
+                               int H, int W, int Ho, int Wo, rgda_stream_t stream) {
+    if (!img || !dy || !dw || !ws || N <= 0 || H <= 0 || W <= 0 || (lddy & 7) || lddy < 64) return RGDA_ERR_ARG;
+    if (Ho != (H + 6 - 7) / 2 + 1 || Wo != (W + 6 - 7) / 2 + 1) return RGDA_ERR_ARG;
+    if (Wo % 64) return RGDA_ERR_UNSUPPORTED;           // rgda_stem_im2col + rgda_conv2d_wgrad serve these
+    if (((uintptr_t)ws & 15) || ws_bytes < rgda_stem_wgrad_workspace(N, H, W)) return RGDA_ERR_WORKSPACE;
+    const int rpw = stem_wgrad_rows(N, Ho, Wo);
+    const long long blocks = (long long)N * (Ho / rpw) * (Wo / 64);
+    if (blocks > 0x7fffffffLL || (long long)N * Ho * Wo > 0x7fffffffLL) return RGDA_ERR_ARG;
+    hipStream_t st = to_stream(stream);
+    stem_wgrad_kernel<<<(int)blocks, 256, 0, st>>>(img, (const bf16_t*)dy, lddy, (float*)ws, H, W, Ho, Wo, rpw);
+    RGDA_CHECK_LAUNCH();
+    stem_wgrad_reduce_kernel<<<cdiv(64 * 147, 32), 256, 0, st>>>((const float*)ws, (int)blocks, dw);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
 extern "C" int rgda_stem_conv(const float* img, const void* wgt, void* y, int ldy, rgda_stat_t* stats, int stat_groups,
                               int N, int H, int W, int Ho, int Wo, rgda_stream_t stream) {
     return stem_conv_launch(img, wgt, y, ldy, stats, stat_groups, nullptr, N, H, W, Ho, Wo, stream);

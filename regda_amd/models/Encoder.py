@@ -290,6 +290,7 @@ class Deeplabv2(nn.Module):
         self.parallel_heads = True       # training forward: the second head on its own stream
         self.early_last_flush = True     # layer1's weight gradients start before the stem's backward
         self.fused_stem = True           # conv1 straight from the image where the map width allows it (rgda_stem_conv)
+        self.fused_stem_wgrad = True     # ... and its weight gradient too (rgda_stem_wgrad): no patch matrix at all
         self.parallel_ds = True          # downsample branches on the head stream
         self._head_stream = None
         self._mat_cache = {}
@@ -898,8 +899,13 @@ class Deeplabv2(nn.Module):
         ops.bn_bwd_apply(g, y if (relu and rmask is None) else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm,
                          bn.dgamma, bn.dbeta, nscale, Ho * Wo, groups=G, relu_mask=rmask)
         if stem:
-            ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
-            ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
+            if isinstance(x, tuple):        # the fp32 image batches themselves (one per BatchNorm group): no patch matrix
+                Ng = N // len(x)
+                for gi, xg in enumerate(x):
+                    ops.stem_wgrad(xg, dc[gi * Ng * Ho * Wo:(gi + 1) * Ng * Ho * Wo], conv.g.view(64, 147), Ng, H, W, Ho, Wo)
+            else:
+                ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
+                ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
             return None, gm
         # weight gradients are only needed by the optimizer: they are queued, and launched in groups
         T['wgrad_pending'].append((x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil))
@@ -942,7 +948,6 @@ class Deeplabv2(nn.Module):
                 ops.stem_conv_bneval(xg, self.stem_wb, y[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], bn.rm, bn.rv, bn.gamma,
                                      bn.beta, True, Ng, H, W, H1, W1)
             return y, None
-        col = torch.empty(M, STEM_KP, dtype=BF, device=dev)
         side = None
         if self.parallel_heads:
             if self._head_stream is None:
@@ -950,8 +955,16 @@ class Deeplabv2(nn.Module):
             side = self._head_stream
             plan.wait_event(side, plan.record_event(main_stream))       # the images are ready on the main stream
         with (ops.use_stream(side) if side is not None else contextlib.nullcontext()):
-            for gi, xg in enumerate(xs):
-                ops.stem_im2col(xg, col[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], Ng, H, W, H1, W1)
+            if self.fused_stem_wgrad:
+                # the weight gradient reads the images again at the END of backward (rgda_stem_wgrad): private copies, so
+                # the caller's buffers are free for the next batch once the forward has read them (25 MB, beside the forward)
+                col = tuple(torch.empty_like(xg) for xg in xs)
+                for xc, xg in zip(col, xs):
+                    plan.host(lambda xc=xc, xg=xg: xc.copy_(xg))
+            else:
+                col = torch.empty(M, STEM_KP, dtype=BF, device=dev)
+                for gi, xg in enumerate(xs):
+                    ops.stem_im2col(xg, col[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], Ng, H, W, H1, W1)
             col_ready = plan.record_event(side) if side is not None else None
         c = torch.empty(M, 64, dtype=BF, device=dev)
         stats = T['stats_pool'].take(G * NREP * 2 * 64)

@@ -337,6 +337,29 @@ def stem_im2col(img, col, N, H, W, Ho, Wo):
     lib().call('rgda_stem_im2col', img.data_ptr(), col.data_ptr(), N, H, W, Ho, Wo, col.shape[1], _stream())
 
 
+_STEM_WS = {}           # (device index, raw stream) -> workspace of rgda_stem_wgrad on that stream (grown on demand, never freed)
+_STEM_WS_OLD = []
+
+
+def stem_wgrad(img, dy, dw, N, H, W, Ho, Wo):
+    """The stem's weight gradient straight from the NCHW fp32 image (rgda_stem_wgrad; Wo % 64 == 0): dw f32 [64, 147]
+    (contiguous, accumulated), dy bf16 [N*Ho*Wo, 64(view)]."""
+    assert dw.is_contiguous() and dw.dtype == torch.float32 and dw.numel() == 64 * 147 and img.is_contiguous()
+    L = lib()
+    nbytes = L.size('rgda_stem_wgrad_workspace', N, H, W)
+    if nbytes == 0:
+        raise ValueError('rgda_stem_wgrad: geometry not served (Wo % 64 != 0): use stem_im2col + conv2d_wgrad')
+    key = (img.device.index, _stream())
+    ws = _STEM_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _STEM_WS_OLD.append(ws)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+        _STEM_WS[key] = ws
+    L.call('rgda_stem_wgrad', img.data_ptr(), dy.data_ptr(), _ld(dy), dw.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, Ho, Wo,
+           _stream())
+
+
 def bn_stats(x, stats, M, C):
     lib().call('rgda_bn_stats', x.data_ptr(), _ld(x), _stat(stats), M, C, _stream())
 

@@ -219,6 +219,42 @@ def test_fused_stem_conv_equals_the_im2col_route(ops, N, H, W, groups):
         ops.stem_conv(imgc[:, :, :, :96].contiguous(), wb, y, None, N, H, 96, Ho, 48)
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 40, 128), (8, 128, 256), (3, 18, 384)])
+def test_fused_stem_weight_gradient(ops, N, H, W):
+    """rgda_stem_wgrad (the stem's weight gradient straight from the image, Wo % 64 == 0) against (a) autograd of F.conv2d on
+    the bf16-rounded operands and (b) the rgda_stem_im2col + rgda_conv2d_wgrad route (the same bf16 products, another
+    summation order); accumulating (two calls = twice), bit-identical from run to run; other widths are refused."""
+    g = torch.Generator().manual_seed(33)
+    img = torch.randn(N, 3, H, W, generator=g)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    M = N * Ho * Wo
+    dy = rbf(torch.randn(N, 64, Ho, Wo, generator=g))
+    imgc, dyg = img.cuda(), to_pxc(dy)
+    dw = torch.zeros(64, 147, device='cuda')
+    ops.stem_wgrad(imgc, dyg, dw, N, H, W, Ho, Wo)
+    xr = rbf(img).requires_grad_(False)
+    wr = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(xr, wr, None, 2, 3).backward(dy)
+    ref = wr.grad.permute(0, 2, 3, 1).reshape(64, 147)
+    assert relerr(dw.cpu(), ref) < 2e-3
+    col = torch.empty(M, 192, dtype=BF, device='cuda')
+    ops.stem_im2col(imgc, col, N, H, W, Ho, Wo)
+    dwp = torch.zeros(64, 1, 192, device='cuda')
+    ops.conv2d_wgrad(col, dyg, dwp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
+    assert relerr(dw.cpu(), dwp.view(64, 192)[:, :147].cpu()) < 1e-4
+    first = dw.clone()
+    ops.stem_wgrad(imgc, dyg, dw, N, H, W, Ho, Wo)
+    torch.testing.assert_close(dw, 2 * first, rtol=0, atol=0)          # x + x is exact: the second pass summed identically
+    # a strided gradient view (64 channels of a wider buffer)
+    wide = torch.zeros(M, 96, dtype=BF, device='cuda')
+    wide[:, 16:80] = dyg
+    dw2 = torch.zeros(64, 147, device='cuda')
+    ops.stem_wgrad(imgc, wide[:, 16:80], dw2, N, H, W, Ho, Wo)
+    assert torch.equal(dw2, first)
+    with pytest.raises(ValueError):
+        ops.stem_wgrad(imgc[:, :, :, :96].contiguous(), dyg, dw, N, H, 96, Ho, 48)
+
+
 @pytest.mark.parametrize('N,H,W', [(2, 32, 48), (1, 38, 270), (3, 16, 130)])
 def test_stem_im2col_columns_exact(ops, N, H, W):
     """Every column vector, bit-exact: col[(n,ho,wo)][(kh*7+kw)*3 + c] = bf16(img[n, c, 2ho-3+kh, 2wo-3+kw]) or 0

@@ -155,11 +155,25 @@ __global__ void __launch_bounds__(256) weight_transpose_batched_kernel(const lon
     // 64 x 64 tiles: 256-byte fp32 row reads, 128-byte bf16 row writes in every mode (32-wide tiles wrote half lines)
     constexpr int TS = RGDA_LAYOUT_TILE;
     __shared__ float tile[TS][TS + 1];
-    int lo = 0, hi = n - 1;
+    // which table row owns this block: last entry with first_block <= b.  The first_block column goes to LDS in ONE
+    // coalesced round trip and is searched there: eight DEPENDENT global loads per block (a binary search in memory) were
+    // most of a block's life (21 600 blocks of a few microseconds each)
+    constexpr int NFB = 1024;
+    __shared__ long long fb[NFB];
     const long long b = blockIdx.x;
-    while (lo < hi) {                       // last entry with first_block <= b
-        int mid = (lo + hi + 1) >> 1;
-        if (table[mid * 8 + 5] <= b) lo = mid; else hi = mid - 1;
+    int lo = 0, hi = n - 1;
+    if (n <= NFB) {
+        for (int i = threadIdx.x; i < n; i += 256) fb[i] = table[i * 8 + 5];
+        __syncthreads();
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (fb[mid] <= b) lo = mid; else hi = mid - 1;
+        }
+    } else {
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (table[mid * 8 + 5] <= b) lo = mid; else hi = mid - 1;
+        }
     }
     const long long* e = table + lo * 8;
     const float* w = (const float*)e[0];

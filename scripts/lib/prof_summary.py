@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite) as text: per-kernel calls, total ms,
-average us, share.  usage: python scripts/prof_summary.py <results.db> [steps]"""
+average us, share.  usage: python scripts/prof_summary.py <results.db> [steps]  (steps: only used when the
+run has no sgd_step_kernel to count them by)"""
 import re
 import sqlite3
 import sys
@@ -24,6 +25,10 @@ def main():
         a = agg.setdefault(k, [0, 0.0])
         a[0] += calls
         a[1] += tot
+    # the run executes more steps than it times (warm-up, plan recording, the step behind it): count them by the kernel
+    # that runs exactly once per step
+    if 'sgd_step_kernel' in agg:
+        steps = float(agg['sgd_step_kernel'][0])
     total = sum(v[1] for v in agg.values())
     print('total kernel time %.3f ms over %.0f steps = %.3f ms/step' % (total / 1e3, steps, total / 1e3 / steps))
     print('%-60s %8s %10s %9s %6s' % ('kernel', 'calls/st', 'ms/step', 'avg us', '%'))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 4
+#define RGDA_ABI_VERSION 5
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore rgda_stat_t[RGDA_STAT_REPLICAS][2][C], zeroed by the caller.
@@ -220,6 +220,12 @@ typedef struct rgda_wgrad_desc {
     float* dw;          /* f32 [Cout][kh*kw][Cin] */
     int ldx, lddy;
     int N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil;
+    /* ABI 5: where dw's rows live, so that a gradient can be written straight into a slice of a wider tensor.
+     * lddw: elements between consecutive (co, tap) rows of dw (0 = Cin: dense).  co_split (0 = off; a power of two
+     * dividing Cout; 1x1 layers only): output row r of the layer is dw row (r % co_split) * (Cout / co_split) +
+     * r / co_split -- a layer whose Cout stacks T filters of co_split channels, [t][co], lands in a [co][t][Cin]
+     * tensor (the PPM branches of the heads' 3x3 convolution, regda/models/Encoder.py:29-37,54-60). */
+    int lddw, co_split;
 } rgda_wgrad_desc;
 size_t rgda_conv2d_wgrad_workspace(const rgda_wgrad_desc* descs, int n);
 int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, void* ws, size_t ws_bytes, rgda_stream_t stream);

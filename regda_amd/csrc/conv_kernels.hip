@@ -1355,6 +1355,8 @@ struct WgradArgs {
     int tiles_co, tiles_ci, splits, kt_per_split;
     int howo_shift, wo_shift;   // log2 when powers of two, else -1
     int tap_fused;              // host side: which kernel family the layer maps to
+    int lddw;                   // elements between consecutive (co, tap) rows of dw
+    int co_shift, co_nsub;      // co_shift >= 0: output row r -> dw row (r & ((1 << co_shift) - 1)) * co_nsub + (r >> co_shift)
     float* ws_part;             // splits > 1: this layer's partial tiles [tile][split][accumulators of the workgroup]
     int* ws_cnt;                //             and its per-tile arrival counters (zero before and after the launch)
     unsigned long long* dbg;    // tuning builds only: per-workgroup phase timestamps
@@ -1713,7 +1715,10 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
         if (!split_k_combine<FI * FJ, 64 * NW>(a, (tap * a.tiles_ci + tci) * a.tiles_co + tco, split, flat, smem)) return;
     }
     const int lcol = lane & 31, lk = lane >> 5;
-    const unsigned rs = (unsigned)(taps * a.Cin);
+    // dw row of output channel co: co itself, or (stacked filters, co_shift >= 0) its channel-major position; consecutive
+    // channels of one 32-channel block are `rstep` rows apart either way (a block never straddles a filter)
+    const unsigned rstep = a.co_shift >= 0 ? (unsigned)a.co_nsub : 1u;
+    const unsigned rs = rstep * (unsigned)(taps * a.lddw);
     const bool full = (co0 + BCO <= a.Cout) && (ci0 + BCI <= a.Cin);
 #pragma unroll
     for (int i = 0; i < FI; ++i)
@@ -1721,7 +1726,9 @@ __global__ void __launch_bounds__(64 * WI * WJ) conv_wgrad_kernel(WgradGroup g) 
         for (int j = 0; j < FJ; ++j) {
             const int cob = co0 + wi * (BCO / WI) + i * 32 + 4 * lk;
             const int ci = ci0 + wj * (BCI / WJ) + j * 32 + lcol;
-            unsigned o = (unsigned)cob * rs + (unsigned)(tap * a.Cin + ci);
+            const unsigned rowb = a.co_shift >= 0 ? (unsigned)((cob & ((1 << a.co_shift) - 1)) * a.co_nsub + (cob >> a.co_shift))
+                                                  : (unsigned)cob;
+            unsigned o = rowb * (unsigned)(taps * a.lddw) + (unsigned)(tap * a.lddw + ci);
             if (full) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -1887,7 +1894,7 @@ static __device__ __forceinline__ void conv_wgrad3x3_body(const WgradGroup& g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int co = co0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * 9 + q) * a.Cin + ci, acc[q][r]);
+                if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * 9 + q) * a.lddw + ci, acc[q][r]);
             }
     }
 #endif
@@ -1922,6 +1929,15 @@ static int wgrad_prepare(const rgda_wgrad_desc& d, WgradArgs& a) {
     a.x = (const bf16_t*)d.x; a.dy = (const bf16_t*)d.dy; a.dw = d.dw; a.ldx = d.ldx; a.lddy = d.lddy;
     a.N = d.N; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.Ho = d.Ho; a.Wo = d.Wo; a.Cout = d.Cout; a.KH = d.kh; a.KW = d.kw;
     a.stride = d.stride; a.pad = d.pad; a.dil = d.dil;
+    a.lddw = d.lddw ? d.lddw : d.Cin;
+    a.co_shift = -1; a.co_nsub = 1;
+    if (a.lddw < d.Cin) return RGDA_ERR_ARG;
+    if (d.co_split) {           // stacked 1x1 filters written channel-major
+        const int sh = ilog2_exact(d.co_split);
+        if (sh < 5 || (d.Cout % d.co_split) || d.kh != 1 || d.kw != 1) return RGDA_ERR_ARG;    // (32-channel blocks stay inside a filter)
+        a.co_shift = sh; a.co_nsub = d.Cout / d.co_split;
+    }
+    if ((long long)d.Cout * d.kh * d.kw * a.lddw > 0xffffffffLL) return RGDA_ERR_ARG;          // 32-bit element offsets
     long long M = (long long)d.N * d.Ho * d.Wo;
     if (M > 0x7fffffffLL - 64) return RGDA_ERR_ARG;
     a.M = (int)M;
@@ -2129,7 +2145,7 @@ extern "C" int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int ldd
                                  int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
                                  void* ws, size_t ws_bytes, rgda_stream_t stream) {
     rgda_wgrad_desc d;
-    d.x = x; d.dy = dy; d.dw = dw; d.ldx = ldx; d.lddy = lddy;
+    d.x = x; d.dy = dy; d.dw = dw; d.ldx = ldx; d.lddy = lddy; d.lddw = 0; d.co_split = 0;
     d.N = N; d.H = H; d.W = W; d.Cin = Cin; d.Ho = Ho; d.Wo = Wo; d.Cout = Cout; d.kh = kh; d.kw = kw;
     d.stride = stride; d.pad = pad; d.dil = dil;
     return rgda_conv2d_wgrad_grouped(&d, 1, ws, ws_bytes, stream);

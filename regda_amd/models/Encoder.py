@@ -423,39 +423,27 @@ class Deeplabv2(nn.Module):
         self._wt_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._wt_blocks = blk
         self.stem_wb = torch.zeros(64, 1, STEM_KP, dtype=BF, device=dev)
-        # fp32 landing buffers of the weight gradients that are not written straight into the flat gradient (stem, head
-        # slices): ONE arena, zeroed by one fill at the start of every backward pass
-        n_head = 0 if self.head_kind == 'aspp' else 2 * (512 * 9 * 2048 + len(POOL_SCALES) * 9 * 512 * 512)
-        self.grad_arena = torch.zeros(64 * STEM_KP + n_head, device=dev)
-        self.stem_gtmp = self.grad_arena[:64 * STEM_KP].view(64, 1, STEM_KP)
+        # fp32 landing buffer of the one weight gradient that is not written straight into the flat gradient (the stem's,
+        # on maps the fused kernel does not serve), zeroed at the start of every backward pass
+        self.grad_arena = torch.zeros(64 * STEM_KP, device=dev)
+        self.stem_gtmp = self.grad_arena.view(64, 1, STEM_KP)
         # head 3x3 conv (4096 -> 512) split into its feature half and the four PPM branches (see ppm_tap_matrix):
         #   wfeat [512][9][2048]            the feature-map half, contiguous
         #   wz[i] [9*512][1][512]           Z = q_i @ W_tap^T for all nine taps at once (a 1x1 conv, Cout = 4608)
         #   wzt[i] [512][1][9*512]          its transpose, for the gradient w.r.t. q_i
-        #   gfeat / gz[i]                   fp32 landing buffers of the two kinds of weight gradient
+        # (their weight gradients are written straight into the channel slices of the master gradient [512][9][4096]:
+        #  rgda_wgrad_desc.lddw / co_split)
         self.head_w = {}
         self._hw_ready = None
         if self.head_kind == 'aspp':
             self._build_aspp_weights()
             return
-        apos = [64 * STEM_KP]
-
-        def arena(*shape):
-            n = 1
-            for d in shape:
-                n *= d
-            t = self.grad_arena[apos[0]:apos[0] + n].view(*shape)
-            apos[0] += n
-            return t
         for head in ('layer5', 'layer6'):
             self.head_w[head] = {
                 'wfeat': torch.zeros(512, 9, 2048, dtype=BF, device=dev),
                 'wz': [torch.zeros(9 * 512, 1, 512, dtype=BF, device=dev) for _ in POOL_SCALES],
                 'wzt': [torch.zeros(512, 1, 9 * 512, dtype=BF, device=dev) for _ in POOL_SCALES],
-                'gfeat': arena(512, 9, 2048),
-                'gz': [arena(9 * 512, 1, 512) for _ in POOL_SCALES],
             }
-        assert apos[0] == self.grad_arena.numel()
         self._hw_ready = None
         # the head slices are two more tables for the same kernel: the forward operands (feature half + stacked tap
         # filters; also all the EMA teacher needs) and the transposes for the gradient w.r.t. the PPM branches
@@ -777,11 +765,9 @@ class Deeplabv2(nn.Module):
         dc = torch.empty(M, 512, dtype=BF, device=dev)
         ops.bn_bwd_apply(g, y, c, mi, bn.gamma, sums, dc, M, 512, True, None, bn.dgamma, bn.dbeta, nscale, HW, groups=G)
         gview = conv.g.view(512, 9, 4096)
-        # weight gradients land in contiguous fp32 buffers (the kernels write [Cout][taps][Cin] densely) and are
-        # added into the strided slices of the real gradient behind the grouped launch
-        T['wgrad_pending'].append((xn, dc, hw['gfeat'], N, h, w, h, w, 3, 3, 1, 1, 1))
+        # the weight gradients go straight into the channel slices of the master gradient (row stride 4096)
+        T['wgrad_pending'].append((xn, dc, gview[:, :, :2048], N, h, w, h, w, 3, 3, 1, 1, 1))
         T['wgrad_pending_flop'] += 2.0 * M * 512 * 2048 * 9
-        T['wgrad_post'].append(lambda gv=gview, t=hw['gfeat']: gv[:, :, :2048].add_(t))
         dfeat = torch.empty(M, 2048, dtype=BF, device=dev)
         ops.conv2d(dc, conv.wtb[:2048], dfeat, N, h, w, h, w, 3, 3, 1, 1, 1, 1, dfeat_prev, None)
         dqs = []
@@ -800,9 +786,8 @@ class Deeplabv2(nn.Module):
             dzr = dz.view(N * s * s, 9 * 512)
             dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
             ops.conv2d(dzr, hw['wzt'][i], dq, N, s, s, s, s, 1, 1, 1, 0, 1)
-            T['wgrad_pending'].append((qs[i], dzr, hw['gz'][i], N, s, s, s, s, 1, 1, 1, 0, 1))
-            T['wgrad_post'].append(lambda gv=gview, t=hw['gz'][i], i=i:
-                                   gv[:, :, 2048 + 512 * i: 2048 + 512 * (i + 1)].add_(t.view(9, 512, 512).permute(1, 0, 2)))
+            # nine stacked 1x1 filters (rows tap * 512 + co) written channel-major into [co][tap][2048 + 512 i ...]
+            T['wgrad_pending'].append((qs[i], dzr, gview[:, :, 2048 + 512 * i: 2048 + 512 * (i + 1)], N, s, s, s, s, 1, 1, 1, 0, 1))
             T['keep'].append((dz, dq))
             dqs.append(dq)
         T['keep'].append((dc, dfeat))

@@ -282,7 +282,8 @@ def conv2d_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
 class _WgradDesc(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('ldx', ctypes.c_int),
                 ('lddy', ctypes.c_int)] + [(k, ctypes.c_int) for k in
-                                           ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'kh', 'kw', 'stride', 'pad', 'dil')]
+                                           ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'kh', 'kw', 'stride', 'pad', 'dil',
+                                            'lddw', 'co_split')]
 
 
 _WGRAD_WS = {}          # (device index, raw stream) -> workspace of the weight-gradient launches issued on that stream
@@ -310,11 +311,18 @@ def conv2d_wgrad_grouped(items):
         return
     arr = (_WgradDesc * len(items))()
     for d, (x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil) in zip(arr, items):
-        Cout, taps, Cin = dw.shape
-        assert dw.is_contiguous() and dw.dtype == torch.float32 and taps == kh * kw
+        # dw: [Cout, taps, Cin], dense or a channel slice of a wider [Cout, taps, C] tensor (lddw = its row stride); for a
+        # 1x1 layer also [S, T, Cin] with T > 1: the layer's S * T output rows are T stacked filters of S channels
+        # ([t][s] order) and land channel-major in that tensor (co_split = S)
+        S, T, Cin = dw.shape
+        assert dw.dtype == torch.float32 and dw.stride(2) == 1 and dw.stride(0) == T * dw.stride(1)
+        stacked = kh * kw == 1 and T > 1
+        assert stacked or T == kh * kw
+        Cout = S * T if stacked else S
         d.x, d.dy, d.dw, d.ldx, d.lddy = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ld(x), _ld(dy)
         d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
         d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
+        d.lddw, d.co_split = dw.stride(1), (S if stacked else 0)
     L = lib()
     ap = ctypes.cast(arr, ctypes.c_void_p)
     ws = _wgrad_ws(L.size('rgda_conv2d_wgrad_workspace', ap, len(items)), items[0][0].device)

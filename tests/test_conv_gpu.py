@@ -144,6 +144,39 @@ def test_wgrad_grouped_matches_reference_and_single_launches(ops):
     assert torch.equal(before, items[2][2])
 
 
+def test_wgrad_into_channel_slices_and_stacked_filters(ops):
+    """rgda_wgrad_desc.lddw / co_split (ABI 5): a weight gradient written straight into a channel slice of a wider
+    [Cout][taps][C] tensor, and a 1x1 layer whose output rows are T stacked filters of S channels landing channel-major
+    ([s][t][ci]) in such a slice -- the head convolution's feature half and PPM branches.  Both against the dense call
+    (bit for bit: same kernels, same summation order), untouched elements stay untouched, generic and tap-fused kernels."""
+    g = torch.Generator().manual_seed(61)
+    N, H, W = 2, 16, 32
+    M = N * H * W
+    for (Ci, Co, k) in [(128, 256, 3), (64, 64, 3), (128, 128, 1)]:
+        x = rbf(torch.randn(M, Ci, generator=g)).to(BF).cuda()
+        dy = rbf(torch.randn(M, Co, generator=g)).to(BF).cuda()
+        dense = torch.zeros(Co, k * k, Ci, device='cuda')
+        ops.conv2d_wgrad(x, dy, dense, N, H, W, H, W, k, k, 1, k // 2, 1)
+        wide = torch.full((Co, k * k, Ci + 96), 7.0, device='cuda')
+        view = wide[:, :, 32:32 + Ci]
+        view.zero_()
+        ops.conv2d_wgrad_grouped([(x, dy, view, N, H, W, H, W, k, k, 1, k // 2, 1)])
+        assert torch.equal(view, dense), (Ci, Co, k)
+        assert float(wide[:, :, :32].min()) == 7.0 and float(wide[:, :, 32 + Ci:].min()) == 7.0
+    # stacked 1x1 filters: T = 3 filters of S = 64 channels, output row r = t * 64 + s -> wide[s][t][16 + ci]
+    S, T, Ci = 64, 3, 128
+    x = rbf(torch.randn(M, Ci, generator=g)).to(BF).cuda()
+    dy = rbf(torch.randn(M, S * T, generator=g)).to(BF).cuda()
+    dense = torch.zeros(S * T, 1, Ci, device='cuda')
+    ops.conv2d_wgrad(x, dy, dense, N, H, W, H, W, 1, 1, 1, 0, 1)
+    wide = torch.full((S, T, Ci + 48), 7.0, device='cuda')
+    view = wide[:, :, 16:16 + Ci]
+    view.zero_()
+    ops.conv2d_wgrad_grouped([(x, dy, view, N, H, W, H, W, 1, 1, 1, 0, 1)])
+    assert torch.equal(view, dense.view(T, S, Ci).permute(1, 0, 2))
+    assert float(wide[:, :, :16].min()) == 7.0 and float(wide[:, :, 16 + Ci:].min()) == 7.0
+
+
 def test_conv_strided_views_and_row_tail(ops):
     """ld > C on both sides (channel-slice views of a concat buffer) and M not a tile multiple."""
     g = torch.Generator().manual_seed(4)

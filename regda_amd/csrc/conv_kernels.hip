@@ -575,11 +575,11 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 //   LDS: two halo buffers (slab s + 1 lands while slab s is multiplied; its pieces are issued one per tap step) + a
 //   3-stage ring of weight tiles = 144 KB (D = 1) / 160 KB (D = 2); one barrier per tap step; the counted vmcnt wait
 //   lets exactly the pieces of the previous step stay in flight.
-template <int D>
+template <int D, int TR>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BC = 128, BP = 256, WC = 2, WP = 4, NW = 8, FI = 2, FJ = 2;
-    constexpr int TR = 8, TC = 32;                          // pixel tile: 8 image rows x the 32 columns of the map
+    constexpr int TC = 32;                                  // pixel tile: TR image rows x the 32 columns of the map
+    constexpr int BC = 128, BP = TR * TC, WC = 2, WP = 4, NW = 8, FI = 2, FJ = TR / WP;
     constexpr int HR = TR + 2 * D, HC = TC + 2 * D, NH = HR * HC;
     constexpr int PXW = (NH + 63) / 64;                     // halo pieces (8 rows of 128 B) per wave and slab
     constexpr int XS = PXW * 64 * 128, WS = BC * 128;       // bytes of a halo buffer / a weight stage
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     const int S = a.Cin >> 6, KT = 9 * S;
     int hb[FJ];                                             // halo row of this lane's pixel (tap 0,0) per pixel block
 #pragma unroll
-    for (int j = 0; j < FJ; ++j) hb[j] = (wp * 2 + j) * HC + lrow;
+    for (int j = 0; j < FJ; ++j) hb[j] = (wp * FJ + j) * HC + lrow;
     int wr[FI];                                             // weight-tile row byte offset and its swizzle key
 #pragma unroll
     for (int i = 0; i < FI; ++i) wr[i] = wc * 64 + i * 32 + lrow;
@@ -828,17 +828,18 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
 // byte, 8 waves); large-M layers run 128 x 128 tiles with 8 waves and a 2-stage ring (64 KiB: two workgroups =
 // 16 waves per CU); everything else 128 x 64 tiles with 4 waves, two workgroups per CU.  `stages` 82 / 83 mean
 // 8-wave workgroups with 2 / 3 stages.  rows_per_group != 0: a tile may not straddle two statistics groups.
-// the cases conv3x3_halo_kernel serves: 3x3 / stride 1 / pad = dilation 1 or 2 on 32-wide maps whose height is a multiple
-// of 8, long K (where the 128 x 256 tile would be picked), enough tiles to fill the chip, tiles inside one statistics group
-static bool conv_use_halo(long long M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho,
-                          int Wo, int rows_per_group) {
-    if (const char* e = TUNE_ENV("RGDA_HALO")) { if (!atoi(e)) return false; }           // tuning experiments only
-    if (kh != 3 || kw != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return false;
-    if (W != 32 || Wo != 32 || Ho != H || (H & 7)) return false;
-    if ((long long)9 * Cin < 4096 || (Cin & 63)) return false;
-    if ((M / 256) * cdiv(Cout, 128) < 240) return false;
-    if (rows_per_group % 256) return false;
-    return true;
+// the cases conv3x3_halo_kernel serves: 3x3 / stride 1 / pad = dilation on 32-wide maps, tiles inside one statistics group,
+// enough tiles to fill the chip -> image rows per tile (0 = not served):
+//   8 (128 x 256 tiles): K >= 4096, dilation 1 or 2 (the heads, layer 4) -- where the 128 x 256 implicit-GEMM tile would be picked;
+//   4 (128 x 128 tiles): K >= 2048, dilation 1 (layer 3's 256 -> 256: 27.4 -> 25.0 us against the pipelined 128 x 128 tile).
+static int conv_use_halo(long long M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho,
+                         int Wo, int rows_per_group) {
+    if (const char* e = TUNE_ENV("RGDA_HALO")) { if (!atoi(e)) return 0; }              // tuning experiments only
+    if (kh != 3 || kw != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return 0;
+    if (W != 32 || Wo != 32 || Ho != H || (Cin & 63)) return 0;
+    if ((long long)9 * Cin >= 4096 && !(H & 7) && !(rows_per_group % 256) && (M / 256) * cdiv(Cout, 128) >= 240) return 8;
+    if ((long long)9 * Cin >= 2048 && dil == 1 && !(H & 3) && !(rows_per_group % 128) && (M / 128) * cdiv(Cout, 128) >= 240) return 4;
+    return 0;
 }
 
 static int pick_tile(long long M, int Cout, long long ktot, int rows_per_group, int& bc, int& bp, int& stages) {
@@ -934,12 +935,21 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         }
     }
     // long-K 3x3 convolutions on 32-wide maps (heads, layer 4): the halo kernel (tiles of 8 image rows = 256 pixels)
-    if (conv_use_halo(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, a.rows_per_group)) {
+    if (const int tr = conv_use_halo(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, a.rows_per_group)) {
         a.tiles_c = cdiv(Cout, 128);
-        a.tiles_p = (int)(M / 256);
+        a.tiles_p = (int)(M / (tr * 32));
         const int grid = a.tiles_c * a.tiles_p;
-        if (dil == 1) conv3x3_halo_kernel<1><<<grid, 512, 0, st>>>(a);
-        else conv3x3_halo_kernel<2><<<grid, 512, 0, st>>>(a);
+        if (tr == 4) conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a);
+        else if (dil == 1) conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a);
+        else conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a);
+        RGDA_CHECK_LAUNCH();
+        return RGDA_OK;
+    }
+    if (TUNE_ENV("RGDA_HALO4") && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && W == 32 && Wo == 32 && Ho == H &&
+        !(H & 3) && !(Cin & 63) && !(a.rows_per_group % 128) && (M / 128) * cdiv(Cout, 128) >= 240) {
+        a.tiles_c = cdiv(Cout, 128);
+        a.tiles_p = (int)(M / 128);
+        conv3x3_halo_kernel<1, 4><<<a.tiles_c * a.tiles_p, 512, 0, st>>>(a);
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
     }

@@ -83,9 +83,9 @@ def conv_flops_probe(step_fn, park_ms=150.0):
             name = 'conv3x3_c64_kernel<128>'        # layer1's 3x3: the weights-resident rolling-window kernel
         if kh == 3 and kw == 3 and stride == 1 and dil in (1, 2) and Wo == 32 and in_rows in (None, M):
             # long-K 3x3 on 32-wide maps (csrc/conv_kernels.hip: conv_use_halo)
-            if (9 * ci >= 4096 and Ho % 8 == 0 and (M // 256) * ((co + 127) // 128) >= 240 and (rows_per_group or M) % 256 == 0):
+            if (9 * ci >= 4096 and Ho % 8 == 0 and (M // 256) * ((co + 127) // 128) >= 100 and (rows_per_group or M) % 256 == 0):
                 name = 'conv3x3_halo_kernel<%d, 8>' % dil
-            elif (9 * ci >= 2048 and dil == 1 and Ho % 4 == 0 and (M // 128) * ((co + 127) // 128) >= 240
+            elif (9 * ci >= 2048 and dil == 1 and Ho % 4 == 0 and (M // 128) * ((co + 127) // 128) >= 100
                   and (rows_per_group or M) % 128 == 0):
                 name = 'conv3x3_halo_kernel<1, 4>'
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

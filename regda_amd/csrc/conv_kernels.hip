@@ -828,17 +828,24 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
 // byte, 8 waves); large-M layers run 128 x 128 tiles with 8 waves and a 2-stage ring (64 KiB: two workgroups =
 // 16 waves per CU); everything else 128 x 64 tiles with 4 waves, two workgroups per CU.  `stages` 82 / 83 mean
 // 8-wave workgroups with 2 / 3 stages.  rows_per_group != 0: a tile may not straddle two statistics groups.
-// the cases conv3x3_halo_kernel serves: 3x3 / stride 1 / pad = dilation on 32-wide maps, tiles inside one statistics group,
-// enough tiles to fill the chip -> image rows per tile (0 = not served):
+// the cases conv3x3_halo_kernel serves: 3x3 / stride 1 / pad = dilation on 32-wide maps, tiles inside one statistics group
+// -> image rows per tile (0 = not served):
 //   8 (128 x 256 tiles): K >= 4096, dilation 1 or 2 (the heads, layer 4) -- where the 128 x 256 implicit-GEMM tile would be picked;
 //   4 (128 x 128 tiles): K >= 2048, dilation 1 (layer 3's 256 -> 256: 27.4 -> 25.0 us against the pipelined 128 x 128 tile).
+// From 100 tiles on: the EMA teacher's launches (M = 8192: 128 tiles) then occupy HALF the CUs with one fat workgroup
+// each instead of all of them with 128 x 64 tiles -- no faster alone (20.4 vs 21.0 us), but they run beside the student's
+// forward on another stream, which gets the other half: -0.33 ms per step in an interleaved A/B (240 -> 100 for both forms).
 static int conv_use_halo(long long M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho,
                          int Wo, int rows_per_group) {
     if (const char* e = TUNE_ENV("RGDA_HALO")) { if (!atoi(e)) return 0; }              // tuning experiments only
     if (kh != 3 || kw != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return 0;
     if (W != 32 || Wo != 32 || Ho != H || (Cin & 63)) return 0;
-    if ((long long)9 * Cin >= 4096 && !(H & 7) && !(rows_per_group % 256) && (M / 256) * cdiv(Cout, 128) >= 240) return 8;
-    if ((long long)9 * Cin >= 2048 && dil == 1 && !(H & 3) && !(rows_per_group % 128) && (M / 128) * cdiv(Cout, 128) >= 240) return 4;
+    int min_tiles = 100;
+    if (const char* e = TUNE_ENV("RGDA_HALO_MIN")) min_tiles = atoi(e);                 // tuning experiments only
+    int min8 = 100;
+    if (const char* e = TUNE_ENV("RGDA_HALO_MIN8")) min8 = atoi(e);                     // tuning experiments only
+    if ((long long)9 * Cin >= 4096 && !(H & 7) && !(rows_per_group % 256) && (M / 256) * cdiv(Cout, 128) >= min8) return 8;
+    if ((long long)9 * Cin >= 2048 && dil == 1 && !(H & 3) && !(rows_per_group % 128) && (M / 128) * cdiv(Cout, 128) >= min_tiles) return 4;
     return 0;
 }
 
@@ -942,14 +949,6 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         if (tr == 4) conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a);
         else if (dil == 1) conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a);
         else conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a);
-        RGDA_CHECK_LAUNCH();
-        return RGDA_OK;
-    }
-    if (TUNE_ENV("RGDA_HALO4") && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && W == 32 && Wo == 32 && Ho == H &&
-        !(H & 3) && !(Cin & 63) && !(a.rows_per_group % 128) && (M / 128) * cdiv(Cout, 128) >= 240) {
-        a.tiles_c = cdiv(Cout, 128);
-        a.tiles_p = (int)(M / 128);
-        conv3x3_halo_kernel<1, 4><<<a.tiles_c * a.tiles_p, 512, 0, st>>>(a);
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
     }

@@ -1017,8 +1017,8 @@ extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* 
 // chain).  Here a workgroup owns 64 consecutive pixels of `rpw` consecutive output rows: the weights [64][192] stay in
 // LDS, every row stages the 7 x 133 x 3 image patch it touches (bf16), builds ITS 64 x 192 patch tile in LDS in the
 // swizzled layout the MFMA fragment reads expect, multiplies (12 MFMAs per wave) and leaves through the common
-// epilogue (bf16 rows, BatchNorm statistics or inference BatchNorm + ReLU).  The training forward still needs the
-// patch matrix for the weight gradient; it is written by rgda_stem_im2col on another stream, off the critical path.
+// epilogue (bf16 rows, BatchNorm statistics or inference BatchNorm + ReLU).  The weight gradient is computed from the
+// image as well (stem_wgrad_kernel below): no patch matrix anywhere when the map width is a multiple of 64.
 // Requires Wo % 64 == 0 (the 1x1 route serves everything else).  8 images of 512 x 512: 66 us against 66 + 58 us for
 // im2col + 1x1 convolution; on the whole step (where the teacher's stem runs beside the student's) -0.06 ms.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))

@@ -921,8 +921,9 @@ class Deeplabv2(nn.Module):
 
     def _stem_fwd(self, T, xs, Ng, H, W, H1, W1, main_stream):
         """conv1 + bn1 + ReLU from the fp32 images in one convolution kernel per BatchNorm group (rgda_stem_conv: no patch
-        matrix on the forward chain).  Training still needs the patch matrix -- the weight gradient's operand -- so
-        rgda_stem_im2col writes it on the head stream, next to the forward; -> (activation, event after the im2col)."""
+        matrix).  The weight gradient reads the images again at the end of backward (rgda_stem_wgrad): training keeps
+        private copies of them, made on the head stream next to the forward (without `fused_stem_wgrad`: the patch matrix
+        of rgda_stem_im2col instead); -> (activation, event after the copies / the im2col)."""
         dev = self.device
         conv, bn = self.convs['encoder.resnet.conv1'], self.bns['encoder.resnet.bn1']
         G = len(xs)

@@ -58,6 +58,15 @@ def parse():
     return ap.parse_args()
 
 
+def flush_c_stdio():
+    """Drain the C library's stdout buffer (RCCL's init banner lives there when stdout is a pipe or a file)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def conv_flops_probe(step_fn, park_ms=150.0):
     """Run one step with HIP events (torch.cuda.Event on the launch stream) around every conv launch.
     Returns {kernel instantiation: dict(gflop, ms, launches, tflops, avg_us)}; names match rocprofv3's."""
@@ -393,6 +402,7 @@ def main():
     for _ in range(args.warmup):
         one()
     torch.cuda.synchronize()
+    flush_c_stdio()         # every rank: the communicator exists now, its banner goes out here, not behind the JSON line
     graphed = planned = False
     if not args.graph and not args.eager:      # (the collectives of a multi-GPU step are host actions of the plan)
         try:        # the step is a static launch sequence: replay it below the ABI (one C loop per segment)
@@ -574,10 +584,13 @@ def main():
         model.train()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args)
-    if rank == 0:
-        print(json.dumps(res))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which a pipe or file buffers until the process exits -- behind
+        # anything Python printed.  Drain it first so that the JSON line is the LAST line of stdout.
+        flush_c_stdio()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':

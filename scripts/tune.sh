@@ -15,7 +15,7 @@
 #     bash scripts/tune.sh profiles rNN        regenerate everything profiles/ holds for a round into gpurun_out/
 #     bash scripts/tune.sh dev <script> [args] a scripts/dev/ probe with the tuning library copied over the product one
 #                                              (conv_phases.py, kbench.py, one_conv.py, conv_ablate.sh, mfma_ceiling.py,
-#                                               gemm_calib.py, wgrad_calib.py)
+#                                               gemm_calib.py, wgrad_calib.py, coresidency.py, grid_barrier.py)
 # Every rocprofv3 run sits under `timeout`; counter passes use --kernel-trace only (no other trace domains).
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"

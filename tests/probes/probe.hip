@@ -168,3 +168,26 @@ extern "C" int probe_run_mfma_rate(const void* seed, void* out, int blocks, int 
     probe_mfma_rate<<<blocks, threads, 0, (hipStream_t)stream>>>((const unsigned*)seed, (float*)out, iters);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// Cost of a software grid barrier (all workgroups co-resident): every round thread 0 of a workgroup adds 1 to a
+// device-scope counter and spins on it until all gridDim.x workgroups of the round have arrived; then the workgroup
+// continues.  Launch with at most one small workgroup per CU.  (Sizing a conv + BatchNorm-apply fusion that would keep a
+// layer's tile in LDS across the statistics' global reduction.)
+__global__ void __launch_bounds__(256) probe_grid_barrier(unsigned* counter, unsigned long long* out, int rounds) {
+    const unsigned n = gridDim.x;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < rounds; ++r) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)(r + 1) * n;
+            while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_readcyclecounter() - t0;
+}
+
+extern "C" int probe_run_grid_barrier(void* counter, void* out, int blocks, int rounds, void* stream) {
+    probe_grid_barrier<<<blocks, 256, 0, (hipStream_t)stream>>>((unsigned*)counter, (unsigned long long*)out, rounds);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 5
+#define RGDA_ABI_VERSION 6
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore rgda_stat_t[RGDA_STAT_REPLICAS][2][C], zeroed by the caller.
@@ -182,13 +182,50 @@ int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void* y, int ldy
  *   g' = g * [bn_y > 0 if relu] * nscale[n][c],  xhat = (bn_x - mean) * invstd  (mean/invstd from bn_mi[group]),
  * ([bn_y > 0] is read from bn_relu_mask instead when that is given, see rgda_bn_train_apply)
  * sums[group][REPLICAS][2][Cout] += (sum g', sum g' * xhat) -- exactly what rgda_bn_bwd_reduce would compute
- * from the stored tensor, without re-reading it. */
+ * from the stored tensor, without re-reading it.
+ * relu == 2 (ABI 6): the consumer's activation was never written (it ran on ITS consumer's operand path,
+ * rgda_conv2d_bnin): [bn_y > 0] is recomputed from bn_x as [fma(bn_x, scale, shift) > 0] with the forward's own
+ * (scale, shift) = (gamma * invstd, fma(-mean, scale, beta)); bn_gamma / bn_beta f32 [Cout] are needed only then. */
 int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
                       const uint8_t* res_relu_mask, rgda_stat_t* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
                       const void* bn_x, int bn_ldx,
-                      const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N, int H,
+                      const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu,
+                      const float* bn_gamma, const float* bn_beta, int N, int H,
                       int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
                       int mode, rgda_stream_t stream);
+
+/* BatchNorm (+ ReLU) on the CONSUMER's operand path (ABI 6).  The reference's bottleneck runs conv -> bn -> relu -> conv
+ * (regda/_resnets.py:92-112); as separate passes the normalised activation is written and read back once per unit.
+ * Here the producing convolution leaves its RAW output and its statistic accumulators, and the consuming convolution
+ * applies  a = relu(fma(x, scale, shift)),  scale = gamma * invstd, shift = fma(-mean, scale, beta)  to the operand tile
+ * on its way to the matrix pipe (mean / invstd from `stats` exactly as rgda_bn_train_apply derives them: biased batch
+ * variance, eps inside the square root).  The activation is never written; padding positions contribute zeros as in the
+ * reference (the padding of conv2 pads the ACTIVATION).  One workgroup of the launch also writes `mi` (mean, invstd per
+ * group, for the backward pass) and updates running_mean / running_var (momentum, unbiased variance) group after group
+ * and num_batches_tracked += groups -- nn.BatchNorm2d's train-mode side effects (regda/resnet.py:170-181 keeps every
+ * BatchNorm trainable; tools/train_ssl_reg.py:210-212 runs source then target).
+ * The struct is HOST memory holding DEVICE pointers; it is consumed before the call returns. */
+typedef struct rgda_bn_operand {
+    const rgda_stat_t* stats;       /* [groups][REPLICAS][2][C] (FRAC_FWD) of the producing convolution, complete */
+    const float* gamma;             /* f32 [C] */
+    const float* beta;              /* f32 [C] */
+    float* mi;                      /* NULL or out f32 [groups][2][C]: mean, invstd */
+    float* running_mean;            /* NULL or f32 [C], updated in place (both or neither) */
+    float* running_var;
+    int64_t* num_batches_tracked;   /* NULL or += groups */
+    float eps, momentum;
+    int groups;                     /* equal blocks of whole images, normalised independently (= stat_groups of the call) */
+    int relu;
+} rgda_bn_operand;
+/* rgda_conv2d (mode 0) whose operand x [N*H*W][ldx] is the RAW output of the producing convolution and bn_in describes
+ * the BatchNorm (+ ReLU) between them.  Served: Cin <= 512 and the geometries rgda_conv2d_bnin_supported() reports
+ * (1x1 and 3x3 convolutions with >= 512 tiles of 128 x 128, and the 3x3 / dilation 1 convolutions on 32-wide maps);
+ * anything else returns RGDA_ERR_UNSUPPORTED and the caller materialises the activation with rgda_bn_train_apply. */
+int rgda_conv2d_bnin_supported(int64_t M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H, int W,
+                               int Ho, int Wo, int groups);
+int rgda_conv2d_bnin(const rgda_bn_operand* bn_in, const void* x, int ldx, const void* wgt, void* y, int ldy,
+                     const void* res, int ldres, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin,
+                     int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, rgda_stream_t stream);
 
 /* Which conv_igemm_kernel<BC, BP, STAGES, ...> instantiation rgda_conv2d picks for a problem: returns
  * BC | BP << 10 | STAGES << 20 (STAGES 82 / 83 = 8-wave workgroups with a 2 / 3 stage ring), or a negative
@@ -273,23 +310,34 @@ int rgda_bn_train_apply(const void* x, int ldx, const rgda_stat_t* stats, float*
                         int groups, float eps, float momentum, rgda_stream_t stream);
 /* sums rgda_stat_t[REPLICAS][2][C] (FRAC_BWD) must be ZERO on entry (the caller clears one arena per backward pass):
  * sums[0] += sum(g'), sums[1] += sum(g' * xhat), g' = g*[y>0]*nscale.  With relu, [y>0] comes from relu_mask
- * when given, else from y. */
+ * when given, else from y.
+ * relu == 2 (ABI 6): [y>0] is recomputed from x, [fma(x, gamma * invstd, fma(-mean, gamma * invstd, beta)) > 0] -- the
+ * unit's activation was never written (rgda_conv2d_bnin); gamma / beta are needed only then. */
 int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask, const void* x,
                        int ldx, const float* mi, const float* nscale, int rows_per_image, rgda_stat_t* sums,
-                       int64_t M, int C, int relu, int groups, rgda_stream_t stream);
+                       int64_t M, int C, int relu, const float* gamma, const float* beta, int groups,
+                       rgda_stream_t stream);
 /* dx = gamma*invstd*(g' - sum(g')/M - xhat*sum(g' xhat)/M); gmask (optional) = g';
- * dgamma += sum(g' xhat), dbeta += sum(g') (f32, accumulated) */
+ * dgamma += sum(g' xhat), dbeta += sum(g') (f32, accumulated)
+ * relu == 2 (ABI 6, needs beta): the ReLU sign from x as in rgda_bn_bwd_reduce; act_out (optional, bf16 [M][ldact]) then
+ * receives the activation relu(fma(x, scale, shift)) itself -- bit for bit what the consuming convolution's operand
+ * path fed the matrix pipe -- for that convolution's weight gradient (rgda_conv2d_wgrad), written here beside the
+ * read of x this pass does anyway instead of in the forward pass. */
 int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask, const void* x,
                       int ldx, const float* mi, const float* gamma, const float* nscale,
                       int rows_per_image, const rgda_stat_t* sums, void* dx, int lddx, void* gmask,
-                      int ldgm, float* dgamma, float* dbeta, int64_t M, int C, int relu, int groups,
-                      rgda_stream_t stream);
+                      int ldgm, float* dgamma, float* dbeta, int64_t M, int C, int relu, const float* beta,
+                      void* act_out, int ldact, int groups, rgda_stream_t stream);
 
 /* MaxPool2d(3,2,1) on PxC bf16 (regda/_resnets.py:153); idx = argmax tap (uint8). */
 int rgda_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho,
                      int Wo, rgda_stream_t stream);
 int rgda_maxpool_bwd(const void* gy, const uint8_t* idx, void* gx, int N, int H, int W, int C,
                      int Ho, int Wo, rgda_stream_t stream);
+/* The same pooling over relu(BatchNorm(x)) of the RAW stem convolution output x (rgda_bn_operand above; conv1 -> bn1 ->
+ * relu -> maxpool, regda/_resnets.py:150-153): the stem's activation is never written. */
+int rgda_maxpool_fwd_bnin(const rgda_bn_operand* bn_in, const void* x, void* y, uint8_t* idx, int N, int H, int W,
+                          int C, int Ho, int Wo, rgda_stream_t stream);
 
 /* InstanceNorm2d(C, affine=False, eps) (regda/models/Encoder.py:123,146-147).
  * x [N*HW][ldx] bf16 -> y0,y1 (optional, bf16 PxC, ld ldy) and feat NCHW f32 (optional);

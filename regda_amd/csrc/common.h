@@ -62,13 +62,19 @@ static __device__ __forceinline__ float wave_max(float v) {
 
 // ---- order-independent per-channel accumulators (include/rgda_hip.h: rgda_stat_t, 64-bit fixed point).
 // A workgroup's partial sum (reduced in a fixed order inside the workgroup) -> round(v * 2^frac) -> integer atomic.
+// A partial that is out of range (|v * 2^frac| >= 2^59) or not finite adds RGDA_STAT_POISON instead: stat_total() turns a
+// replica whose magnitude reached 2^60 into +inf, so a diverging run shows inf / NaN in its BatchNorm outputs instead of
+// silently wrapped (sign-flipped) statistics.  (Up to 15 poisoned partials on one word cannot cancel: k * 3 * 2^60 mod 2^64
+// stays >= 2^60 in magnitude for k = 1 .. 15.)  In-range totals: |sum| < 2^60 / 2^frac per replica = 1.7e10 forward,
+// 1.0e6 backward.
+#define RGDA_STAT_POISON (3ll << 60)
 static __device__ __forceinline__ long long stat_fix(float v, int frac) {
     // round(v * 2^frac) as a 64-bit integer without fp64 or the software float -> int64 routine (40+ instructions at the
     // tail of every convolution workgroup): the scaling by a power of two is exact in fp32; x = hi * 2^31 + lo with
     // hi = trunc(x / 2^31) and the remainder lo (same sign, |lo| < 2^31, exactly representable: it is the low part of a
     // 24-bit mantissa), each converted by a native 32-bit instruction.
-    float x = ldexpf(v, frac);
-    if (!(fabsf(x) < 0x1p61f)) x = (v == v && fabsf(v) != __builtin_inff()) ? copysignf(0x1p61f, v) : 0.f;   // clamp; NaN / Inf add nothing
+    const float x = ldexpf(v, frac);
+    if (!(fabsf(x) < 0x1p59f)) return RGDA_STAT_POISON;       // out of range, Inf or NaN
     const float hi = truncf(x * 0x1p-31f);
     const float lo = x - hi * 0x1p31f;
     return ((long long)__float2int_rz(hi) << 31) + (long long)__float2int_rn(lo);
@@ -79,9 +85,94 @@ static __device__ __forceinline__ void stat_add(rgda_stat_t* p, float v, int fra
 // total of statistic `which` (0: first sum, 1: second) of channel c over the replicas of one row group, as a double
 static __device__ __forceinline__ double stat_total(const rgda_stat_t* __restrict__ st, int C, int c, int which, int frac) {
     long long t = 0;
+    bool poisoned = false;
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) t += st[(size_t)(2 * r + which) * C + c];
+    for (int r = 0; r < NREP; ++r) {
+        const long long v = st[(size_t)(2 * r + which) * C + c];
+        poisoned |= (v >= (1ll << 60)) || (v <= -(1ll << 60));
+        t += v;
+    }
+    if (poisoned) return (double)__builtin_inff();
     return (double)t * (1.0 / (double)(1ll << frac));
+}
+
+// mean, biased variance and 1 / sqrt(var + eps) of channel c from one row group's accumulators: fp64 from the exact
+// integer totals (every consumer goes through here, so forward, backward and the running update see the same values)
+static __device__ __forceinline__ void stat_moments(const rgda_stat_t* __restrict__ st, int C, int c, double invM, float eps,
+                                                    float& mean, float& var, float& istd) {
+    const double m = stat_total(st, C, c, 0, RGDA_STAT_FRAC_FWD) * invM;
+    double v = stat_total(st, C, c, 1, RGDA_STAT_FRAC_FWD) * invM - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    istd = 1.f / sqrtf((float)v + eps);       // (fp32: a double-precision sqrt + divide per channel shows in the apply passes)
+}
+
+// ---- BatchNorm (+ ReLU) applied on the CONSUMER's operand path (include/rgda_hip.h: rgda_bn_operand).
+// The producing convolution leaves its raw output and the per-channel accumulators; the consumer (a convolution, the
+// stem's max-pool) rebuilds (scale, shift) per channel in its prologue and applies  a = relu(fma(x, scale, shift))  to the
+// operand on its way to the matrix pipe -- the activation is never written.  ONE formula everywhere (forward operand,
+// the backward kernels' ReLU sign and the activation they hand to the weight gradient), so all of them see the same bits:
+//     scale = gamma * invstd,  shift = fma(-mean, scale, beta),  a = max(fma(x, scale, shift), 0) rounded to bf16 (RNE)
+struct BnOperand {
+    const rgda_stat_t* stats;
+    const float* gamma;
+    const float* beta;
+    float* mi;
+    float* rm;
+    float* rv;
+    long long* nbt;
+    float eps, mom;
+    int groups, relu, C;
+    int rows_per_group;        // rows of the operand map in one group
+};
+static __device__ __forceinline__ void bn_scale_shift(float mean, float istd, float gamma, float beta, float& sc, float& sh) {
+    sc = gamma * istd;
+    sh = __builtin_fmaf(-mean, sc, beta);
+}
+static __device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// eight packed bf16 values -> relu(fma(x, sc, sh)) (relu optional), packed bf16 again
+static __device__ __forceinline__ uint4 bn_operand8(uint4 v, const float (&sc)[8], const float (&sh)[8], bool relu) {
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f32x2v x = {__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)};
+        f32x2v s = {sc[2 * e], sc[2 * e + 1]}, h = {sh[2 * e], sh[2 * e + 1]};
+        f32x2v f = __builtin_elementwise_fma(x, s, h);
+        if (relu) { f.x = fmaxf(f.x, 0.f); f.y = fmaxf(f.y, 0.f); }
+        w[e] = pack2bf(f.x, f.y);
+    }
+    return uint4{w[0], w[1], w[2], w[3]};
+}
+// Prologue of a consumer workgroup of NT threads: (scale, shift) of all C channels of row group `grp` -> tab[0..C),
+// tab[C..2C) (LDS; the caller puts a barrier between this and the first use).  The `leader` workgroup of the launch also
+// publishes (mean, invstd) of every group for the backward pass and updates the running statistics, group after group
+// (the reference runs the source batch, then the target batch: tools/train_ssl_reg.py:210-212).
+template <int NT>
+static __device__ __forceinline__ void bn_operand_table(const BnOperand& b, int grp, bool leader, float* tab) {
+    const int C = b.C;
+    const double invM = 1.0 / (double)b.rows_per_group;
+    for (int c = threadIdx.x; c < C; c += NT) {
+        float mean, var, istd, sc, sh;
+        stat_moments(b.stats + (size_t)grp * NREP * 2 * C, C, c, invM, b.eps, mean, var, istd);
+        bn_scale_shift(mean, istd, b.gamma[c], b.beta[c], sc, sh);
+        tab[c] = sc;
+        tab[C + c] = sh;
+        if (leader) {
+            const float unb = (b.rows_per_group > 1) ? (float)b.rows_per_group / (float)(b.rows_per_group - 1) : 1.f;
+            float rm = b.rm ? b.rm[c] : 0.f, rv = b.rm ? b.rv[c] : 0.f;
+            for (int g = 0; g < b.groups; ++g) {
+                float gm, gv, gi;
+                stat_moments(b.stats + (size_t)g * NREP * 2 * C, C, c, invM, b.eps, gm, gv, gi);
+                if (b.mi) { b.mi[(size_t)g * 2 * C + c] = gm; b.mi[(size_t)g * 2 * C + C + c] = gi; }
+                rm = (1.f - b.mom) * rm + b.mom * gm;
+                rv = (1.f - b.mom) * rv + b.mom * gv * unb;
+            }
+            if (b.rm) { b.rm[c] = rm; b.rv[c] = rv; }
+            if (c == 0 && b.nbt) *b.nbt += b.groups;
+        }
+    }
 }
 
 // Tuning hooks (tile overrides, per-workgroup timestamps, ablation switches) read environment variables.  They exist

@@ -51,6 +51,12 @@ struct ConvArgs {
     const float* ev_beta;
     float ev_eps;
     int ev_relu;
+    // bn_relu == 2: the ReLU sign of the consumer's BatchNorm output is recomputed from bn_x (that unit's activation
+    // was never written: it ran on its consumer's operand path), with the forward's own formula (common.h: bn_affine)
+    const float* bn_gamma;
+    const float* bn_beta;
+    // optional BatchNorm (+ ReLU) of the PRODUCER of x applied on this convolution's operand path (xf.stats != nullptr)
+    BnOperand xf;
 };
 
 // Per-workgroup timestamps and K-loop ablation switches exist in tuning builds only (`make TUNING=1`): in the product
@@ -90,6 +96,25 @@ static __device__ __forceinline__ void src_coord(int mode, int base, int t, int 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// LDS-DMA issued from inline assembly (weight-gradient kernels; the halo pieces of conv3x3_halo_kernel<.., XF>, whose
+// in-place transform the compiler would otherwise order behind EVERY DMA in flight: `s_waitcnt vmcnt(0)` per LDS store).  Through the builtin the compiler knows the
+// instruction writes LDS and -- it cannot prove which bytes -- puts `s_waitcnt vmcnt(0)` in front of the
+// transposing LDS reads of the K loop, which drains the tiles prefetched for the NEXT iterations as well and
+// serialises memory latency with the MFMAs.  The kernels order DMA against LDS reads themselves (explicit
+// vmcnt + one barrier per K tile), so the DMA is kept opaque.  M0 carries the wave-uniform LDS destination.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+static __device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r = {(int)(unsigned)b, (int)((unsigned)(b >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    return r;
+}
+static __device__ __forceinline__ void dma16_to_lds(i32x4 rsrc, const unsigned char* lds_dst, int voffset, int soffset) {
+    const unsigned m0 = (unsigned)(__UINTPTR_TYPE__)LDS_PTR(lds_dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(m0), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+
+
 // ---- the row pass of the epilogue: bf16 C tile [pixel][cout] in LDS -> 16-byte row pieces in memory, one variant per
 // fused epilogue.  Every thread owns one 8-channel vector of BP / RPP rows; the LDS reads and the global loads of up to
 // four rows are issued together (the pass is latency- and instruction-bound: ~40 % of a small-K 1x1 workgroup's life
@@ -97,6 +122,8 @@ static __device__ __forceinline__ void src_coord(int mode, int base, int t, int 
 // (v_pk_*_f32) on bf16 pairs unpacked with a shift / a mask.
 enum { EPI_PLAIN = 0, EPI_STATS, EPI_RES, EPI_RES_STATS, EPI_EV, EPI_BNX };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4r;
+#define RGDA_BNIN_MAX_C 512      /* most input channels a BatchNorm-on-the-operand-path launch serves (LDS table) */
 static __device__ __forceinline__ f32x2 bf2f_pair(unsigned u) {
     f32x2 r;
     r.x = __uint_as_float(u << 16);
@@ -117,10 +144,12 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
     const int co = c0 + cv * 8;
     const bool cok = co < a.Cout;
     f32x2 k0[4], k1[4];                                     // EV: scale, shift;  BNX: invstd, mean
+    f32x2 k2[4], k3[4];                                     // BNX with bn_relu == 2: scale, shift of the forward operand path
     f32x2 s2[4], q2[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         k0[e] = f32x2{0.f, 0.f}; k1[e] = f32x2{0.f, 0.f};
+        k2[e] = f32x2{0.f, 0.f}; k3[e] = f32x2{0.f, 0.f};
         s2[e] = f32x2{s[2 * e], s[2 * e + 1]}; q2[e] = f32x2{q[2 * e], q[2 * e + 1]};
     }
     if (KIND == EPI_BNX && cok) {
@@ -129,6 +158,15 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
         for (int e = 0; e < 4; ++e) {
             k1[e] = f32x2{mi[2 * e], mi[2 * e + 1]};
             k0[e] = f32x2{mi[a.Cout + 2 * e], mi[a.Cout + 2 * e + 1]};
+        }
+        if (a.bn_relu == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float sc, sh;
+                bn_scale_shift(k1[e >> 1][e & 1], k0[e >> 1][e & 1], a.bn_gamma[co + e], a.bn_beta[co + e], sc, sh);
+                k2[e >> 1][e & 1] = sc;
+                k3[e >> 1][e & 1] = sh;
+            }
         }
     }
     if (KIND == EPI_EV && cok) {
@@ -162,7 +200,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
                 }
                 if (KIND == EPI_BNX) {
                     xv[i] = *(const uint4*)(a.bn_x + (size_t)m * a.bn_ldx + co);
-                    if (a.bn_relu) {
+                    if (a.bn_relu == 1) {
                         if (a.bn_mask) bmb[i] = a.bn_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
                         else yv[i] = *(const uint4*)(a.bn_y + (size_t)m * a.bn_ldy + co);
                     }
@@ -221,7 +259,11 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         f32x2 g = bf2f_pair(ow[e]);
-                        if (a.bn_relu) {
+                        if (a.bn_relu == 2) {
+                            const f32x2 xx = bf2f_pair(xw[e]);
+                            g.x = (bn_affine(xx.x, k2[e].x, k3[e].x) > 0.f) ? g.x : 0.f;
+                            g.y = (bn_affine(xx.y, k2[e].y, k3[e].y) > 0.f) ? g.y : 0.f;
+                        } else if (a.bn_relu) {
                             if (a.bn_mask) {
                                 g.x = ((bmb[i] >> (2 * e)) & 1u) ? g.x : 0.f;
                                 g.y = ((bmb[i] >> (2 * e + 1)) & 1u) ? g.y : 0.f;
@@ -326,7 +368,11 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
     }
 }
 
-template <int BC, int BP, int STAGES = 3, int WC = 2, int WP = 2, bool PIPE = false>
+// XF: the pixel operand is  relu(BatchNorm(x))  of the producing convolution's RAW output x, applied on the way into LDS
+// (ConvArgs::xf, common.h: BnOperand): the rows travel global -> registers -> fma / max / bf16 -> ds_write_b128 instead of by
+// LDS-DMA (padding rows are written as zeros: the activation of a padding pixel is 0, not relu(shift)); the weight tiles
+// keep the DMA ring.  Written for the 2-stage ring (two workgroups per CU hide each other's load latency).
+template <int BC, int BP, int STAGES = 3, int WC = 2, int WP = 2, bool PIPE = false, bool XF = false>
 __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only
     constexpr int NW = WC * WP;                         // waves per workgroup
@@ -337,7 +383,9 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
     constexpr int CSTR = BC * 2 + 16;                   // epilogue row stride (bytes)
     constexpr int EPI = BP * CSTR + NW * BC * 2 * 4;
     constexpr int SMEM = (STAGES * TILE > EPI) ? STAGES * TILE : EPI;
-    __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM];
+    constexpr int XFTAB = XF ? RGDA_BNIN_MAX_C * 2 * 4 : 0;      // (scale, shift) of the operand's channels
+    static_assert(!XF || (STAGES == 2 && !PIPE), "the operand-transform loop is written for the 2-stage ring");
+    __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM + XFTAB];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -374,7 +422,9 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         xn[i] = n * a.H * a.W;
         if (a.mode == 0) { xh[i] = ho * a.stride - a.pad; xw[i] = wo * a.stride - a.pad; }
         else             { xh[i] = ho + a.pad;            xw[i] = wo + a.pad; }
-        xsw[i] = (lslot ^ ((r >> 1) & 7)) * 16;           // swizzle lives on the SOURCE side (LDS image is lane-linear)
+        // DMA: the swizzle lives on the SOURCE side (the LDS image is lane-linear); XF: the lane fetches its own logical
+        // slot (so that its channels, hence its scale / shift registers, are the same for every row) and swizzles the STORE
+        xsw[i] = XF ? lslot * 16 : (lslot ^ ((r >> 1) & 7)) * 16;
     }
     int wvo[WL];
 #pragma unroll
@@ -432,7 +482,83 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
     if (TDBG(a)) tq0 = __builtin_readcyclecounter();
     const int lrow = lane & 31, lk = lane >> 5;
     int stage = 0;
-    if constexpr (PIPE) {
+    if constexpr (XF) {
+        float* xtab = (float*)(smem + SMEM);
+        auto issue_w = [&](int st) {
+            unsigned char* wb = smem + st * TILE + wave * 1024;
+            const int so_w = (tap * a.Cin + ci0) * 2;
+#pragma unroll
+            for (int i = 0; i < WL; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * NW * 1024), 16, wvo[i], so_w, 0, 0);
+        };
+        u32x4r xr[XL];
+        bool xok[XL];
+        auto load_x = [&]() {
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                xok[i] = xvo[i] != OOB;
+                xr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xvo[i], ci0 * 2, 0);
+            }
+        };
+        issue_w(0);
+        load_x();
+        bn_operand_table<64 * NW>(a.xf, m0 / a.rows_per_group, logical == 0, xtab);
+        __syncthreads();
+        bf16x8 af[4][FI], bfr[4][FJ];
+        int ci_cur = 0;                                     // first channel of the tile held in xr
+        for (int kt = 0; kt < KT; ++kt) {
+            // ---- tile kt: registers -> BatchNorm + ReLU -> its LDS stage (the stage's last readers finished before the
+            // previous barrier); the weight tile of the same stage was DMA'd one iteration ago
+            {
+                float sc[8], sh[8];
+                const f32x4* ts = (const f32x4*)(xtab + ci_cur + lslot * 8);
+                const f32x4* th = (const f32x4*)(xtab + a.Cin + ci_cur + lslot * 8);
+                const f32x4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = h0[e]; sh[4 + e] = h1[e]; }
+                unsigned char* xb = smem + stage * TILE + BC * 128;
+#pragma unroll
+                for (int i = 0; i < XL; ++i) {
+                    const int r = (i * NW + wave) * 8 + lrow8;
+                    uint4 v = uint4{xr[i][0], xr[i][1], xr[i][2], xr[i][3]};
+                    v = xok[i] ? bn_operand8(v, sc, sh, a.xf.relu != 0) : uint4{0u, 0u, 0u, 0u};
+                    *(uint4*)(xb + r * 128 + ((lslot ^ ((r >> 1) & 7)) << 4)) = v;
+                }
+            }
+            WAIT_VMCNT(0);                                   // this wave's pieces of weight tile kt have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < KT) {
+                advance();
+                issue_w(stage ^ 1);
+                load_x();
+                ci_cur = ci0;
+            }
+            const unsigned char* wb = smem + stage * TILE;
+            const unsigned char* xb = wb + BC * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < FI; ++i) {
+                    int r = wc * (BC / WC) + i * 32 + lrow;
+                    af[kk][i] = *(const bf16x8*)(wb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    int r = wp * (BP / WP) + j * 32 + lrow;
+                    bfr[kk][j] = *(const bf16x8*)(xb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i], bfr[kk][j], acc[i][j], 0, 0, 0);
+            stage ^= 1;
+        }
+    } else if constexpr (PIPE) {
         // ---- software-pipelined K loop: the barrier of K tile kt+1 sits BETWEEN the two halves of tile kt's MFMAs.
         // Fragments of k-steps 0-1 of the next tile are read behind the barrier and land while k-steps 2-3 of this
         // tile run; fragments of k-steps 2-3 are read at the top and land while k-steps 0-1 run.  The MFMA stream of
@@ -575,7 +701,11 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
 //   LDS: two halo buffers (slab s + 1 lands while slab s is multiplied; its pieces are issued one per tap step) + a
 //   3-stage ring of weight tiles = 144 KB (D = 1) / 160 KB (D = 2); one barrier per tap step; the counted vmcnt wait
 //   lets exactly the pieces of the previous step stay in flight.
-template <int D, int TR>
+// XF (forward only): the halo holds the producing convolution's RAW output; every wave turns the pieces IT deposited into
+// relu(BatchNorm(x)) in place -- slab s + 1's piece i two tap steps after it was issued (the counted wait at the top of a
+// step leaves only the previous step's pieces in flight, and a wave needs no barrier to see its own DMA data); halo rows
+// outside the image stay the zeros the DMA deposited.  One 16-byte vector per thread and tap step.
+template <int D, int TR, bool XF = false>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TC = 32;                                  // pixel tile: TR image rows x the 32 columns of the map
@@ -585,8 +715,10 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     constexpr int XS = PXW * 64 * 128, WS = BC * 128;       // bytes of a halo buffer / a weight stage
     constexpr int CSTR = BC * 2 + 16, EPI = BP * CSTR + NW * BC * 2 * 4;
     constexpr int SMEM = 2 * XS + 3 * WS;
-    static_assert(EPI <= SMEM && SMEM <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM];
+    constexpr int XFTAB = XF ? RGDA_BNIN_MAX_C * 2 * 4 : 0;
+    static_assert(EPI <= SMEM && SMEM + XFTAB <= 160 * 1024, "LDS budget");
+    static_assert(!XF || PXW + 2 <= 9, "every piece of the next slab is transformed before the slab ends");
+    __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM + XFTAB];
     unsigned char* const sxb = smem;
     unsigned char* const swb = smem + 2 * XS;
 
@@ -617,17 +749,22 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
         const bool ok = h < NH && y >= 0 && y < a.H && x >= 0 && x < TC;
         hvo[i] = ok ? (((n * a.H + y) * TC + x) * a.ldx * 2 + (lslot ^ ((h >> 1) & 7)) * 16) : OOB;
     }
+    const i32x4 rs_wa = dma_rsrc(a.w, (unsigned)((size_t)a.Cout * 9 * a.Cin * 2));
     auto issue_w = [&](int q, int stage) {
         const int tap = q % 9, sl = q / 9;
         const int so = (tap * a.Cin + sl * 64) * 2;
         unsigned char* wb = swb + stage * WS + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * NW * 1024), 16, wvo[i], so, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (XF) dma16_to_lds(rs_wa, wb + i * NW * 1024, wvo[i], so);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * NW * 1024), 16, wvo[i], so, 0, 0);
+        }
     };
+    const i32x4 rs_xa = dma_rsrc(a.x, (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2));
     auto issue_h = [&](int sl, int i) {
         unsigned char* xb = sxb + (sl & 1) * XS + wave * 1024 + i * NW * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(xb), 16, hvo[i], sl * 128, 0, 0);
+        if constexpr (XF) dma16_to_lds(rs_xa, xb, hvo[i], sl * 128);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(xb), 16, hvo[i], sl * 128, 0, 0);
     };
 
     f32x16 acc[FI][FJ];
@@ -677,6 +814,31 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     for (int i = 0; i < PXW; ++i) issue_h(0, i);
     issue_w(0, 0);
     issue_w(1, 1);
+    // ---- XF: this thread's vector of halo piece k is row k * 64 + (t >> 3), LOGICAL slot lslot (the channels, hence the
+    // scale / shift registers, are the same for every row); those are bytes of the wave's own DMA instructions
+    float xsc[8], xsh[8];
+    float* const xtab = (float*)(smem + SMEM);
+    auto xf_load = [&](int sl) {
+        const f32x4* ts = (const f32x4*)(xtab + sl * 64 + lslot * 8);
+        const f32x4* th = (const f32x4*)(xtab + a.Cin + sl * 64 + lslot * 8);
+        const f32x4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xsc[e] = s0[e]; xsc[4 + e] = s1[e]; xsh[e] = h0[e]; xsh[4 + e] = h1[e]; }
+    };
+    auto xf_piece = [&](int sl, int k) {
+        if (hvo[k] == OOB) return;                          // padding (or beyond the halo): stays zero
+        const int h = k * 64 + (t >> 3);
+        unsigned char* p = sxb + (sl & 1) * XS + h * 128 + ((lslot ^ ((h >> 1) & 7)) << 4);
+        *(uint4*)p = bn_operand8(*(const uint4*)p, xsc, xsh, a.xf.relu != 0);
+    };
+    if constexpr (XF) {
+        bn_operand_table<512>(a.xf, m0 / a.rows_per_group, logical == 0, xtab);
+        WAIT_VMCNT(0);                                      // (the halo DMA is opaque to the compiler)
+        __syncthreads();                                    // the table; also every DMA of the prologue has landed
+        xf_load(0);
+#pragma unroll
+        for (int k = 0; k < PXW; ++k) xf_piece(0, k);
+    }
     int pend = 2, wstage = 0;
     bf16x8 fa0[2][FI], fb0[2][FJ], fa1[2][FI], fb1[2][FJ];
     for (int sl = 0; sl < S; ++sl) {
@@ -691,10 +853,17 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
                 case 2: WAIT_VMCNT(2); break;
                 default: WAIT_VMCNT(3); break;
             }
+            if constexpr (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the previous step's in-place transform
             __builtin_amdgcn_s_barrier();
             pend = 0;
             if (q + 2 < KT) { issue_w(q + 2, wstage >= 1 ? wstage - 1 : 2); pend += 2; }
             if (more && tp < PXW) { issue_h(sl + 1, tp); pend += 1; }
+            if constexpr (XF) {
+                if (more) {
+                    if (tp == 1) xf_load(sl + 1);
+                    if (tp >= 2 && tp - 2 < PXW) xf_piece(sl + 1, tp - 2);
+                }
+            }
             const unsigned char* wb = swb + wstage * WS;
             read_half(wb, xb, tp, 0, fa0, fb0);
             read_half(wb, xb, tp, 1, fa1, fb1);
@@ -875,13 +1044,32 @@ extern "C" int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, in
 }
 
 static int ilog2_exact(int v);
-struct BnBwdFuse { const void* y; int ldy; const unsigned char* mask; const void* x; int ldx; const float* mi; const float* nscale; int rpi; int relu; };
+struct BnBwdFuse { const void* y; int ldy; const unsigned char* mask; const void* x; int ldx; const float* mi; const float* nscale; int rpi; int relu; const float* gamma; const float* beta; };
 struct BnEvalFuse { const float* rm; const float* rv; const float* gamma; const float* beta; float eps; int relu; };
+
+// which kernel serves a convolution whose operand is a BatchNorm (+ ReLU) on the operand path: 1 = conv3x3_halo_kernel
+// <1, 4>, 2 = <1, 8>, 3 = conv_igemm_kernel<128, 128, 2, 2, 4, false, true>; 0 = none (the caller materialises the
+// activation with rgda_bn_train_apply and runs the plain convolution)
+static int conv_bnin_kind(long long M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H, int W, int Ho,
+                          int Wo, int groups) {
+    if (groups < 1 || (M % groups) || Cin > RGDA_BNIN_MAX_C || (Cin & 63)) return 0;
+    const int rpg = (int)(M / groups);
+    if (const int tr = conv_use_halo(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, rpg))
+        return (tr == 4) ? 1 : (dil == 1 ? 2 : 0);          // (dilation 2: its 160 KB of LDS leave no room for the table)
+    int bc, bp, stages;
+    if (pick_tile(M, Cout, (long long)kh * kw * Cin, rpg, bc, bp, stages)) return 0;
+    return (bc == 128 && bp == 128 && stages == 82) ? 3 : 0;
+}
+
+extern "C" int rgda_conv2d_bnin_supported(int64_t M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H,
+                                          int W, int Ho, int Wo, int groups) {
+    return conv_bnin_kind(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, groups) != 0;
+}
 
 static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
                          const unsigned char* res_mask, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int kh, int kw, int stride, int pad, int dil, int mode, const BnBwdFuse* bnb,
-                         rgda_stream_t stream, const BnEvalFuse* bne = nullptr) {
+                         rgda_stream_t stream, const BnEvalFuse* bne = nullptr, const rgda_bn_operand* bnin = nullptr) {
     if (!x || !wgt || !y) return RGDA_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || dil <= 0 || pad < 0 || (mode != 0 && mode != 1))
@@ -906,13 +1094,16 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
     if (M % stat_groups) return RGDA_ERR_ARG;
     a.rows_per_group = (int)(M / stat_groups);
     a.bn_y = a.bn_x = nullptr; a.bn_mask = nullptr; a.bn_mi = a.bn_nscale = nullptr; a.bn_ldy = a.bn_ldx = a.bn_rpi = a.bn_relu = 0;
+    a.bn_gamma = a.bn_beta = nullptr;
     if (bnb) {
-        if (!stats || !bnb->x || !bnb->mi || (bnb->relu && !bnb->y && !bnb->mask) || (bnb->ldx & 7) ||
-            (bnb->relu && bnb->y && (bnb->ldy & 7)) || (bnb->nscale && bnb->rpi <= 0))
+        if (!stats || !bnb->x || !bnb->mi || (bnb->relu == 1 && !bnb->y && !bnb->mask) || (bnb->ldx & 7) ||
+            (bnb->relu == 1 && bnb->y && (bnb->ldy & 7)) || (bnb->nscale && bnb->rpi <= 0) || bnb->relu < 0 || bnb->relu > 2)
             return RGDA_ERR_ARG;
-        a.bn_mask = bnb->relu ? bnb->mask : nullptr;
+        a.bn_mask = bnb->relu == 1 ? bnb->mask : nullptr;
         a.bn_y = (const bf16_t*)bnb->y; a.bn_x = (const bf16_t*)bnb->x; a.bn_mi = bnb->mi; a.bn_nscale = bnb->nscale;
         a.bn_ldy = bnb->ldy; a.bn_ldx = bnb->ldx; a.bn_rpi = bnb->rpi; a.bn_relu = bnb->relu;
+        if (bnb->relu == 2 && (!bnb->gamma || !bnb->beta)) return RGDA_ERR_ARG;
+        a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
     }
     a.ev_rm = a.ev_rv = a.ev_gamma = a.ev_beta = nullptr; a.ev_eps = 0.f; a.ev_relu = 0;
     if (bne) {
@@ -923,6 +1114,33 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
     a.dbg = nullptr; a.skip = 0;
     if (const char* e = TUNE_ENV("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
     if (const char* e = TUNE_ENV("RGDA_CONV_SKIP")) a.skip = atoi(e);                                      // tuning only
+    a.xf.stats = nullptr;
+    if (bnin) {
+        // BatchNorm (+ ReLU) of the producer on this convolution's operand path: forward only, statistics groups = the
+        // operand's groups (whole images), a kernel that carries the transform
+        if (mode != 0 || bne || bnb || !bnin->stats || !bnin->gamma || !bnin->beta || bnin->groups != stat_groups ||
+            ((long long)N * H * W) % bnin->groups || (bnin->running_mean == nullptr) != (bnin->running_var == nullptr))
+            return RGDA_ERR_ARG;
+        if ((long long)N * H * W / bnin->groups < 2) return RGDA_ERR_ARG;      // "Expected more than 1 value per channel"
+        const int kind = conv_bnin_kind(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, stat_groups);
+        if (!kind) return RGDA_ERR_UNSUPPORTED;
+        a.xf.stats = bnin->stats; a.xf.gamma = bnin->gamma; a.xf.beta = bnin->beta; a.xf.mi = bnin->mi;
+        a.xf.rm = bnin->running_mean; a.xf.rv = bnin->running_var; a.xf.nbt = (long long*)bnin->num_batches_tracked;
+        a.xf.eps = bnin->eps; a.xf.mom = bnin->momentum; a.xf.groups = bnin->groups; a.xf.relu = bnin->relu; a.xf.C = Cin;
+        a.xf.rows_per_group = (int)((long long)N * H * W / bnin->groups);
+        hipStream_t st2 = to_stream(stream);
+        if (kind == 3) {
+            a.tiles_c = cdiv(Cout, 128); a.tiles_p = cdiv(M, 128);
+            conv_igemm_kernel<128, 128, 2, 2, 4, false, true><<<a.tiles_c * a.tiles_p, 512, 0, st2>>>(a);
+        } else {
+            const int tr = kind == 1 ? 4 : 8;
+            a.tiles_c = cdiv(Cout, 128); a.tiles_p = (int)(M / (tr * 32));
+            if (kind == 1) conv3x3_halo_kernel<1, 4, true><<<a.tiles_c * a.tiles_p, 512, 0, st2>>>(a);
+            else conv3x3_halo_kernel<1, 8, true><<<a.tiles_c * a.tiles_p, 512, 0, st2>>>(a);
+        }
+        RGDA_CHECK_LAUNCH();
+        return RGDA_OK;
+    }
     // layer1's 64 -> 64 3x3 on 128-wide maps: weights-resident rolling-window kernel, one workgroup per CU
     {
         int c64_on = 1;
@@ -999,13 +1217,22 @@ extern "C" int rgda_conv2d_bneval(const void* x, int ldx, const void* wgt, void*
                          pad, dil, 0, nullptr, stream, &e);
 }
 
+extern "C" int rgda_conv2d_bnin(const rgda_bn_operand* bn_in, const void* x, int ldx, const void* wgt, void* y, int ldy,
+                                const void* res, int ldres, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin,
+                                int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, rgda_stream_t stream) {
+    if (!bn_in) return RGDA_ERR_ARG;
+    return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, nullptr, stats, stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
+                         pad, dil, 0, nullptr, stream, nullptr, bn_in);
+}
+
 extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
                                  const uint8_t* res_relu_mask, rgda_stat_t* sums, int groups, const void* bn_y, int bn_ldy, const uint8_t* bn_relu_mask,
                                  const void* bn_x, int bn_ldx,
-                                 const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu, int N,
+                                 const float* bn_mi, const float* bn_nscale, int rows_per_image, int relu,
+                                 const float* bn_gamma, const float* bn_beta, int N,
                                  int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
                                  int dil, int mode, rgda_stream_t stream) {
-    BnBwdFuse b = {bn_y, bn_ldy, bn_relu_mask, bn_x, bn_ldx, bn_mi, bn_nscale, rows_per_image, relu};
+    BnBwdFuse b = {bn_y, bn_ldy, bn_relu_mask, bn_x, bn_ldx, bn_mi, bn_nscale, rows_per_image, relu, bn_gamma, bn_beta};
     return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, res_relu_mask, sums, groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw,
                          stride, pad, dil, mode, &b, stream);
 }
@@ -1142,6 +1369,7 @@ static int stem_conv_launch(const float* img, const void* wgt, void* y, int ldy,
     a.rows_per_group = (int)(M / stat_groups);
     a.howo_shift = a.wo_shift = -1; a.dbg = nullptr; a.tpw = 0; a.skip = 0;
     a.bn_y = a.bn_x = nullptr; a.bn_mask = nullptr; a.bn_mi = a.bn_nscale = nullptr; a.bn_ldy = a.bn_ldx = a.bn_rpi = a.bn_relu = 0;
+    a.bn_gamma = a.bn_beta = nullptr; a.xf.stats = nullptr;
     a.ev_rm = a.ev_rv = a.ev_gamma = a.ev_beta = nullptr; a.ev_eps = 0.f; a.ev_relu = 0;
     if (bne) {
         if (!bne->rm || !bne->rv || !bne->gamma || !bne->beta) return RGDA_ERR_ARG;
@@ -1497,23 +1725,6 @@ struct WgradGroup {
     int first[RGDA_WGRAD_MAXG + 1];
     WgradArgs a[RGDA_WGRAD_MAXG];
 };
-
-// LDS-DMA issued from inline assembly (weight-gradient kernels).  Through the builtin the compiler knows the
-// instruction writes LDS and -- it cannot prove which bytes -- puts `s_waitcnt vmcnt(0)` in front of the
-// transposing LDS reads of the K loop, which drains the tiles prefetched for the NEXT iterations as well and
-// serialises memory latency with the MFMAs.  The kernels order DMA against LDS reads themselves (explicit
-// vmcnt + one barrier per K tile), so the DMA is kept opaque.  M0 carries the wave-uniform LDS destination.
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-static __device__ __forceinline__ i32x4 dma_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long b = (unsigned long long)base;
-    i32x4 r = {(int)(unsigned)b, (int)((unsigned)(b >> 32) & 0xffffu), (int)bytes, 0x00020000};
-    return r;
-}
-static __device__ __forceinline__ void dma16_to_lds(i32x4 rsrc, const unsigned char* lds_dst, int voffset, int soffset) {
-    const unsigned m0 = (unsigned)(__UINTPTR_TYPE__)LDS_PTR(lds_dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(m0), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
-}
 
 // wait until at most `tiles` of the most recently issued K tiles (LD DMA instructions each) are still in flight
 template <int LD>

@@ -144,18 +144,6 @@ extern "C" int rgda_bn_stats(const void* x, int ldx, rgda_stat_t* stats, int64_t
 }
 
 // ------------------------------------------------------------------ BN finalize
-// mean, biased variance and 1 / sqrt(var + eps) of channel c from one row group's accumulators: fp64 from the exact
-// integer totals (every consumer goes through here, so forward, backward and the running update see the same values)
-static __device__ __forceinline__ void stat_moments(const rgda_stat_t* __restrict__ st, int C, int c, double invM, float eps,
-                                                    float& mean, float& var, float& istd) {
-    const double m = stat_total(st, C, c, 0, RGDA_STAT_FRAC_FWD) * invM;
-    double v = stat_total(st, C, c, 1, RGDA_STAT_FRAC_FWD) * invM - m * m;
-    if (v < 0.0) v = 0.0;
-    mean = (float)m;
-    var = (float)v;
-    istd = 1.f / sqrtf((float)v + eps);       // (fp32: a double-precision sqrt + divide per channel shows in the apply passes)
-}
-
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const rgda_stat_t* stats, float* mi, float* rm, float* rv,
                                                           long long* nbt, double M, int C, int groups, float eps,
                                                           float mom) {
@@ -391,7 +379,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ x, int ldx,
                                                             const float* __restrict__ mi, const float* __restrict__ nscale,
                                                             int rpi, rgda_stat_t* sums, long long M, int C, int relu, int vpb,
-                                                            int rpb, int rows_per_block, int bpg) {
+                                                            int rpb, int rows_per_block, int bpg,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta) {
     __shared__ float lds[256 * 16];
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
@@ -401,9 +390,13 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
     sums += (size_t)grp * NREP * 2 * C;
     float s[8] = {0}, q[8] = {0};
     if (cok) {
-        float mean[8], istd[8];
+        float mean[8], istd[8], fsc[8], fsh[8];      // fsc / fsh: the forward operand path's (scale, shift), relu == 2 only
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { mean[e] = mi[cg + e]; istd[e] = mi[C + cg + e]; }
+        for (int e = 0; e < 8; ++e) {
+            mean[e] = mi[cg + e]; istd[e] = mi[C + cg + e];
+            fsc[e] = 0.f; fsh[e] = 0.f;
+            if (relu == 2) bn_scale_shift(mean[e], istd[e], gamma[cg + e], beta[cg + e], fsc[e], fsh[e]);
+        }
         long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
         long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
         for (long long rb = r0 + rl; rb < r1; rb += (long long)rpb * RB_REDUCE) {
@@ -415,7 +408,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                 if (r < r1) {
                     gv[u] = *(const u16x8*)(g + r * ldg + cg);
                     xv[u] = *(const u16x8*)(x + r * ldx + cg);
-                    if (relu) {
+                    if (relu == 1) {
                         if (rmask) mb[u] = rmask[r * (C >> 3) + (cg >> 3)];
                         else yv[u] = *(const u16x8*)(y + r * ldy + cg);
                     }
@@ -428,7 +421,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                 float gf[8], xf[8];
                 cvt8(gv[u], gf);
                 cvt8(xv[u], xf);
-                if (relu) {
+                if (relu == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gf[e] = (bn_affine(xf[e], fsc[e], fsh[e]) > 0.f) ? gf[e] : 0.f;
+                } else if (relu) {
                     if (rmask) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) gf[e] = ((mb[u] >> e) & 1u) ? gf[e] : 0.f;
@@ -455,8 +451,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
 
 extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy, const uint8_t* relu_mask,
                                   const void* x, int ldx, const float* mi, const float* nscale, int rows_per_image,
-                                  rgda_stat_t* sums, int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
-    if (!g || !x || !mi || !sums || (relu && !y && !relu_mask) || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || (ldx & 7)) return RGDA_ERR_ARG;
+                                  rgda_stat_t* sums, int64_t M, int C, int relu, const float* gamma, const float* beta,
+                                  int groups, rgda_stream_t stream) {
+    if (!g || !x || !mi || !sums || (relu == 1 && !y && !relu_mask) || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || (ldx & 7)) return RGDA_ERR_ARG;
+    if (relu < 0 || relu > 2 || (relu == 2 && (!gamma || !beta))) return RGDA_ERR_ARG;
     if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     hipStream_t st = to_stream(stream);
     RowLayout L = row_layout(C);
@@ -472,7 +470,7 @@ extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy
     dim3 grid(bpg * groups, cdiv(L.vpr, L.vpb));
     bn_bwd_reduce_kernel<<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask, (const bf16_t*)x, ldx, mi,
                                                nscale, rows_per_image, sums, Mg, C, relu, L.vpb, L.rpb, rows_per_block,
-                                               bpg);
+                                               bpg, gamma, beta);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
@@ -486,7 +484,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const rgda_stat_t* __restrict__ sums, bf16_t* __restrict__ dx,
                                                            int lddx, bf16_t* __restrict__ gmask, int ldgm, float* dgamma,
                                                            float* dbeta, long long M, int C, int relu, int vpb, int rpb,
-                                                           int rows_per_block, int bpg) {
+                                                           int rows_per_block, int bpg, const float* __restrict__ beta,
+                                                           bf16_t* __restrict__ act_out, int ldact) {
     const int cvl = threadIdx.x % vpb, rl = threadIdx.x / vpb;
     const int cg = (blockIdx.y * vpb + cvl) * 8;
     const int grp = blockIdx.x / bpg, chunk = blockIdx.x % bpg;     // M = rows of ONE group
@@ -495,9 +494,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     // per-channel constants of the workgroup's vpb * 8 channels: one channel per thread (coalesced across threads; the
     // 2 * NREP replicated partial sums are 16 loads per CHANNEL, not per thread: 16 row lanes used to fetch the same 38
     // vectors each, more load instructions than the rows a workgroup streams), shared through LDS
-    extern __shared__ __attribute__((aligned(16))) float sk_dyn[];      // [5][vpb * 8]
+    extern __shared__ __attribute__((aligned(16))) float sk_dyn[];      // [6][vpb * 8]
     const int nch = vpb * 8;
-    float* const sk0 = sk_dyn;          // mean, istd, k0 = gamma * istd, k1 = sum(g') / M, k2 = sum(g' xhat) / M
+    float* const sk0 = sk_dyn;          // mean, istd, k0 = gamma * istd, k1 = sum(g') / M, k2 = sum(g' xhat) / M,
+                                        // (relu == 2) the forward operand path's shift (its scale is k0)
     const float invM = 1.f / (float)M;
     for (int c = threadIdx.x; c < vpb * 8; c += 256) {
         const int cc = blockIdx.y * vpb * 8 + c;
@@ -510,6 +510,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             sk0[2 * nch + c] = gamma[cc] * is;
             sk0[3 * nch + c] = t1 * invM;
             sk0[4 * nch + c] = t2 * invM;
+            if (relu == 2) {
+                float fsc, fsh;
+                bn_scale_shift(mi[cc], is, gamma[cc], beta[cc], fsc, fsh);      // fsc == sk0[2][c]: the same product
+                sk0[5 * nch + c] = fsh;
+            }
             if (chunk == 0 && grp == 0 && dgamma) {
                 // ONE workgroup per channel block folds the sums of every group into the parameter gradients, group
                 // after group (a fixed order: nothing depends on which group's workgroup retires first).  The add itself
@@ -528,7 +533,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     }
     __syncthreads();
     if (cg >= C) return;
-    float mean[8], istd[8], k0[8], k1[8], k2[8];
+    float mean[8], istd[8], k0[8], k1[8], k2[8], fsh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         mean[e] = sk0[0 * nch + cvl * 8 + e];
@@ -536,6 +541,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
         k0[e] = sk0[2 * nch + cvl * 8 + e];
         k1[e] = sk0[3 * nch + cvl * 8 + e];
         k2[e] = sk0[4 * nch + cvl * 8 + e];
+        fsh[e] = (relu == 2) ? sk0[5 * nch + cvl * 8 + e] : 0.f;
     }
     long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
@@ -548,7 +554,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             if (r < r1) {
                 gv[u] = *(const u16x8*)(g + r * ldg + cg);
                 xv[u] = *(const u16x8*)(x + r * ldx + cg);
-                if (relu) {
+                if (relu == 1) {
                     if (rmask) mb[u] = rmask[r * (C >> 3) + (cg >> 3)];
                     else yv[u] = *(const u16x8*)(y + r * ldy + cg);
                 }
@@ -561,7 +567,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             float gf[8], xf[8];
             cvt8(gv[u], gf);
             cvt8(xv[u], xf);
-            if (relu) {
+            if (relu == 2) {
+                // the unit's activation was never written (it ran on its consumer's operand path): its ReLU sign, and
+                // the activation itself for the consumer's weight gradient, are recomputed with the forward's own formula
+                float af[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    af[e] = bn_affine(xf[e], k0[e], fsh[e]);
+                    gf[e] = (af[e] > 0.f) ? gf[e] : 0.f;
+                    af[e] = fmaxf(af[e], 0.f);
+                }
+                if (act_out) store8(act_out + r * ldact + cg, af);
+            } else if (relu) {
                 if (rmask) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gf[e] = ((mb[u] >> e) & 1u) ? gf[e] : 0.f;
@@ -590,17 +607,20 @@ extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy,
                                  const void* x, int ldx,
                                  const float* mi, const float* gamma, const float* nscale, int rows_per_image,
                                  const rgda_stat_t* sums, void* dx, int lddx, void* gmask, int ldgm, float* dgamma,
-                                 float* dbeta, int64_t M, int C, int relu, int groups, rgda_stream_t stream) {
-    if (!g || !x || !mi || !gamma || !sums || !dx || (relu && !y && !relu_mask) || M <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
+                                 float* dbeta, int64_t M, int C, int relu, const float* beta, void* act_out, int ldact,
+                                 int groups, rgda_stream_t stream) {
+    if (!g || !x || !mi || !gamma || !sums || !dx || (relu == 1 && !y && !relu_mask) || M <= 0 || C <= 0 || (C & 7)) return RGDA_ERR_ARG;
+    if (relu < 0 || relu > 2 || (relu == 2 && !beta) || (act_out && (relu != 2 || (ldact & 7) || ldact < C))) return RGDA_ERR_ARG;
     if ((ldg & 7) || (ldx & 7) || (lddx & 7) || (gmask && (ldgm & 7)) || ((dgamma == nullptr) != (dbeta == nullptr)))
         return RGDA_ERR_ARG;
     if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     RowLayout L; int rpbk, bpg; dim3 grid;
     elementwise_grid(M / groups, C, groups, L, rpbk, bpg, grid);
-    bn_bwd_apply_kernel<<<grid, 256, (size_t)5 * L.vpb * 8 * sizeof(float), to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask,
+    bn_bwd_apply_kernel<<<grid, 256, (size_t)6 * L.vpb * 8 * sizeof(float), to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask,
                                                               (const bf16_t*)x, ldx, mi, gamma, nscale, rows_per_image,
                                                               sums, (bf16_t*)dx, lddx, (bf16_t*)gmask, ldgm, dgamma,
-                                                              dbeta, M / groups, C, relu, L.vpb, L.rpb, rpbk, bpg);
+                                                              dbeta, M / groups, C, relu, L.vpb, L.rpb, rpbk, bpg, beta,
+                                                              (bf16_t*)act_out, ldact);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
@@ -674,6 +694,80 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const bf16_t* __restri
         }
     }
     store8(gx + (size_t)p * C + cv * 8, acc);
+}
+
+// The stem's MaxPool with conv1's BatchNorm + ReLU applied on ITS operand path (rgda_bn_operand): x is the RAW output of
+// the stem convolution, the pooled value is max over the window of relu(fma(x, scale, shift)) -- the 134 MB activation of
+// 16 images of 512 x 512 is never written or read back.  Workgroups own whole rows of ONE image (one statistics group).
+__global__ void __launch_bounds__(256) maxpool_fwd_bnin_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                               uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho,
+                                                               int Wo, BnOperand b, int blocks_per_image) {
+    extern __shared__ __attribute__((aligned(16))) float mp_tab[];         // [2][C]
+    const int vpr = C / 8;
+    const int n = blockIdx.x / blocks_per_image;
+    const long long per_image = (long long)Ho * Wo * vpr;
+    const long long i = (long long)(blockIdx.x % blocks_per_image) * 256 + threadIdx.x;
+    bn_operand_table<256>(b, n / (N / b.groups), blockIdx.x == 0, mp_tab);
+    __syncthreads();
+    if (i >= per_image) return;
+    const int cv = (int)(i % vpr);
+    const long long p = i / vpr;
+    const int wo = (int)(p % Wo), ho = (int)(p / Wo);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = mp_tab[cv * 8 + e]; sh[e] = mp_tab[C + cv * 8 + e]; }
+    float best[8];
+    unsigned char bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    bool first = true;
+    for (int kh = 0; kh < 3; ++kh) {
+        int hi = ho * 2 - 1 + kh;
+        if (hi < 0 || hi >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            int wi = wo * 2 - 1 + kw;
+            if (wi < 0 || wi >= W) continue;
+            float f[8];
+            load8(x + ((size_t)(n * H + hi) * W + wi) * C + cv * 8, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                // the value the materialised activation would hold: rounded to bf16 before the comparison
+                float a = bn_affine(f[e], sc[e], sh[e]);
+                if (b.relu) a = fmaxf(a, 0.f);
+                a = bf2f(f2bf(a));
+                if (first || a > best[e]) { best[e] = a; bi[e] = (unsigned char)(kh * 3 + kw); }
+            }
+            first = false;
+        }
+    }
+    const size_t o = ((size_t)n * Ho * Wo + p) * C + cv * 8;
+    store8(y + o, best);
+    uint2 pk;
+    pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
+    pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
+    *(uint2*)(idx + o) = pk;
+}
+
+extern "C" int rgda_maxpool_fwd_bnin(const rgda_bn_operand* bn_in, const void* x, void* y, uint8_t* idx, int N, int H, int W,
+                                     int C, int Ho, int Wo, rgda_stream_t stream) {
+    if (!bn_in || !x || !y || !idx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || C > 512) return RGDA_ERR_ARG;
+    if (Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return RGDA_ERR_ARG;
+    if (!bn_in->stats || !bn_in->gamma || !bn_in->beta || bn_in->groups < 1 || (N % bn_in->groups) ||
+        (bn_in->running_mean == nullptr) != (bn_in->running_var == nullptr))
+        return RGDA_ERR_ARG;
+    if ((long long)N * H * W / bn_in->groups < 2) return RGDA_ERR_ARG;
+    BnOperand b;
+    b.stats = bn_in->stats; b.gamma = bn_in->gamma; b.beta = bn_in->beta; b.mi = bn_in->mi;
+    b.rm = bn_in->running_mean; b.rv = bn_in->running_var; b.nbt = (long long*)bn_in->num_batches_tracked;
+    b.eps = bn_in->eps; b.mom = bn_in->momentum; b.groups = bn_in->groups; b.relu = bn_in->relu; b.C = C;
+    b.rows_per_group = (int)((long long)N * H * W / bn_in->groups);
+    const long long per_image = (long long)Ho * Wo * (C / 8);
+    const int bpi = cdiv(per_image, 256);
+    if ((long long)bpi * N > 0x7fffffffLL) return RGDA_ERR_ARG;
+    maxpool_fwd_bnin_kernel<<<bpi * N, 256, (size_t)2 * C * sizeof(float), to_stream(stream)>>>(
+        (const bf16_t*)x, (bf16_t*)y, idx, N, H, W, C, Ho, Wo, b, bpi);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
 }
 
 extern "C" int rgda_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho, int Wo,

@@ -223,6 +223,21 @@ class _Container(nn.Module):
     pass
 
 
+class _Lazy:
+    """The output of a conv + BatchNorm (+ ReLU) unit whose BatchNorm has NOT been applied: the raw convolution output
+    `c` and the statistic accumulators.  The consuming convolution applies relu(BatchNorm(c)) on its operand path
+    (ops.conv2d_bnin) where a kernel carries the transform; otherwise `_materialise` runs the ordinary apply pass."""
+    __slots__ = ('key', 'c', 'stats', 'bn', 'G', 'relu', 'M', 'shape')
+
+    def __init__(self, key, c, stats, bn, G, relu, M):
+        self.key, self.c, self.stats, self.bn, self.G, self.relu, self.M = key, c, stats, bn, G, relu, M
+        self.shape = c.shape
+
+
+FROM_X = 'sign-from-x'      # tape marker (in the ReLU-mask slot): the unit's activation was never written; the backward
+                            # kernels recompute its ReLU sign from the raw convolution output (relu == 2)
+
+
 def _attach(root, dotted, kind, tensor):
     """Register `tensor` as parameter/buffer under the reference's dotted name, creating containers."""
     parts = dotted.split('.')
@@ -292,6 +307,10 @@ class Deeplabv2(nn.Module):
         self.fused_stem = True           # conv1 straight from the image where the map width allows it (rgda_stem_conv)
         self.fused_stem_wgrad = True     # ... and its weight gradient too (rgda_stem_wgrad): no patch matrix at all
         self.parallel_ds = True          # downsample branches on the head stream
+        # bn1 / bn2 (+ ReLU) of every bottleneck and the stem's bn1 run on the CONSUMER's operand path (the next
+        # convolution / the max-pool) wherever a kernel carries the transform: the activation is never written in the
+        # forward pass (ops.conv2d_bnin).  False = one rgda_bn_train_apply pass per unit (the cross-check)
+        self.bn_on_operand = True
         self._head_stream = None
         self._mat_cache = {}
         self._synced_version = -1
@@ -667,7 +686,31 @@ class Deeplabv2(nn.Module):
                 ops.conv2d(x[g * Ng * H * W:(g + 1) * Ng * H * W], w, c[ro], Ng, H,
                            W, Ho, Wo, k, k, stride, pad, dil, 0, None if res is None else res[ro], st[g], 1)
 
-    def _cbr_fwd(self, T, key, conv, bn, x, N, H, W, relu, res=None, nscale=None, wb=None, geom=None):
+    def _materialise(self, T, lz):
+        """The ordinary apply pass for a deferred unit whose consumer has no operand-transform kernel."""
+        mi = torch.empty(lz.G, 2, lz.bn.c, device=self.device)
+        y = torch.empty(lz.M, lz.bn.c, dtype=BF, device=self.device)
+        rmask = (torch.empty(lz.M, lz.bn.c // 8, dtype=torch.uint8, device=self.device)
+                 if (lz.relu and self.relu_sign_mask and lz.bn.c >= self.relu_sign_mask) else None)
+        geom = T[lz.key][4]
+        ops.bn_train_apply(lz.c, lz.stats, mi, lz.bn.rm, lz.bn.rv, lz.bn.nbt, lz.bn.gamma, lz.bn.beta, y, lz.M, lz.bn.c,
+                           lz.relu, None, None, geom[3] * geom[4], groups=lz.G, relu_mask=rmask)
+        e = T[lz.key]
+        T[lz.key] = (e[0], e[1], y, mi, e[4], e[5], rmask)
+        return y
+
+    def _bn_operand(self, T, lz):
+        """rgda_bn_operand of a deferred unit + its tape entry: (mean, invstd) are written by the consumer's launch."""
+        mi = torch.empty(lz.G, 2, lz.bn.c, device=self.device)
+        e = T[lz.key]
+        T[lz.key] = (e[0], e[1], None, mi, e[4], e[5], FROM_X)
+        bnop = ops.bn_operand(lz.stats, lz.bn.gamma, lz.bn.beta, mi, lz.bn.rm, lz.bn.rv, lz.bn.nbt, lz.G, lz.relu)
+        T['keep'].append(bnop)
+        return bnop
+
+    def _cbr_fwd(self, T, key, conv, bn, x, N, H, W, relu, res=None, nscale=None, wb=None, geom=None, defer=False):
+        """conv + BatchNorm (+ residual + ReLU) unit.  `x` may be a deferred unit (_Lazy): its BatchNorm + ReLU then runs on
+        this convolution's operand path.  defer=True (training only): return this unit deferred in turn."""
         Ho, Wo = conv.out_hw(H, W) if geom is None else geom
         M = N * Ho * Wo
         train = T is not None
@@ -680,29 +723,35 @@ class Deeplabv2(nn.Module):
             else:
                 ops.conv2d_bneval(x, wb, y, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1, bn.rm, bn.rv, bn.gamma, bn.beta, relu, res)
             return y, Ho, Wo
+        if M // G < 2:
+            raise ValueError('Expected more than 1 value per channel when training')
         c = torch.empty(M, conv.co, dtype=BF, device=self.device)
         stats = T['stats_pool'].take(G * NREP * 2 * conv.co) if train else None
-        if geom is None:
-            self._conv_stats(x, conv.wb if wb is None else wb, c, stats, G, N, H, W, Ho, Wo, conv.k, conv.stride,
-                             conv.pad, conv.dil)
-        else:       # stem: GEMM over the im2col matrix
-            self._conv_stats(x, wb, c, stats, G, N, Ho, Wo, Ho, Wo, 1, 1, 0, 1)
+        if isinstance(x, _Lazy):
+            if geom is None and ops.conv2d_bnin_supported(M, conv.co, conv.ci, conv.k, conv.k, conv.stride, conv.pad,
+                                                          conv.dil, H, W, Ho, Wo, G):
+                ops.conv2d_bnin(self._bn_operand(T, x), x.c, conv.wb if wb is None else wb, c, N, H, W, Ho, Wo, conv.k,
+                                conv.k, conv.stride, conv.pad, conv.dil, None, stats, G)
+            else:
+                x = self._materialise(T, x)
+        if not isinstance(x, _Lazy):
+            if geom is None:
+                self._conv_stats(x, conv.wb if wb is None else wb, c, stats, G, N, H, W, Ho, Wo, conv.k, conv.stride,
+                                 conv.pad, conv.dil)
+            else:       # stem: GEMM over the im2col matrix
+                self._conv_stats(x, wb, c, stats, G, N, Ho, Wo, Ho, Wo, 1, 1, 0, 1)
+        if defer and self.bn_on_operand and res is None and nscale is None:
+            T[key] = (x, c, None, None, (N, H, W, Ho, Wo), None, None)      # completed by the consumer (_bn_operand / _materialise)
+            return _Lazy(key, c, stats, bn, G, relu, M), Ho, Wo
         mi = torch.empty(G, 2, conv.co, device=self.device)
         y = torch.empty(M, conv.co, dtype=BF, device=self.device)
-        if train:
-            if M // G < 2:
-                raise ValueError('Expected more than 1 value per channel when training')
-            # the backward pass needs only the SIGN of y (ReLU): one bit per element written next to y.  The byte
-            # stores cost the forward ~2 us per launch, so only wide units do it (see relu_sign_mask).
-            rmask = (torch.empty(M, conv.co // 8, dtype=torch.uint8, device=self.device)
-                     if (relu and self.relu_sign_mask and conv.co >= self.relu_sign_mask) else None)
-            ops.bn_train_apply(c, stats, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale,
-                               Ho * Wo, groups=G, relu_mask=rmask)
-        else:
-            ops.bn_finalize(None, mi, bn.rm, bn.rv, None, M, conv.co)
-            ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale, Ho * Wo, groups=G)
-        if train:
-            T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale, rmask)
+        # the backward pass needs only the SIGN of y (ReLU): one bit per element written next to y.  The byte
+        # stores cost the forward ~2 us per launch, so only wide units do it (see relu_sign_mask).
+        rmask = (torch.empty(M, conv.co // 8, dtype=torch.uint8, device=self.device)
+                 if (relu and self.relu_sign_mask and conv.co >= self.relu_sign_mask) else None)
+        ops.bn_train_apply(c, stats, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, y, M, conv.co, relu, res, nscale,
+                           Ho * Wo, groups=G, relu_mask=rmask)
+        T[key] = (x, c, y, mi, (N, H, W, Ho, Wo), nscale, rmask)
         return y, Ho, Wo
 
     def _head_last_fwd(self, T, head, xn, qs, N, h, w, nscale):
@@ -872,17 +921,29 @@ class Deeplabv2(nn.Module):
         `dx_res` (+ optional ReLU sign mask gating it) is added to the data gradient in the same epilogue."""
         x, c, y, mi, (N, H, W, Ho, Wo), nscale, rmask = T[key]
         M, C, G = N * Ho * Wo, conv.co, T['groups']
+        # a unit whose BatchNorm + ReLU ran on its consumer's operand path: no y, no sign mask -- the ReLU sign is recomputed
+        # from c (relu == 2), and the activation the consumer's WEIGHT gradient needs is written by our backward apply
+        from_x = rmask is FROM_X
+        rl = 2 if (from_x and relu) else relu
+        if from_x:
+            rmask = None
         sums = T.pop('sums:' + key, None)
         if sums is None:
             sums = T.pop('presums:' + key, None)        # arena slice reserved by a producer that could not fuse
             if sums is None:
                 sums = T['sums_pool'].take(G * NREP * 2 * C)
-            ops.bn_bwd_reduce(g, y if (relu and rmask is None) else None, c, mi, sums, M, C, relu, nscale, Ho * Wo,
-                              groups=G, relu_mask=rmask)
+            ops.bn_bwd_reduce(g, y if (rl == 1 and rmask is None) else None, c, mi, sums, M, C, rl, nscale, Ho * Wo,
+                              groups=G, relu_mask=rmask, gamma=bn.gamma, beta=bn.beta)
         dc = torch.empty(M, C, dtype=BF, device=self.device)
         gm = torch.empty(M, C, dtype=BF, device=self.device) if want_gmask else None
-        ops.bn_bwd_apply(g, y if (relu and rmask is None) else None, c, mi, bn.gamma, sums, dc, M, C, relu, gm,
-                         bn.dgamma, bn.dbeta, nscale, Ho * Wo, groups=G, relu_mask=rmask)
+        deferred = T.pop('wgrad_deferred:' + key, None)
+        act = torch.empty(M, C, dtype=BF, device=self.device) if deferred is not None else None
+        ops.bn_bwd_apply(g, y if (rl == 1 and rmask is None) else None, c, mi, bn.gamma, sums, dc, M, C, rl, gm,
+                         bn.dgamma, bn.dbeta, nscale, Ho * Wo, groups=G, relu_mask=rmask, beta=bn.beta, act_out=act)
+        if deferred is not None:        # the consumer's weight gradient: its operand exists from here on
+            ddc, dg, geom, flop = deferred
+            T['wgrad_pending'].append((act, ddc, dg) + geom)
+            T['wgrad_pending_flop'] += flop
         if stem:
             if isinstance(x, tuple):        # the fp32 image batches themselves (one per BatchNorm group): no patch matrix
                 Ng = N // len(x)
@@ -893,8 +954,13 @@ class Deeplabv2(nn.Module):
                 ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
             return None, gm
         # weight gradients are only needed by the optimizer: they are queued, and launched in groups
-        T['wgrad_pending'].append((x, dc, conv.g, N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil))
-        T['wgrad_pending_flop'] += 2.0 * M * conv.co * conv.ci * conv.k * conv.k
+        wgeom = (N, H, W, Ho, Wo, conv.k, conv.k, conv.stride, conv.pad, conv.dil)
+        wflop = 2.0 * M * conv.co * conv.ci * conv.k * conv.k
+        if isinstance(x, _Lazy):        # the operand was never written: queued by the producing unit's backward (above)
+            T['wgrad_deferred:' + x.key] = (dc, conv.g, wgeom, wflop)
+        else:
+            T['wgrad_pending'].append((x, dc, conv.g) + wgeom)
+            T['wgrad_pending_flop'] += wflop
         if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
             self._flush_wgrads(T)
         dx = None
@@ -906,10 +972,14 @@ class Deeplabv2(nn.Module):
                 cx, cc, cy, cmi, (cN, cH, cW, cHo, cWo), cns, cmask = T[ckey]
                 assert cN * cHo * cWo == N * H * W and cc.shape[1] == conv.ci
                 csums = T['sums_pool'].take(G * NREP * 2 * conv.ci)
+                cbn = None
+                if cmask is FROM_X:     # the consumer's activation was never written: its ReLU sign comes from cc
+                    cbn, cmask, crelu = x.bn, None, (2 if crelu else 0)
                 try:
                     ops.conv2d_bnbwd(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil,
-                                     1, dx_res, csums, G, cy if (crelu and cmask is None) else None, cc, cmi, crelu,
-                                     cns, cHo * cWo, relu_mask=cmask, res_mask=dx_res_mask)
+                                     1, dx_res, csums, G, cy if (crelu == 1 and cmask is None) else None, cc, cmi, crelu,
+                                     cns, cHo * cWo, relu_mask=cmask, res_mask=dx_res_mask,
+                                     bn_gamma=None if cbn is None else cbn.gamma, bn_beta=None if cbn is None else cbn.beta)
                     T['sums:' + ckey] = csums
                     fused = True
                 except ValueError:          # row groups do not tile (tiny maps): plain conv, standalone reduction
@@ -928,7 +998,8 @@ class Deeplabv2(nn.Module):
         conv, bn = self.convs['encoder.resnet.conv1'], self.bns['encoder.resnet.bn1']
         G = len(xs)
         N, M = Ng * G, Ng * G * H1 * W1
-        y = torch.empty(M, 64, dtype=BF, device=dev)
+        y = torch.empty(M, 64, dtype=BF, device=dev) if (T is None or not self.bn_on_operand or
+                                                           getattr(self, '_debug_taps', None) is not None) else None
         if T is None:
             for gi, xg in enumerate(xs):
                 ops.stem_conv_bneval(xg, self.stem_wb, y[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], bn.rm, bn.rv, bn.gamma,
@@ -957,6 +1028,11 @@ class Deeplabv2(nn.Module):
         st = stats.view(G, -1)
         for gi, xg in enumerate(xs):
             ops.stem_conv(xg, self.stem_wb, c[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], st[gi], Ng, H, W, H1, W1)
+        if self.bn_on_operand and getattr(self, '_debug_taps', None) is None:
+            # bn1 + ReLU run on the max-pool's operand path (ops.maxpool_fwd_bnin): the 64-channel full-resolution
+            # activation (134 MB for 16 images of 512 x 512) is never written
+            T['stem'] = (col, c, None, None, (N, H, W, H1, W1), None, None)
+            return _Lazy('stem', c, stats, bn, G, True, M), col_ready
         mi = torch.empty(G, 2, 64, device=dev)
         rmask = (torch.empty(M, 8, dtype=torch.uint8, device=dev) if (self.relu_sign_mask and 64 >= self.relu_sign_mask) else None)
         ops.bn_train_apply(c, stats, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, y, M, 64, True, None, None, H1 * W1, groups=G,
@@ -989,12 +1065,15 @@ class Deeplabv2(nn.Module):
         H2, W2 = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         y = torch.empty(N * H2 * W2, 64, dtype=BF, device=dev)
         idx = torch.empty(N * H2 * W2, 64, dtype=torch.uint8, device=dev)
-        ops.maxpool_fwd(a0, y, idx, N, H1, W1, 64, H2, W2)
+        if isinstance(a0, _Lazy):
+            ops.maxpool_fwd_bnin(self._bn_operand(T, a0), a0.c, y, idx, N, H1, W1, 64, H2, W2)
+        else:
+            ops.maxpool_fwd(a0, y, idx, N, H1, W1, 64, H2, W2)
         if T is not None:
             T['pool'] = (idx, (N, H1, W1, H2, W2))
         dbg = getattr(self, '_debug_taps', None)
         if dbg is not None:
-            dbg['stem'] = a0.float().reshape(N, H1, W1, -1).permute(0, 3, 1, 2)
+            dbg['stem'] = a0.float().reshape(N, H1, W1, -1).permute(0, 3, 1, 2)       # (debug taps keep the stem materialised)
             dbg['pool'] = y.float().reshape(N, H2, W2, -1).permute(0, 3, 1, 2)
         h, w = H2, W2
         # a downsample branch (first block of a layer) only meets the main branch in bn3's residual add: in training it
@@ -1015,8 +1094,9 @@ class Deeplabv2(nn.Module):
                                               False)
                     if bs is not None:
                         joined = plan.record_event(bs)
-            a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True)
-            a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True)
+            # bn1 / bn2 (+ ReLU) are deferred to the next convolution's operand path (training; see bn_on_operand)
+            a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True, defer=True)
+            a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True, defer=True)
             if joined is not None:
                 plan.wait_event(main_stream, joined)
             y, _, _ = self._cbr_fwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], a2, N, h2, w2, True, res=idt)

@@ -262,14 +262,44 @@ def conv2d_bneval(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, ga
 
 
 def conv2d_bnbwd(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, bn_mi, relu,
-                 nscale=None, rows_per_image=0, relu_mask=None, res_mask=None):
-    """conv2d whose epilogue also accumulates the BN-backward sums of the consumer of `y` (see rgda_conv2d_bnbwd)."""
+                 nscale=None, rows_per_image=0, relu_mask=None, res_mask=None, bn_gamma=None, bn_beta=None):
+    """conv2d whose epilogue also accumulates the BN-backward sums of the consumer of `y` (see rgda_conv2d_bnbwd).
+    relu: False / True, or 2 = the ReLU sign recomputed from bn_x (needs bn_gamma, bn_beta)."""
     Cout, taps, Cin = w.shape
     assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
     lib().call('rgda_conv2d_bnbwd', x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
                _ld(res) if res is not None else 0, _p(res_mask), _stat(sums), groups, _p(bn_y), _ld(bn_y) if bn_y is not None else 0,
-               _p(relu_mask), bn_x.data_ptr(), _ld(bn_x), bn_mi.data_ptr(), _p(nscale), rows_per_image, int(relu), N, H, W, Cin, Ho, Wo,
-               Cout, kh, kw, stride, pad, dil, mode, _stream())
+               _p(relu_mask), bn_x.data_ptr(), _ld(bn_x), bn_mi.data_ptr(), _p(nscale), rows_per_image, int(relu),
+               _p(bn_gamma), _p(bn_beta), N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, mode, _stream())
+
+
+class _BnOperand(ctypes.Structure):
+    _fields_ = [('stats', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p), ('mi', ctypes.c_void_p),
+                ('running_mean', ctypes.c_void_p), ('running_var', ctypes.c_void_p), ('num_batches_tracked', ctypes.c_void_p),
+                ('eps', ctypes.c_float), ('momentum', ctypes.c_float), ('groups', ctypes.c_int), ('relu', ctypes.c_int)]
+
+
+def bn_operand(stats, gamma, beta, mi=None, rm=None, rv=None, nbt=None, groups=1, relu=True, eps=1e-5, momentum=0.1):
+    """rgda_bn_operand: a BatchNorm (+ ReLU) that runs on its consumer's operand path.  stats: the producing convolution's
+    accumulators [groups][8][2][C] (int64); mi (out) f32 [groups][2][C].  Returns a pointer object for conv2d_bnin /
+    maxpool_fwd_bnin (host memory holding device pointers; the caller keeps the tensors alive)."""
+    d = _BnOperand(_stat(stats), gamma.data_ptr(), beta.data_ptr(), _p(mi), _p(rm), _p(rv), _p(nbt), eps, momentum,
+                   int(groups), int(bool(relu)))
+    return ctypes.cast(ctypes.pointer(d), ctypes.c_void_p)
+
+
+def conv2d_bnin_supported(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, groups):
+    return bool(lib().size('rgda_conv2d_bnin_supported', M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, groups))
+
+
+def conv2d_bnin(bnop, x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, res=None, stats=None, stat_groups=1):
+    """conv2d (forward) over  relu(BatchNorm(x))  of the producing convolution's RAW output x, applied on the operand path
+    (rgda_conv2d_bnin; bnop from bn_operand()).  Raises ValueError where no kernel carries the transform."""
+    Cout, taps, Cin = w.shape
+    assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
+    lib().call('rgda_conv2d_bnin', bnop, x.data_ptr(), _ld(x), w.data_ptr(), y.data_ptr(), _ld(y), _p(res),
+               _ld(res) if res is not None else 0, _stat(stats), stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad,
+               dil, _stream())
 
 
 def conv2d_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
@@ -390,23 +420,31 @@ def bn_train_apply(x, stats, mi, rm, rv, nbt, gamma, beta, y, M, C, relu, res=No
                rows_per_image, y.data_ptr(), _ld(y), _p(relu_mask), M, C, int(relu), groups, eps, momentum, _stream())
 
 
-def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0, groups=1, relu_mask=None):
+def bn_bwd_reduce(g, y, x, mi, sums, M, C, relu, nscale=None, rows_per_image=0, groups=1, relu_mask=None, gamma=None,
+                  beta=None):
+    """relu: False / True ([y > 0] from relu_mask or y), or 2 = the sign recomputed from x (needs gamma, beta)."""
     lib().call('rgda_bn_bwd_reduce', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, _p(relu_mask),
                x.data_ptr(), _ld(x),
-               mi.data_ptr(), _p(nscale), rows_per_image, _stat(sums), M, C, int(relu), groups, _stream())
+               mi.data_ptr(), _p(nscale), rows_per_image, _stat(sums), M, C, int(relu), _p(gamma), _p(beta), groups, _stream())
 
 
 def bn_bwd_apply(g, y, x, mi, gamma, sums, dx, M, C, relu, gmask=None, dgamma=None, dbeta=None, nscale=None,
-                 rows_per_image=0, groups=1, relu_mask=None):
+                 rows_per_image=0, groups=1, relu_mask=None, beta=None, act_out=None):
+    """relu == 2: the ReLU sign from x (needs beta); act_out (bf16 [M, C(view)]) then receives relu(BatchNorm(x))."""
     lib().call('rgda_bn_bwd_apply', g.data_ptr(), _ld(g), _p(y), _ld(y) if y is not None else 0, _p(relu_mask),
                x.data_ptr(), _ld(x),
                mi.data_ptr(), gamma.data_ptr(), _p(nscale), rows_per_image, _stat(sums), dx.data_ptr(), _ld(dx),
-               _p(gmask), _ld(gmask) if gmask is not None else 0, _p(dgamma), _p(dbeta), M, C, int(relu), groups,
-               _stream())
+               _p(gmask), _ld(gmask) if gmask is not None else 0, _p(dgamma), _p(dbeta), M, C, int(relu), _p(beta),
+               _p(act_out), _ld(act_out) if act_out is not None else 0, groups, _stream())
 
 
 def maxpool_fwd(x, y, idx, N, H, W, C, Ho, Wo):
     lib().call('rgda_maxpool_fwd', x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, C, Ho, Wo, _stream())
+
+
+def maxpool_fwd_bnin(bnop, x, y, idx, N, H, W, C, Ho, Wo):
+    """MaxPool over relu(BatchNorm(x)) of the RAW stem convolution output (rgda_maxpool_fwd_bnin)."""
+    lib().call('rgda_maxpool_fwd_bnin', bnop, x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, C, Ho, Wo, _stream())
 
 
 def maxpool_bwd(gy, idx, gx, N, H, W, C, Ho, Wo):

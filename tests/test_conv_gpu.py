@@ -949,3 +949,169 @@ def test_big_tile_data_gradient_with_fused_bn_backward(ops, Cf, Cb, k, pad, dil)
         ops.bn_bwd_reduce(dx2, cy, cx, mi, want, M, Cf, True, groups=groups)
         torch.testing.assert_close(ops.stats_value(sums, backward=True).sum(1).float(),
                                    ops.stats_value(want, backward=True).sum(1).float(), rtol=3e-4, atol=0.5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BatchNorm + ReLU on the consumer's operand path (rgda_conv2d_bnin, rgda_maxpool_fwd_bnin, relu == 2 in the backward
+# kernels): regda/_resnets.py:92-112's conv -> bn -> relu -> conv chain without the activation ever being written.
+BNIN_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, kernel kind   -- the production geometries (bottleneck conv2 / conv3)
+    (16, 32, 32, 256, 1024, 1, 1, 0, 1, 'igemm'),    # layer 3 conv3 (the dominant 1x1 kernel's tile)
+    (4, 32, 32, 512, 2048, 1, 1, 0, 1, 'igemm'),     # layer 4 conv3
+    (4, 64, 64, 128, 512, 1, 1, 0, 1, 'igemm'),      # layer 2 conv3
+    (2, 128, 128, 64, 256, 1, 1, 0, 1, 'igemm'),     # layer 1 conv3
+    (16, 64, 64, 128, 128, 3, 1, 1, 1, 'igemm'),     # layer 2 conv2
+    (16, 128, 128, 128, 128, 3, 2, 1, 1, 'igemm'),   # layer 2 block 0 conv2 (stride 2: padding rows on the operand path)
+    (16, 32, 32, 256, 256, 3, 1, 1, 1, 'halo4'),     # layer 3 conv2
+    (16, 32, 32, 512, 512, 3, 1, 1, 1, 'halo8'),     # layer 4 block 0 conv2
+]
+
+
+def _bn_ref(c, gamma, beta, groups, eps=1e-5):
+    """Train-mode BatchNorm of NCHW fp32 `c` per group of images (biased variance), fp64 inside."""
+    outs, means, vars_ = [], [], []
+    for cg in c.double().chunk(groups, 0):
+        m = cg.mean((0, 2, 3))
+        v = cg.var((0, 2, 3), unbiased=False)
+        outs.append((cg - m[None, :, None, None]) / torch.sqrt(v + eps)[None, :, None, None] * gamma.double()[None, :, None, None]
+                    + beta.double()[None, :, None, None])
+        means.append(m)
+        vars_.append(v)
+    return torch.cat(outs, 0).float(), torch.stack(means), torch.stack(vars_)
+
+
+@pytest.mark.parametrize('case', BNIN_CASES)
+def test_conv_with_batchnorm_relu_on_the_operand_path(ops, case):
+    """rgda_conv2d_bnin against fp32 F.conv2d(F.relu(bn(c))) on the bf16-rounded raw operand c: output, its fused
+    statistics, (mean, invstd) and the running statistics (src then tgt, unbiased variance, momentum 0.1); then the
+    backward side of the same unit: rgda_bn_bwd_apply(relu = 2) against autograd, and the activation it writes for the
+    weight gradient fed to the PLAIN convolution reproduces the operand-path convolution bit for bit."""
+    N, H, W, Cin, Cout, k, s, p, d, kind = case
+    G = 2
+    gen = torch.Generator().manual_seed(1 + hash(case) % 1000)
+    # the raw output of the producing convolution: per-channel offsets / scales so that BatchNorm has something to do
+    c = rbf(torch.randn(N, Cin, H, W, generator=gen) * (0.5 + torch.rand(1, Cin, 1, 1, generator=gen)) +
+            torch.randn(1, Cin, 1, 1, generator=gen))
+    gamma = 0.5 + torch.rand(Cin, generator=gen)
+    gamma[::7] *= -1.0                                  # negative scales too
+    beta = 0.3 * torch.randn(Cin, generator=gen)
+    w = rbf(torch.randn(Cout, Cin, k, k, generator=gen) * (2.0 / (Cin * k * k)) ** 0.5)
+    Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
+    Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
+    M = N * Ho * Wo
+    assert ops.conv2d_bnin_supported(M, Cout, Cin, k, k, s, p, d, H, W, Ho, Wo, G), 'geometry must be served'
+    bnr, mean_ref, var_ref = _bn_ref(c, gamma, beta, G)
+    a_ref = rbf(F.relu(bnr))
+    ref = F.conv2d(a_ref, w, None, s, p, d)
+    cg = to_pxc(c)
+    wg = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin).to(BF).cuda().contiguous()
+    # the producer's accumulators, as its epilogue would have left them
+    pst = ops.new_stats(G, 8, 2, Cin)
+    rows = N * H * W // G
+    for g_ in range(G):
+        ops.bn_stats(cg[g_ * rows:(g_ + 1) * rows], pst[g_], rows, Cin)
+    mi = torch.zeros(G, 2, Cin, device='cuda')
+    rm = torch.full((Cin,), 0.25, device='cuda')
+    rv = torch.full((Cin,), 2.0, device='cuda')
+    nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+    gam, bet = gamma.cuda(), beta.cuda()
+    bnop = ops.bn_operand(pst, gam, bet, mi, rm, rv, nbt, G, True)
+    y = torch.zeros(M, Cout, dtype=BF, device='cuda')
+    stats = ops.new_stats(G, 8, 2, Cout)
+    ops.conv2d_bnin(bnop, cg, wg, y, N, H, W, Ho, Wo, k, k, s, p, d, None, stats, G)
+    out = from_pxc(y, N, Ho, Wo)
+    assert relerr(out, ref) < 1.2e-2, ('forward', relerr(out, ref))
+    yf = y.float().view(G, M // G, Cout)
+    sv = ops.stats_value(stats).sum(1)
+    torch.testing.assert_close(sv[:, 0].float().cpu(), yf.sum(1).cpu(), rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(sv[:, 1].float().cpu(), (yf * yf).sum(1).cpu(), rtol=1e-3, atol=2e-2)
+    # nn.BatchNorm2d's train-mode side effects, written by one workgroup of the launch
+    torch.testing.assert_close(mi[:, 0].cpu(), mean_ref.float(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mi[:, 1].cpu(), (1.0 / torch.sqrt(var_ref + 1e-5)).float(), rtol=1e-4, atol=1e-5)
+    n_g = N * H * W // G
+    rm_ref, rv_ref = torch.full((Cin,), 0.25).double(), torch.full((Cin,), 2.0).double()
+    for g_ in range(G):
+        rm_ref = 0.9 * rm_ref + 0.1 * mean_ref[g_]
+        rv_ref = 0.9 * rv_ref + 0.1 * var_ref[g_] * n_g / (n_g - 1)
+    torch.testing.assert_close(rm.cpu(), rm_ref.float(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv.cpu(), rv_ref.float(), rtol=1e-4, atol=1e-5)
+    assert int(nbt.item()) == G
+    # ---- backward of the deferred unit: ReLU sign from c, the activation written for the weight gradient
+    gact = rbf(torch.randn(N, Cin, H, W, generator=gen))              # d(loss) / d(activation)
+    cr = c.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    outs = []
+    for cgrp in cr.chunk(G, 0):
+        outs.append(F.relu(F.batch_norm(cgrp, None, None, gr, br, True, 0.1, 1e-5)))
+    torch.cat(outs, 0).backward(gact)
+    gg = to_pxc(gact)
+    sums = ops.new_stats(G, 8, 2, Cin)
+    ops.bn_bwd_reduce(gg, None, cg, mi, sums, N * H * W, Cin, 2, groups=G, gamma=gam, beta=bet)
+    dcx = torch.zeros(N * H * W, Cin, dtype=BF, device='cuda')
+    act = torch.zeros(N * H * W, Cin, dtype=BF, device='cuda')
+    dgam, dbet = torch.zeros(Cin, device='cuda'), torch.zeros(Cin, device='cuda')
+    ops.bn_bwd_apply(gg, None, cg, mi, gam, sums, dcx, N * H * W, Cin, 2, None, dgam, dbet, groups=G, beta=bet, act_out=act)
+    assert relerr(from_pxc(dcx, N, H, W), cr.grad) < 1.5e-2, 'bn backward (relu sign from x)'
+    assert relerr(dgam.cpu(), gr.grad) < 5e-3 and relerr(dbet.cpu(), br.grad) < 5e-3
+    assert relerr(from_pxc(act, N, H, W), a_ref) < 1e-2
+    # the same bits the operand path fed the matrix pipe: the plain convolution over `act` gives the identical result
+    y2 = torch.zeros(M, Cout, dtype=BF, device='cuda')
+    st2 = ops.new_stats(G, 8, 2, Cout)
+    ops.conv2d(act, wg, y2, N, H, W, Ho, Wo, k, k, s, p, d, 0, None, st2, G)
+    assert torch.equal(y2, y), 'operand-path activation != the activation written for the weight gradient'
+    assert torch.equal(st2, stats)
+    # the data-gradient convolution with the fused BatchNorm-backward sums of this unit (relu == 2: sign from c)
+    dyn = rbf(torch.randn(N, Cout, Ho, Wo, generator=gen) * 0.1)
+    ar = a_ref.clone().requires_grad_(True)
+    F.conv2d(ar, w, None, s, p, d).backward(dyn)
+    wt = w.permute(1, 2, 3, 0).reshape(Cin, k * k, Cout).to(BF).cuda().contiguous()
+    da = torch.zeros(N * H * W, Cin, dtype=BF, device='cuda')
+    fsums = ops.new_stats(G, 8, 2, Cin)
+    try:
+        ops.conv2d_bnbwd(to_pxc(dyn), wt, da, N, Ho, Wo, H, W, k, k, s, p, d, 1, None, fsums, G, None, cg, mi, 2,
+                         bn_gamma=gam, bn_beta=bet)
+    except ValueError:
+        return          # row groups do not tile for this geometry: the model falls back to rgda_bn_bwd_reduce
+    assert relerr(from_pxc(da, N, H, W), ar.grad) < 1.5e-2
+    rsums = ops.new_stats(G, 8, 2, Cin)
+    ops.bn_bwd_reduce(da, None, cg, mi, rsums, N * H * W, Cin, 2, groups=G, gamma=gam, beta=bet)
+    a_, b_ = ops.stats_value(fsums, True).sum(1), ops.stats_value(rsums, True).sum(1)
+    torch.testing.assert_close(a_.float().cpu(), b_.float().cpu(), rtol=2e-3, atol=2e-2)
+
+
+def test_maxpool_with_batchnorm_relu_on_the_operand_path(ops):
+    """rgda_maxpool_fwd_bnin against F.max_pool2d(F.relu(bn(c))) on the stem geometry (64 channels, 2 groups), and the
+    argmax taps against the materialised route (rgda_maxpool_fwd over the same bf16 activation)."""
+    N, C, H, W, G = 4, 64, 64, 128, 2
+    gen = torch.Generator().manual_seed(5)
+    c = rbf(torch.randn(N, C, H, W, generator=gen) * 1.5 + 0.2)
+    gamma = 0.5 + torch.rand(C, generator=gen)
+    gamma[::5] *= -1.0
+    beta = 0.2 * torch.randn(C, generator=gen)
+    bnr, mean_ref, var_ref = _bn_ref(c, gamma, beta, G)
+    a_ref = rbf(F.relu(bnr))
+    ref = F.max_pool2d(a_ref, 3, 2, 1)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    cg = to_pxc(c)
+    pst = ops.new_stats(G, 8, 2, C)
+    rows = N * H * W // G
+    for g_ in range(G):
+        ops.bn_stats(cg[g_ * rows:(g_ + 1) * rows], pst[g_], rows, C)
+    mi = torch.zeros(G, 2, C, device='cuda')
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    nbt = torch.zeros((), dtype=torch.int64, device='cuda')
+    gam, bet = gamma.cuda(), beta.cuda()
+    y = torch.zeros(N * Ho * Wo, C, dtype=BF, device='cuda')
+    idx = torch.zeros(N * Ho * Wo, C, dtype=torch.uint8, device='cuda')
+    ops.maxpool_fwd_bnin(ops.bn_operand(pst, gam, bet, mi, rm, rv, nbt, G, True), cg, y, idx, N, H, W, C, Ho, Wo)
+    assert relerr(from_pxc(y, N, Ho, Wo), ref) < 1e-2
+    torch.testing.assert_close(mi[:, 0].cpu(), mean_ref.float(), rtol=1e-4, atol=1e-5)
+    assert int(nbt.item()) == G
+    # the activation rgda_bn_bwd_apply(relu = 2) writes is the operand the pooling saw: pooling it reproduces y and idx
+    sums = ops.new_stats(G, 8, 2, C)
+    gz = torch.zeros(N * H * W, C, dtype=BF, device='cuda')
+    dcx, act = torch.zeros_like(gz), torch.zeros_like(gz)
+    ops.bn_bwd_apply(gz, None, cg, mi, gam, sums, dcx, N * H * W, C, 2, groups=G, beta=bet, act_out=act)
+    y2, idx2 = torch.zeros_like(y), torch.zeros_like(idx)
+    ops.maxpool_fwd(act, y2, idx2, N, H, W, C, Ho, Wo)
+    assert torch.equal(y2, y) and torch.equal(idx2, idx)

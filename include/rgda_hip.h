@@ -220,7 +220,9 @@ typedef struct rgda_bn_operand {
 /* rgda_conv2d (mode 0) whose operand x [N*H*W][ldx] is the RAW output of the producing convolution and bn_in describes
  * the BatchNorm (+ ReLU) between them.  Served: Cin <= 512 and the geometries rgda_conv2d_bnin_supported() reports
  * (1x1 and 3x3 convolutions with >= 512 tiles of 128 x 128, and the 3x3 / dilation 1 convolutions on 32-wide maps);
- * anything else returns RGDA_ERR_UNSUPPORTED and the caller materialises the activation with rgda_bn_train_apply. */
+ * anything else returns RGDA_ERR_UNSUPPORTED and the caller materialises the activation with rgda_bn_train_apply.
+ * rgda_conv2d_bnin_supported: 0 = not served, 1 = served, 2 = served AND measured faster than the apply pass it
+ * replaces (the model defers a unit only then). */
 int rgda_conv2d_bnin_supported(int64_t M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H, int W,
                                int Ho, int Wo, int groups);
 int rgda_conv2d_bnin(const rgda_bn_operand* bn_in, const void* x, int ldx, const void* wgt, void* y, int ldy,

@@ -62,11 +62,12 @@ static __device__ __forceinline__ float wave_max(float v) {
 
 // ---- order-independent per-channel accumulators (include/rgda_hip.h: rgda_stat_t, 64-bit fixed point).
 // A workgroup's partial sum (reduced in a fixed order inside the workgroup) -> round(v * 2^frac) -> integer atomic.
-// A partial that is out of range (|v * 2^frac| >= 2^59) or not finite adds RGDA_STAT_POISON instead: stat_total() turns a
-// replica whose magnitude reached 2^60 into +inf, so a diverging run shows inf / NaN in its BatchNorm outputs instead of
-// silently wrapped (sign-flipped) statistics.  (Up to 15 poisoned partials on one word cannot cancel: k * 3 * 2^60 mod 2^64
-// stays >= 2^60 in magnitude for k = 1 .. 15.)  In-range totals: |sum| < 2^60 / 2^frac per replica = 1.7e10 forward,
-// 1.0e6 backward.
+// A partial that is out of range (|v * 2^frac| >= 2^59) or not finite adds RGDA_STAT_POISON = 3 * 2^60 instead, and
+// stat_total() reads a total of magnitude >= 2^59 as +inf: with in-range totals below 2^59, k poisons move the 64-bit sum
+// by (3 k mod 16) * 2^60, i.e. out of range for every k that is not a multiple of 16 -- a diverging run shows inf / NaN in
+// its BatchNorm outputs instead of silently wrapped (sign-flipped) statistics.  ONE comparison on the total: a check per
+// replica cost 0.14 ms per step in the BatchNorm preambles.  In-range totals: |sum| < 2^59 / 2^frac = 8.6e9 forward,
+// 5.2e5 backward.
 #define RGDA_STAT_POISON (3ll << 60)
 static __device__ __forceinline__ long long stat_fix(float v, int frac) {
     // round(v * 2^frac) as a 64-bit integer without fp64 or the software float -> int64 routine (40+ instructions at the
@@ -85,14 +86,9 @@ static __device__ __forceinline__ void stat_add(rgda_stat_t* p, float v, int fra
 // total of statistic `which` (0: first sum, 1: second) of channel c over the replicas of one row group, as a double
 static __device__ __forceinline__ double stat_total(const rgda_stat_t* __restrict__ st, int C, int c, int which, int frac) {
     long long t = 0;
-    bool poisoned = false;
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-        const long long v = st[(size_t)(2 * r + which) * C + c];
-        poisoned |= (v >= (1ll << 60)) || (v <= -(1ll << 60));
-        t += v;
-    }
-    if (poisoned) return (double)__builtin_inff();
+    for (int r = 0; r < NREP; ++r) t += st[(size_t)(2 * r + which) * C + c];
+    if (t >= (1ll << 59) || t <= -(1ll << 59)) return (double)__builtin_inff();      // poisoned or out of range
     return (double)t * (1.0 / (double)(1ll << frac));
 }
 

@@ -120,7 +120,7 @@ static __device__ __forceinline__ void dma16_to_lds(i32x4 rsrc, const unsigned c
 // four rows are issued together (the pass is latency- and instruction-bound: ~40 % of a small-K 1x1 workgroup's life
 // went here when it was one generic loop with a load -> wait -> store chain per row), the arithmetic is two-wide
 // (v_pk_*_f32) on bf16 pairs unpacked with a shift / a mask.
-enum { EPI_PLAIN = 0, EPI_STATS, EPI_RES, EPI_RES_STATS, EPI_EV, EPI_BNX };
+enum { EPI_PLAIN = 0, EPI_STATS, EPI_RES, EPI_RES_STATS, EPI_EV, EPI_BNX, EPI_BNX2 };   // BNX2: BNX with the ReLU sign recomputed from bn_x
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4r;
 #define RGDA_BNIN_MAX_C 512      /* most input channels a BatchNorm-on-the-operand-path launch serves (LDS table) */
@@ -152,14 +152,15 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
         k2[e] = f32x2{0.f, 0.f}; k3[e] = f32x2{0.f, 0.f};
         s2[e] = f32x2{s[2 * e], s[2 * e + 1]}; q2[e] = f32x2{q[2 * e], q[2 * e + 1]};
     }
-    if (KIND == EPI_BNX && cok) {
+    constexpr bool BNX = KIND == EPI_BNX || KIND == EPI_BNX2;
+    if (BNX && cok) {
         const float* mi = a.bn_mi + (size_t)(m0 / a.rows_per_group) * 2 * a.Cout + co;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             k1[e] = f32x2{mi[2 * e], mi[2 * e + 1]};
             k0[e] = f32x2{mi[a.Cout + 2 * e], mi[a.Cout + 2 * e + 1]};
         }
-        if (a.bn_relu == 2) {
+        if constexpr (KIND == EPI_BNX2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float sc, sh;
@@ -177,7 +178,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
             k1[e >> 1][e & 1] = a.ev_beta[co + e] - a.ev_rm[co + e] * sc;
         }
     }
-    const bool has_res = (KIND == EPI_RES || KIND == EPI_RES_STATS) || ((KIND == EPI_EV || KIND == EPI_BNX) && a.res);
+    const bool has_res = (KIND == EPI_RES || KIND == EPI_RES_STATS) || ((KIND == EPI_EV || BNX) && a.res);
     const bool res_gate = (KIND != EPI_EV) && has_res && a.res_mask;
     constexpr bool STATS = KIND == EPI_STATS || KIND == EPI_RES_STATS;
 #pragma unroll
@@ -198,9 +199,9 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
                     rv[i] = *(const uint4*)(a.res + (size_t)m * a.ldres + co);
                     if (res_gate) rmb[i] = a.res_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
                 }
-                if (KIND == EPI_BNX) {
+                if (BNX) {
                     xv[i] = *(const uint4*)(a.bn_x + (size_t)m * a.bn_ldx + co);
-                    if (a.bn_relu == 1) {
+                    if (KIND == EPI_BNX && a.bn_relu) {
                         if (a.bn_mask) bmb[i] = a.bn_mask[(size_t)m * (a.Cout >> 3) + (co >> 3)];
                         else yv[i] = *(const uint4*)(a.bn_y + (size_t)m * a.bn_ldy + co);
                     }
@@ -245,7 +246,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
                         q2[e] += f * f;
                     }
                 }
-                if (KIND == EPI_BNX) {
+                if (BNX) {
                     const unsigned xw[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
                     const unsigned yw[4] = {yv[i].x, yv[i].y, yv[i].z, yv[i].w};
                     f32x2 ns[4];
@@ -259,7 +260,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         f32x2 g = bf2f_pair(ow[e]);
-                        if (a.bn_relu == 2) {
+                        if constexpr (KIND == EPI_BNX2) {
                             const f32x2 xx = bf2f_pair(xw[e]);
                             g.x = (bn_affine(xx.x, k2[e].x, k3[e].x) > 0.f) ? g.x : 0.f;
                             g.y = (bn_affine(xx.y, k2[e].y, k3[e].y) > 0.f) ? g.y : 0.f;
@@ -322,7 +323,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
     const int cv = t % VPR;
     // the row pass, specialised per fused variant (uniform branches; each variant is one straight block)
     if (a.ev_rm) epilogue_rows<BC, BP, NT, EPI_EV>(a, smem, m0, c0, s, q);
-    else if (a.bn_x) epilogue_rows<BC, BP, NT, EPI_BNX>(a, smem, m0, c0, s, q);
+    else if (a.bn_x) {
+        if (a.bn_relu == 2) epilogue_rows<BC, BP, NT, EPI_BNX2>(a, smem, m0, c0, s, q);
+        else epilogue_rows<BC, BP, NT, EPI_BNX>(a, smem, m0, c0, s, q);
+    }
     else if (a.res) {
         if (a.stats) epilogue_rows<BC, BP, NT, EPI_RES_STATS>(a, smem, m0, c0, s, q);
         else epilogue_rows<BC, BP, NT, EPI_RES>(a, smem, m0, c0, s, q);
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         };
         issue_w(0);
         load_x();
-        bn_operand_table<64 * NW>(a.xf, m0 / a.rows_per_group, logical == 0, xtab);
+        if (!(TSKIP(a) & 256)) bn_operand_table<64 * NW>(a.xf, m0 / a.rows_per_group, logical == 0, xtab);
         __syncthreads();
         bf16x8 af[4][FI], bfr[4][FJ];
         int ci_cur = 0;                                     // first channel of the tile held in xr
@@ -521,7 +525,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
                 for (int i = 0; i < XL; ++i) {
                     const int r = (i * NW + wave) * 8 + lrow8;
                     uint4 v = uint4{xr[i][0], xr[i][1], xr[i][2], xr[i][3]};
-                    v = xok[i] ? bn_operand8(v, sc, sh, a.xf.relu != 0) : uint4{0u, 0u, 0u, 0u};
+                    if (!(TSKIP(a) & 512)) v = xok[i] ? bn_operand8(v, sc, sh, a.xf.relu != 0) : uint4{0u, 0u, 0u, 0u};
                     *(uint4*)(xb + r * 128 + ((lslot ^ ((r >> 1) & 7)) << 4)) = v;
                 }
             }
@@ -832,7 +836,8 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
         *(uint4*)p = bn_operand8(*(const uint4*)p, xsc, xsh, a.xf.relu != 0);
     };
     if constexpr (XF) {
-        bn_operand_table<512>(a.xf, m0 / a.rows_per_group, logical == 0, xtab);
+        // (tuning builds: skip bit 256 = no statistics -> table prologue, 512 = no in-loop transform; timing only)
+        if (!(TSKIP(a) & 256)) bn_operand_table<512>(a.xf, m0 / a.rows_per_group, logical == 0, xtab);
         WAIT_VMCNT(0);                                      // (the halo DMA is opaque to the compiler)
         __syncthreads();                                    // the table; also every DMA of the prologue has landed
         xf_load(0);
@@ -859,7 +864,7 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
             if (q + 2 < KT) { issue_w(q + 2, wstage >= 1 ? wstage - 1 : 2); pend += 2; }
             if (more && tp < PXW) { issue_h(sl + 1, tp); pend += 1; }
             if constexpr (XF) {
-                if (more) {
+                if (more && !(TSKIP(a) & 512)) {
                     if (tp == 1) xf_load(sl + 1);
                     if (tp >= 2 && tp - 2 < PXW) xf_piece(sl + 1, tp - 2);
                 }
@@ -1061,9 +1066,15 @@ static int conv_bnin_kind(long long M, int Cout, int Cin, int kh, int kw, int st
     return (bc == 128 && bp == 128 && stages == 82) ? 3 : 0;
 }
 
+// 0 = not served, 1 = served, 2 = served and faster than the apply pass it replaces.  Where the transform pays
+// (scripts/dev/xf_bench.py, isolated, against rgda_bn_train_apply + rgda_conv2d back to back): 3x3 256 -> 256 on 32 x 32 maps
+// 36.2 -> 29.3 us, 3x3 128 -> 128 on 64 x 64 39.9 -> 36.9, 1x1 256 -> 1024 31.2 -> 29.5, 1x1 128 -> 512 42.0 -> 41.0; where it
+// does not: 1x1 64 -> 256 on 128 x 128 maps 64.8 -> 70.5 and layer 4's 512-channel operands (3x3 81.5 -> 82.5, 1x1 512 -> 2048
+// 68.8 -> 82.5: every one of 2048 workgroups rebuilds 512 channels' scale / shift from the accumulators).
 extern "C" int rgda_conv2d_bnin_supported(int64_t M, int Cout, int Cin, int kh, int kw, int stride, int pad, int dil, int H,
                                           int W, int Ho, int Wo, int groups) {
-    return conv_bnin_kind(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, groups) != 0;
+    if (!conv_bnin_kind(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, groups)) return 0;
+    return (Cin > 256 || (kh == 1 && Cin < 128)) ? 1 : 2;
 }
 
 static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,

@@ -373,6 +373,7 @@ extern "C" int rgda_bn_train_apply(const void* x, int ldx, const rgda_stat_t* st
 }
 
 // ------------------------------------------------------------------ BN backward
+template <bool FROM_X>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __restrict__ g, int ldg,
                                                             const bf16_t* __restrict__ y, int ldy,
                                                             const uint8_t* __restrict__ rmask,
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
         for (int e = 0; e < 8; ++e) {
             mean[e] = mi[cg + e]; istd[e] = mi[C + cg + e];
             fsc[e] = 0.f; fsh[e] = 0.f;
-            if (relu == 2) bn_scale_shift(mean[e], istd[e], gamma[cg + e], beta[cg + e], fsc[e], fsh[e]);
+            if constexpr (FROM_X) bn_scale_shift(mean[e], istd[e], gamma[cg + e], beta[cg + e], fsc[e], fsh[e]);
         }
         long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
         long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
@@ -408,7 +409,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                 if (r < r1) {
                     gv[u] = *(const u16x8*)(g + r * ldg + cg);
                     xv[u] = *(const u16x8*)(x + r * ldx + cg);
-                    if (relu == 1) {
+                    if (!FROM_X && relu) {
                         if (rmask) mb[u] = rmask[r * (C >> 3) + (cg >> 3)];
                         else yv[u] = *(const u16x8*)(y + r * ldy + cg);
                     }
@@ -421,7 +422,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                 float gf[8], xf[8];
                 cvt8(gv[u], gf);
                 cvt8(xv[u], xf);
-                if (relu == 2) {
+                if constexpr (FROM_X) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) gf[e] = (bn_affine(xf[e], fsc[e], fsh[e]) > 0.f) ? gf[e] : 0.f;
                 } else if (relu) {
@@ -468,13 +469,19 @@ extern "C" int rgda_bn_bwd_reduce(const void* g, int ldg, const void* y, int ldy
     if (rows_per_block > Mg) rows_per_block = (int)((Mg + L.rpb - 1) / L.rpb * L.rpb);
     int bpg = cdiv(Mg, rows_per_block);
     dim3 grid(bpg * groups, cdiv(L.vpr, L.vpb));
-    bn_bwd_reduce_kernel<<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask, (const bf16_t*)x, ldx, mi,
-                                               nscale, rows_per_image, sums, Mg, C, relu, L.vpb, L.rpb, rows_per_block,
-                                               bpg, gamma, beta);
+    if (relu == 2)
+        bn_bwd_reduce_kernel<true><<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask, (const bf16_t*)x, ldx,
+                                                         mi, nscale, rows_per_image, sums, Mg, C, relu, L.vpb, L.rpb,
+                                                         rows_per_block, bpg, gamma, beta);
+    else
+        bn_bwd_reduce_kernel<false><<<grid, 256, 0, st>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask, (const bf16_t*)x, ldx,
+                                                          mi, nscale, rows_per_image, sums, Mg, C, relu, L.vpb, L.rpb,
+                                                          rows_per_block, bpg, gamma, beta);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }
 
+template <bool FROM_X>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restrict__ g, int ldg,
                                                            const bf16_t* __restrict__ y, int ldy,
                                                            const uint8_t* __restrict__ rmask,
@@ -510,7 +517,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             sk0[2 * nch + c] = gamma[cc] * is;
             sk0[3 * nch + c] = t1 * invM;
             sk0[4 * nch + c] = t2 * invM;
-            if (relu == 2) {
+            if constexpr (FROM_X) {
                 float fsc, fsh;
                 bn_scale_shift(mi[cc], is, gamma[cc], beta[cc], fsc, fsh);      // fsc == sk0[2][c]: the same product
                 sk0[5 * nch + c] = fsh;
@@ -541,7 +548,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
         k0[e] = sk0[2 * nch + cvl * 8 + e];
         k1[e] = sk0[3 * nch + cvl * 8 + e];
         k2[e] = sk0[4 * nch + cvl * 8 + e];
-        fsh[e] = (relu == 2) ? sk0[5 * nch + cvl * 8 + e] : 0.f;
+        if constexpr (FROM_X) fsh[e] = sk0[5 * nch + cvl * 8 + e]; else fsh[e] = 0.f;
     }
     long long r0 = (long long)grp * M + (long long)chunk * rows_per_block;
     long long r1 = min((long long)(grp + 1) * M, r0 + rows_per_block);
@@ -554,7 +561,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             if (r < r1) {
                 gv[u] = *(const u16x8*)(g + r * ldg + cg);
                 xv[u] = *(const u16x8*)(x + r * ldx + cg);
-                if (relu == 1) {
+                if (!FROM_X && relu) {
                     if (rmask) mb[u] = rmask[r * (C >> 3) + (cg >> 3)];
                     else yv[u] = *(const u16x8*)(y + r * ldy + cg);
                 }
@@ -567,7 +574,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             float gf[8], xf[8];
             cvt8(gv[u], gf);
             cvt8(xv[u], xf);
-            if (relu == 2) {
+            if constexpr (FROM_X) {
                 // the unit's activation was never written (it ran on its consumer's operand path): its ReLU sign, and
                 // the activation itself for the consumer's weight gradient, are recomputed with the forward's own formula
                 float af[8];
@@ -616,11 +623,16 @@ extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy,
     if (groups < 1 || (M % groups)) return RGDA_ERR_ARG;
     RowLayout L; int rpbk, bpg; dim3 grid;
     elementwise_grid(M / groups, C, groups, L, rpbk, bpg, grid);
-    bn_bwd_apply_kernel<<<grid, 256, (size_t)6 * L.vpb * 8 * sizeof(float), to_stream(stream)>>>((const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask,
-                                                              (const bf16_t*)x, ldx, mi, gamma, nscale, rows_per_image,
-                                                              sums, (bf16_t*)dx, lddx, (bf16_t*)gmask, ldgm, dgamma,
-                                                              dbeta, M / groups, C, relu, L.vpb, L.rpb, rpbk, bpg, beta,
-                                                              (bf16_t*)act_out, ldact);
+    if (relu == 2)
+        bn_bwd_apply_kernel<true><<<grid, 256, (size_t)6 * L.vpb * 8 * sizeof(float), to_stream(stream)>>>(
+            (const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask, (const bf16_t*)x, ldx, mi, gamma, nscale, rows_per_image, sums,
+            (bf16_t*)dx, lddx, (bf16_t*)gmask, ldgm, dgamma, dbeta, M / groups, C, relu, L.vpb, L.rpb, rpbk, bpg, beta,
+            (bf16_t*)act_out, ldact);
+    else
+        bn_bwd_apply_kernel<false><<<grid, 256, (size_t)6 * L.vpb * 8 * sizeof(float), to_stream(stream)>>>(
+            (const bf16_t*)g, ldg, (const bf16_t*)y, ldy, relu_mask, (const bf16_t*)x, ldx, mi, gamma, nscale, rows_per_image, sums,
+            (bf16_t*)dx, lddx, (bf16_t*)gmask, ldgm, dgamma, dbeta, M / groups, C, relu, L.vpb, L.rpb, rpbk, bpg, beta,
+            (bf16_t*)act_out, ldact);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -311,6 +311,8 @@ class Deeplabv2(nn.Module):
         # convolution / the max-pool) wherever a kernel carries the transform: the activation is never written in the
         # forward pass (ops.conv2d_bnin).  False = one rgda_bn_train_apply pass per unit (the cross-check)
         self.bn_on_operand = True
+        self.bn_operand_units = set(os.environ.get('RGDA_BN_OPERAND', 'stem+bn1+bn2').split('+'))   # (A/B experiments)
+        self.bn_operand_level = int(os.environ.get('RGDA_BN_OPERAND_LEVEL', '2'))    # 2: only where it pays; 1: wherever served
         self._head_stream = None
         self._mat_cache = {}
         self._synced_version = -1
@@ -729,7 +731,7 @@ class Deeplabv2(nn.Module):
         stats = T['stats_pool'].take(G * NREP * 2 * conv.co) if train else None
         if isinstance(x, _Lazy):
             if geom is None and ops.conv2d_bnin_supported(M, conv.co, conv.ci, conv.k, conv.k, conv.stride, conv.pad,
-                                                          conv.dil, H, W, Ho, Wo, G):
+                                                          conv.dil, H, W, Ho, Wo, G) >= self.bn_operand_level:
                 ops.conv2d_bnin(self._bn_operand(T, x), x.c, conv.wb if wb is None else wb, c, N, H, W, Ho, Wo, conv.k,
                                 conv.k, conv.stride, conv.pad, conv.dil, None, stats, G)
             else:
@@ -998,8 +1000,7 @@ class Deeplabv2(nn.Module):
         conv, bn = self.convs['encoder.resnet.conv1'], self.bns['encoder.resnet.bn1']
         G = len(xs)
         N, M = Ng * G, Ng * G * H1 * W1
-        y = torch.empty(M, 64, dtype=BF, device=dev) if (T is None or not self.bn_on_operand or
-                                                           getattr(self, '_debug_taps', None) is not None) else None
+        y = torch.empty(M, 64, dtype=BF, device=dev)
         if T is None:
             for gi, xg in enumerate(xs):
                 ops.stem_conv_bneval(xg, self.stem_wb, y[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], bn.rm, bn.rv, bn.gamma,
@@ -1028,7 +1029,7 @@ class Deeplabv2(nn.Module):
         st = stats.view(G, -1)
         for gi, xg in enumerate(xs):
             ops.stem_conv(xg, self.stem_wb, c[gi * Ng * H1 * W1:(gi + 1) * Ng * H1 * W1], st[gi], Ng, H, W, H1, W1)
-        if self.bn_on_operand and getattr(self, '_debug_taps', None) is None:
+        if self.bn_on_operand and 'stem' in self.bn_operand_units and getattr(self, '_debug_taps', None) is None:
             # bn1 + ReLU run on the max-pool's operand path (ops.maxpool_fwd_bnin): the 64-channel full-resolution
             # activation (134 MB for 16 images of 512 x 512) is never written
             T['stem'] = (col, c, None, None, (N, H, W, H1, W1), None, None)
@@ -1095,8 +1096,10 @@ class Deeplabv2(nn.Module):
                     if bs is not None:
                         joined = plan.record_event(bs)
             # bn1 / bn2 (+ ReLU) are deferred to the next convolution's operand path (training; see bn_on_operand)
-            a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True, defer=True)
-            a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True, defer=True)
+            a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True,
+                                     defer='bn1' in self.bn_operand_units)
+            a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True,
+                                       defer='bn2' in self.bn_operand_units)
             if joined is not None:
                 plan.wait_event(main_stream, joined)
             y, _, _ = self._cbr_fwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], a2, N, h2, w2, True, res=idt)

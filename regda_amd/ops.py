@@ -289,7 +289,8 @@ def bn_operand(stats, gamma, beta, mi=None, rm=None, rv=None, nbt=None, groups=1
 
 
 def conv2d_bnin_supported(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, groups):
-    return bool(lib().size('rgda_conv2d_bnin_supported', M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, groups))
+    """0 = not served, 1 = served, 2 = served and faster than the apply pass it replaces."""
+    return lib().size('rgda_conv2d_bnin_supported', M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, groups)
 
 
 def conv2d_bnin(bnop, x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, res=None, stats=None, stat_groups=1):

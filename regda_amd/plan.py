@@ -126,6 +126,13 @@ class Plan:
         """Run `fn()` eagerly under a private memory pool, recording its entry-point calls and host actions."""
         global _ACTIVE
         assert _ACTIVE is None, 'one plan is recorded at a time'
+        # no cyclic garbage collection while the private pool is the active allocator: a collection that happens to run
+        # here may finalise ANOTHER plan's MemPool (or a captured graph) from inside this pool's context, which aborts the
+        # process in the allocator (seen once the step allocated enough Python objects to trigger a collection mid-record)
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         self.pool = torch.cuda.MemPool()
         _ACTIVE = self
         try:
@@ -133,6 +140,8 @@ class Plan:
                 out = fn()
         finally:
             _ACTIVE = None
+            if gc_was_on:
+                gc.enable()
         self._flush()
         return out
 

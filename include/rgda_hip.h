@@ -229,6 +229,15 @@ int rgda_conv2d_bnin(const rgda_bn_operand* bn_in, const void* x, int ldx, const
                      const void* res, int ldres, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin,
                      int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, rgda_stream_t stream);
 
+/* The kernel instantiation that serves a convolution call, as rocprofv3 names it ("conv_igemm_kernel<128, 128, 2, 2, 4,
+ * false, false>", "conv3x3_halo_kernel<1, 4, true>", ...), decided by the library's own dispatch (nothing is launched):
+ * variant 0 = rgda_conv2d (has_stats / stat_groups as in the call), 1 = rgda_conv2d_bneval, 2 = rgda_conv2d_bnbwd,
+ * 3 = rgda_conv2d_bnin; rgda_conv2d_wgrad_kernel: the instantiation a layer of rgda_conv2d_wgrad_grouped maps to
+ * (layers with the same name share launches).  NULL where the call would be refused.  bench.py labels its per-launch
+ * HIP-event timings with these, so that they can be matched against rocprof kernel statistics. */
+const char* rgda_conv2d_kernel(int variant, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
+                               int stride, int pad, int dil, int mode, int has_stats, int stat_groups);
+
 /* Which conv_igemm_kernel<BC, BP, STAGES, ...> instantiation rgda_conv2d picks for a problem: returns
  * BC | BP << 10 | STAGES << 20 (STAGES 82 / 83 = 8-wave workgroups with a 2 / 3 stage ring), or a negative
  * status.  rows_per_group = rows of one BatchNorm group when fused statistics with groups > 1 are requested, else 0.
@@ -267,6 +276,7 @@ typedef struct rgda_wgrad_desc {
     int lddw, co_split;
 } rgda_wgrad_desc;
 size_t rgda_conv2d_wgrad_workspace(const rgda_wgrad_desc* descs, int n);
+const char* rgda_conv2d_wgrad_kernel(const rgda_wgrad_desc* desc);
 int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, void* ws, size_t ws_bytes, rgda_stream_t stream);
 
 /* Stem im2col: NCHW f32 image (N,3,H,W) -> [N*Ho*Wo][Kp] bf16 patches of the

@@ -1080,7 +1080,18 @@ extern "C" int rgda_conv2d_bnin_supported(int64_t M, int Cout, int Cin, int kh, 
 static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
                          const unsigned char* res_mask, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int kh, int kw, int stride, int pad, int dil, int mode, const BnBwdFuse* bnb,
-                         rgda_stream_t stream, const BnEvalFuse* bne = nullptr, const rgda_bn_operand* bnin = nullptr) {
+                         rgda_stream_t stream, const BnEvalFuse* bne = nullptr, const rgda_bn_operand* bnin = nullptr,
+                         const char** sel = nullptr) {
+    // sel != nullptr: dry run -- *sel = the kernel instantiation that would serve the call (the name rocprofv3 reports),
+    // nothing is launched (rgda_conv2d_kernel; bench.py labels its per-launch timings with it)
+#define RGDA_LAUNCH(NAME, ...)                       \
+    do {                                             \
+        if (sel) { *sel = NAME; return RGDA_OK; }    \
+        __VA_ARGS__;                                 \
+    } while (0)
+#define RGDA_IGEMM(BC, BP, ST, WC, WP, PIPE, XF)                                                                  \
+    RGDA_LAUNCH("conv_igemm_kernel<" #BC ", " #BP ", " #ST ", " #WC ", " #WP ", " #PIPE ", " #XF ">",              \
+                conv_igemm_kernel<BC, BP, ST, WC, WP, PIPE, XF><<<grid, 64 * WC * WP, 0, st>>>(a))
     if (!x || !wgt || !y) return RGDA_ERR_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || dil <= 0 || pad < 0 || (mode != 0 && mode != 1))
@@ -1139,15 +1150,16 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         a.xf.rm = bnin->running_mean; a.xf.rv = bnin->running_var; a.xf.nbt = (long long*)bnin->num_batches_tracked;
         a.xf.eps = bnin->eps; a.xf.mom = bnin->momentum; a.xf.groups = bnin->groups; a.xf.relu = bnin->relu; a.xf.C = Cin;
         a.xf.rows_per_group = (int)((long long)N * H * W / bnin->groups);
-        hipStream_t st2 = to_stream(stream);
         if (kind == 3) {
             a.tiles_c = cdiv(Cout, 128); a.tiles_p = cdiv(M, 128);
-            conv_igemm_kernel<128, 128, 2, 2, 4, false, true><<<a.tiles_c * a.tiles_p, 512, 0, st2>>>(a);
+            const int grid = a.tiles_c * a.tiles_p;
+            RGDA_IGEMM(128, 128, 2, 2, 4, false, true);
         } else {
             const int tr = kind == 1 ? 4 : 8;
             a.tiles_c = cdiv(Cout, 128); a.tiles_p = (int)(M / (tr * 32));
-            if (kind == 1) conv3x3_halo_kernel<1, 4, true><<<a.tiles_c * a.tiles_p, 512, 0, st2>>>(a);
-            else conv3x3_halo_kernel<1, 8, true><<<a.tiles_c * a.tiles_p, 512, 0, st2>>>(a);
+            const int grid = a.tiles_c * a.tiles_p;
+            if (kind == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true>", conv3x3_halo_kernel<1, 4, true><<<grid, 512, 0, st>>>(a));
+            else RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true>", conv3x3_halo_kernel<1, 8, true><<<grid, 512, 0, st>>>(a));
         }
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
@@ -1164,7 +1176,7 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
                 a.tpw = rpw;
                 a.tiles_c = 1;
                 a.tiles_p = N * H;
-                conv3x3_c64_kernel<128><<<N * H / rpw, 512, 0, st>>>(a);
+                RGDA_LAUNCH("conv3x3_c64_kernel<128>", conv3x3_c64_kernel<128><<<N * H / rpw, 512, 0, st>>>(a));
                 RGDA_CHECK_LAUNCH();
                 return RGDA_OK;
             }
@@ -1175,9 +1187,9 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         a.tiles_c = cdiv(Cout, 128);
         a.tiles_p = (int)(M / (tr * 32));
         const int grid = a.tiles_c * a.tiles_p;
-        if (tr == 4) conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a);
-        else if (dil == 1) conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a);
-        else conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a);
+        if (tr == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false>", conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a));
+        else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false>", conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a));
+        else RGDA_LAUNCH("conv3x3_halo_kernel<2, 8, false>", conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a));
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
     }
@@ -1189,26 +1201,49 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
     a.tiles_p = cdiv(M, bp);
     int grid = a.tiles_c * a.tiles_p;
     static const bool pipe = TUNE_ENV("RGDA_NO_PIPE") == nullptr;                           // (off switch: tuning experiments only)
-    if (pipe && bc == 128 && bp == 128 && stages == 83) conv_igemm_kernel<128, 128, 3, 2, 4, true><<<grid, 512, 0, st>>>(a);
-    else if (pipe && bc == 128 && bp == 256 && stages == 83) conv_igemm_kernel<128, 256, 3, 2, 4, true><<<grid, 512, 0, st>>>(a);
-    else if (pipe && bc == 128 && bp == 64 && stages == 3) conv_igemm_kernel<128, 64, 3, 2, 2, true><<<grid, 256, 0, st>>>(a);
-    else if (bc == 128 && bp == 128 && stages == 83) conv_igemm_kernel<128, 128, 3, 2, 4><<<grid, 512, 0, st>>>(a);
-    else if (bc == 128 && bp == 128 && stages == 82) conv_igemm_kernel<128, 128, 2, 2, 4><<<grid, 512, 0, st>>>(a);
-    else if (bc == 128 && bp == 256 && stages == 83) conv_igemm_kernel<128, 256, 3, 2, 4><<<grid, 512, 0, st>>>(a);
-    else if (bc == 128 && bp == 256) conv_igemm_kernel<128, 256, 3><<<grid, 256, 0, st>>>(a);
-    else if (bc == 256 && bp == 128) conv_igemm_kernel<256, 128, 3><<<grid, 256, 0, st>>>(a);
-    else if (bc == 128 && bp == 128 && stages == 2) conv_igemm_kernel<128, 128, 2><<<grid, 256, 0, st>>>(a);
-    else if (bc == 128 && bp == 128 && stages == 4) conv_igemm_kernel<128, 128, 4><<<grid, 256, 0, st>>>(a);
-    else if (bc == 128 && bp == 128) conv_igemm_kernel<128, 128><<<grid, 256, 0, st>>>(a);
-    else if (bc == 128 && bp == 64 && stages == 2) conv_igemm_kernel<128, 64, 2><<<grid, 256, 0, st>>>(a);
-    else if (bc == 128 && bp == 64 && stages == 4) conv_igemm_kernel<128, 64, 4><<<grid, 256, 0, st>>>(a);
-    else if (bc == 128 && bp == 64) conv_igemm_kernel<128, 64><<<grid, 256, 0, st>>>(a);
-    else if (bc == 64 && bp == 128) conv_igemm_kernel<64, 128><<<grid, 256, 0, st>>>(a);
-    else if (stages == 4) conv_igemm_kernel<64, 64, 4><<<grid, 256, 0, st>>>(a);
-    else if (stages == 2) conv_igemm_kernel<64, 64, 2><<<grid, 256, 0, st>>>(a);
-    else conv_igemm_kernel<64, 64><<<grid, 256, 0, st>>>(a);
+    if (pipe && bc == 128 && bp == 128 && stages == 83) RGDA_IGEMM(128, 128, 3, 2, 4, true, false);
+    else if (pipe && bc == 128 && bp == 256 && stages == 83) RGDA_IGEMM(128, 256, 3, 2, 4, true, false);
+    else if (pipe && bc == 128 && bp == 64 && stages == 3) RGDA_IGEMM(128, 64, 3, 2, 2, true, false);
+    else if (bc == 128 && bp == 128 && stages == 83) RGDA_IGEMM(128, 128, 3, 2, 4, false, false);
+    else if (bc == 128 && bp == 128 && stages == 82) RGDA_IGEMM(128, 128, 2, 2, 4, false, false);
+    else if (bc == 128 && bp == 256 && stages == 83) RGDA_IGEMM(128, 256, 3, 2, 4, false, false);
+    else if (bc == 128 && bp == 256) RGDA_IGEMM(128, 256, 3, 2, 2, false, false);
+    else if (bc == 256 && bp == 128) RGDA_IGEMM(256, 128, 3, 2, 2, false, false);
+    else if (bc == 128 && bp == 128 && stages == 2) RGDA_IGEMM(128, 128, 2, 2, 2, false, false);
+    else if (bc == 128 && bp == 128 && stages == 4) RGDA_IGEMM(128, 128, 4, 2, 2, false, false);
+    else if (bc == 128 && bp == 128) RGDA_IGEMM(128, 128, 3, 2, 2, false, false);
+    else if (bc == 128 && bp == 64 && stages == 2) RGDA_IGEMM(128, 64, 2, 2, 2, false, false);
+    else if (bc == 128 && bp == 64 && stages == 4) RGDA_IGEMM(128, 64, 4, 2, 2, false, false);
+    else if (bc == 128 && bp == 64) RGDA_IGEMM(128, 64, 3, 2, 2, false, false);
+    else if (bc == 64 && bp == 128) RGDA_IGEMM(64, 128, 3, 2, 2, false, false);
+    else if (stages == 4) RGDA_IGEMM(64, 64, 4, 2, 2, false, false);
+    else if (stages == 2) RGDA_IGEMM(64, 64, 2, 2, 2, false, false);
+    else RGDA_IGEMM(64, 64, 3, 2, 2, false, false);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
+}
+
+#undef RGDA_IGEMM
+#undef RGDA_LAUNCH
+
+// The kernel instantiation that serves a convolution call, as rocprofv3 names it (no launch): `variant` 0 = rgda_conv2d
+// (fused statistics with `stat_groups` groups when has_stats), 1 = rgda_conv2d_bneval, 2 = rgda_conv2d_bnbwd,
+// 3 = rgda_conv2d_bnin.  NULL where the call would fail.
+extern "C" const char* rgda_conv2d_kernel(int variant, int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
+                                          int stride, int pad, int dil, int mode, int has_stats, int stat_groups) {
+    static rgda_stat_t dummy_stats;
+    static const float dummy_f = 0.f;
+    const char* name = nullptr;
+    void* const p = (void*)&dummy_stats;           // never dereferenced: a dry run stops before any launch
+    rgda_stat_t* st = (has_stats || variant >= 2) ? &dummy_stats : nullptr;
+    BnEvalFuse e = {&dummy_f, &dummy_f, &dummy_f, &dummy_f, 1e-5f, 1};
+    BnBwdFuse b = {nullptr, 0, (const unsigned char*)p, p, (Cout + 7) & ~7, &dummy_f, nullptr, 0, 1, nullptr, nullptr};
+    rgda_bn_operand o = {&dummy_stats, &dummy_f, &dummy_f, nullptr, nullptr, nullptr, nullptr, 1e-5f, 0.1f, stat_groups < 1 ? 1 : stat_groups, 1};
+    const int ld_in = (Cin + 7) & ~7, ld_out = (Cout + 7) & ~7;
+    const int rc = conv2d_launch(p, ld_in, p, p, ld_out, nullptr, 0, nullptr, variant == 1 ? nullptr : st, stat_groups, N, H, W, Cin, Ho,
+                                 Wo, Cout, kh, kw, stride, pad, dil, variant == 3 ? 0 : mode, variant == 2 ? &b : nullptr, nullptr,
+                                 variant == 1 ? &e : nullptr, variant == 3 ? &o : nullptr, &name);
+    return rc == RGDA_OK ? name : nullptr;
 }
 
 extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,
@@ -2352,6 +2387,19 @@ static int wgrad_for_each_launch(const rgda_wgrad_desc* descs, int n, F fn) {
             if (rc != RGDA_OK) return rc;
         }
     return RGDA_OK;
+}
+
+// the kernel instantiation (as rocprofv3 names it) a layer's weight gradient maps to; layers with the same name share launches
+extern "C" const char* rgda_conv2d_wgrad_kernel(const rgda_wgrad_desc* d) {
+    static const char* const names[WK_COUNT] = {
+        "conv_wgrad_kernel<128, 128, 2, 4, 3>", "conv_wgrad_kernel<128, 64, 4, 2, 3>", "conv_wgrad_kernel<64, 128, 2, 4, 3>",
+        "conv_wgrad_kernel<64, 64, 2, 2, 3>", "conv_wgrad_kernel<256, 128, 4, 2, 3>",
+        "conv_wgrad3x3_wide_kernel<64, 1, 3>", "conv_wgrad3x3_wide_kernel<64, 2, 3>", "conv_wgrad3x3_kernel<32, 1, 2>",
+        "conv_wgrad3x3_wide_kernel<32, 2, 3>", "conv_wgrad3x3_kernel<16, 1, 3>", "conv_wgrad3x3_kernel<16, 2, 2>"};
+    if (!d) return nullptr;
+    WgradArgs a;
+    const int kind = wgrad_prepare(*d, a);
+    return (kind >= 0 && kind < WK_COUNT) ? names[kind] : nullptr;
 }
 
 extern "C" size_t rgda_conv2d_wgrad_workspace(const rgda_wgrad_desc* descs, int n) {

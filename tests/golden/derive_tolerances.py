@@ -123,6 +123,42 @@ def resnet101_fixture():
     return out
 
 
+FULL_GRAD_NAMES = ['encoder.resnet.conv1.weight', 'encoder.resnet.bn1.weight', 'encoder.resnet.layer1.0.conv1.weight',
+                   'encoder.resnet.layer1.2.conv3.weight', 'encoder.resnet.layer2.1.conv2.weight',
+                   'encoder.resnet.layer2.3.bn3.weight', 'encoder.resnet.layer3.0.downsample.0.weight',
+                   'encoder.resnet.layer3.5.conv2.weight', 'encoder.resnet.layer3.11.bn2.weight',
+                   'encoder.resnet.layer3.17.conv1.weight', 'encoder.resnet.layer3.22.conv3.weight',
+                   'encoder.resnet.layer4.0.conv2.weight', 'encoder.resnet.layer4.2.conv3.weight', 'layer5.ppm.3.1.weight',
+                   'layer5.conv_last.0.weight', 'layer6.conv_last.1.bias', 'layer6.conv_last.4.weight']
+
+
+def full_size_inputs(res_gamma=0.1):
+    """The inputs of tests/test_ssl_step_gpu.py::test_full_size_resnet101_step_vs_oracle (BASELINE config[0]'s shape:
+    ResNet-101, 2 + 2 images of 512 x 512, offline soft labels): shared by the test and by this derivation."""
+    sd = omodel.init_state_dict('resnet101', 6, seed=5, res_gamma=res_gamma)
+    b = make_batch(b=2, size=512, seed=77, device='cpu')
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(2))
+    ones = torch.ones(2, 512)
+    return sd, b, protos, ones
+
+
+def resnet101_full_fixture(res_gamma=0.1):
+    sd, b, protos, ones = full_size_inputs(res_gamma)
+    res = []
+    for emu in (False, True):
+        cpu = CpuStep(sd, protos, resnet_type='resnet101', lr=1e-3, emulate_bf16=('grad' if emu else False))
+        res.append((cpu.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], (ones, ones), (ones, ones)), cpu))
+    (ref, cref), (emu, cemu) = res
+    n = noise(ref, emu, FULL_GRAD_NAMES)
+    out = {k: v for k, v in n.items() if not isinstance(v, dict)}
+    out['grad_cos_min'] = min(n['grad_cos'].values())
+    out['grad_cos'] = n['grad_cos']
+    out['grad_norm_ratio_dev_max'] = max(abs(v - 1) for v in n['grad_norm_ratio'].values())
+    out['protos_rel'] = float((cemu.prototypes - cref.prototypes).norm() / cref.prototypes.norm())
+    out['labelled_fraction'] = float((ref['hard'] >= 0).float().mean())
+    return out
+
+
 def model_fixture(rt, sd, xs, lab, masks):
     """tests/test_model_gpu.py::_run_case: one train-mode forward + loss + backward of the network alone."""
     names = omodel.param_names(sd)

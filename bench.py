@@ -31,7 +31,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (~6.3 achieva
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1, help='number of ranks (one per GPU); without a launcher environment and N > 1 the script re-executes itself under torch.distributed.run')
+    ap.add_argument('--gpus', type=int, default=None, help='number of ranks (one per GPU); without a launcher environment and N > 1 the script re-executes itself under torch.distributed.run')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="'gloo' = launcher self-test without GPUs (rendezvous + one all-reduce, no step)")
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
@@ -75,28 +75,21 @@ def conv_flops_probe(step_fn, park_ms=150.0):
     from regda_amd._lib import lib
     L = lib()
     rec = []
+    import ctypes
     o_conv, o_wgrad, o_bne, o_bnb = ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd
-    o_wgrad_g = ops.conv2d_wgrad_grouped
+    o_wgrad_g, o_bnin = ops.conv2d_wgrad_grouped, ops.conv2d_bnin
 
-    def timed(kind, w, N, Ho, Wo, kh, kw, stride, dil, rows_per_group, launch, extra_bytes=0.0, in_rows=None):
+    kname = L.raw('rgda_conv2d_kernel')
+    wname = L.raw('rgda_conv2d_wgrad_kernel')
+
+    def timed(kind, variant, w, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, has_stats, groups, launch, extra_bytes=0.0):
         co, taps, ci = w.shape
-        M = N * Ho * Wo
+        M, in_rows = N * Ho * Wo, N * H * W
         # algorithmic HBM bytes of the launch: input rows + weights + output (+ what the fused epilogue reads)
-        abytes = 2.0 * (in_rows if in_rows is not None else M) * ci + 2.0 * co * taps * ci + 2.0 * M * co + extra_bytes
-        code = L.raw('rgda_conv2d_tile')(M, co, kh, kw, ci, rows_per_group)
-        bc, bp, stg = code & 1023, (code >> 10) & 1023, code >> 20
-        st3 = stg % 80 if stg >= 80 else stg
-        piped = 'true' if (st3 == 3 and bc == 128 and bp in (64, 128, 256) and (stg >= 80 or bp == 64)) else 'false'
-        name = 'conv_igemm_kernel<%d, %d, %d, %s, %s>' % (bc, bp, st3, '2, 4' if stg >= 80 else '2, 2', piped)
-        if kh == 3 and kw == 3 and stride == 1 and dil == 1 and co == 64 and ci == 64 and Wo == 128 and N * Ho >= 512:
-            name = 'conv3x3_c64_kernel<128>'        # layer1's 3x3: the weights-resident rolling-window kernel
-        if kh == 3 and kw == 3 and stride == 1 and dil in (1, 2) and Wo == 32 and in_rows in (None, M):
-            # long-K 3x3 on 32-wide maps (csrc/conv_kernels.hip: conv_use_halo)
-            if (9 * ci >= 4096 and Ho % 8 == 0 and (M // 256) * ((co + 127) // 128) >= 100 and (rows_per_group or M) % 256 == 0):
-                name = 'conv3x3_halo_kernel<%d, 8>' % dil
-            elif (9 * ci >= 2048 and dil == 1 and Ho % 4 == 0 and (M // 128) * ((co + 127) // 128) >= 100
-                  and (rows_per_group or M) % 128 == 0):
-                name = 'conv3x3_halo_kernel<1, 4>'
+        abytes = 2.0 * in_rows * ci + 2.0 * co * taps * ci + 2.0 * M * co + extra_bytes
+        # the instantiation the library's own dispatch picks for this call (rocprofv3's kernel name)
+        name = kname(variant, N, H, W, ci, Ho, Wo, co, kh, kw, stride, pad, dil, mode, int(has_stats), groups)
+        name = name.decode() if name else 'conv (unserved)'
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
@@ -105,44 +98,43 @@ def conv_flops_probe(step_fn, park_ms=150.0):
                     2.0 * M * co * taps * ci if taps == 9 else 0.0))
 
     def conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None, stats=None, stat_groups=1, **k):
-        rpg = (N * Ho * Wo // stat_groups) if (stats is not None and stat_groups > 1) else 0
         M, co = N * Ho * Wo, w.shape[0]
         extra = (2.0 * M * co if res is not None else 0.0) + (M * co / 8.0 if k.get('res_mask') is not None else 0.0)
-        timed('dgrad' if mode else 'fwd', w, N, Ho, Wo, kh, kw, stride, dil, rpg,
-              lambda: o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups, **k),
-              extra, N * H * W)
+        timed('dgrad' if mode else 'fwd', 0, w, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, stats is not None, stat_groups,
+              lambda: o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups, **k), extra)
+
+    def conv_bnin(bnop, x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, res=None, stats=None, stat_groups=1):
+        M, co = N * Ho * Wo, w.shape[0]
+        timed('fwd<-bn', 3, w, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, 0, True, stat_groups,
+              lambda: o_bnin(bnop, x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, res, stats, stat_groups),
+              2.0 * M * co if res is not None else 0.0)
 
     def conv_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, gamma, beta, relu, res=None, **k):
         M, co = N * Ho * Wo, w.shape[0]
-        timed('fwd-ev', w, N, Ho, Wo, kh, kw, stride, dil, 0,
+        timed('fwd-ev', 1, w, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, 0, False, 1,
               lambda: o_bne(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, gamma, beta, relu, res, **k),
-              2.0 * M * co if res is not None else 0.0, N * H * W)
+              2.0 * M * co if res is not None else 0.0)
 
     def conv_bnb(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, *a, **k):
         M, co = N * Ho * Wo, w.shape[0]
         extra = (2.0 * M * co if res is not None else 0.0) + 2.0 * M * co          # residual, consumer's raw conv output
         extra += 2.0 * M * co if bn_y is not None else (M * co / 8.0 if k.get('relu_mask') is not None else 0.0)
         extra += M * co / 8.0 if k.get('res_mask') is not None else 0.0
-        timed('dgrad+bn' if mode else 'fwd+bn', w, N, Ho, Wo, kh, kw, stride, dil, (N * Ho * Wo // groups) if groups > 1 else 0,
+        timed('dgrad+bn' if mode else 'fwd+bn', 2, w, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, True, groups,
               lambda: o_bnb(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, sums, groups, bn_y, bn_x, *a, **k),
-              extra, N * H * W)
+              extra)
 
     def wgrad_kernel_name(item):
         x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil = item
-        co, taps, ci = dw.shape
-        fused = (kh == 3 and kw == 3 and stride == 1 and pad == dil and Ho == H and Wo == W and
-                 -(-co // 64) * -(-ci // 64) >= 8 and min(W, 64) in (16, 32, 64) and W % min(W, 64) == 0 and
-                 H % (64 // min(W, 64)) == 0 and dil in (1, 2))
-        if fused:
-            wt = min(W, 64)     # ring stages as rgda_conv2d_wgrad_grouped picks them (two workgroups per CU where two rings fit)
-            if (wt, dil) in ((64, 1), (64, 2), (32, 2)):
-                return 'conv_wgrad3x3_wide_kernel<%d, %d, 3>' % (wt, dil)
-            return 'conv_wgrad3x3_kernel<%d, %d, %d>' % (wt, dil, 3 if (wt, dil) == (16, 1) else 2)
-        bco, bci = (64 if co <= 64 else 128), (64 if ci <= 64 else 128)
-        if bci == 128 and co >= 256 and co % 256 == 0:
-            bco = 256
-        wi, wj = {(256, 128): (4, 2), (128, 128): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4), (64, 64): (2, 2)}[(bco, bci)]
-        return 'conv_wgrad_kernel<%d, %d, %d, %d, 3>' % (bco, bci, wi, wj)
+        S, T, Cin = dw.shape
+        stacked = kh * kw == 1 and T > 1
+        d = ops._WgradDesc()
+        d.x, d.dy, d.dw, d.ldx, d.lddy = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), x.stride(0), dy.stride(0)
+        d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, (S * T if stacked else S)
+        d.kh, d.kw, d.stride, d.pad, d.dil = kh, kw, stride, pad, dil
+        d.lddw, d.co_split = dw.stride(1), (S if stacked else 0)
+        name = wname(ctypes.byref(d))
+        return name.decode() if name else 'conv_wgrad (unserved)'
 
     def wgrad_grouped(items):
         # the library buckets a list by kernel instantiation (order kept, 16 layers per launch); hand it one
@@ -165,7 +157,7 @@ def conv_flops_probe(step_fn, park_ms=150.0):
     def wgrad(*item):
         wgrad_grouped([item])
     ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd = conv, wgrad, conv_bne, conv_bnb
-    ops.conv2d_wgrad_grouped = wgrad_grouped
+    ops.conv2d_wgrad_grouped, ops.conv2d_bnin = wgrad_grouped, conv_bnin
     # The wrappers make the host slower than the GPU for the short kernels, and an event pair then also brackets the
     # host's enqueue time between `e0.record()` and the launch.  Park the stream behind a spin kernel long enough for
     # the host to enqueue the whole step first: every bracket then measures queue-to-queue GPU time only.
@@ -188,7 +180,7 @@ def conv_flops_probe(step_fn, park_ms=150.0):
         torch.cuda.synchronize()
     finally:
         ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd = o_conv, o_wgrad, o_bne, o_bnb
-        ops.conv2d_wgrad_grouped = o_wgrad_g
+        ops.conv2d_wgrad_grouped, ops.conv2d_bnin = o_wgrad_g, o_bnin
     kern, shapes = {}, {}
     c3 = [0.0, 0.0]                                # FLOPs / ms of the 3x3 convolutions (forward, data and weight gradient)
     for r in rec:
@@ -330,12 +322,15 @@ def respawn_under_launcher(args):
 
 def main():
     args = parse()
+    gpus_given = args.gpus is not None
+    if not gpus_given:          # under a launcher (torchrun ... bench.py) its world size is adopted; alone: one GPU
+        args.gpus = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(respawn_under_launcher(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
+    if world != args.gpus:      # only an EXPLICIT --gpus that disagrees with the launcher is an error
         sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     if args.backend == 'gloo':          # launcher self-test on a CPU box: rendezvous, one all-reduce, one JSON line
         dist.init_process_group('gloo')

@@ -1402,6 +1402,9 @@ static int stem_conv_launch(const float* img, const void* wgt, void* y, int ldy,
     if (!img || !wgt || !y || N <= 0 || H <= 0 || W <= 0 || (ldy & 7) || ldy < 64) return RGDA_ERR_ARG;
     if (Ho != (H + 6 - 7) / 2 + 1 || Wo != (W + 6 - 7) / 2 + 1) return RGDA_ERR_ARG;
     if (Wo % 64) return RGDA_ERR_UNSUPPORTED;           // the im2col + 1x1 route serves these
+    // the kernel packs the filter row into bits 28-30 of a per-thread image offset: images of 2^28 elements and more
+    // (~9.4 k x 9.4 k) take the im2col route as well
+    if ((long long)3 * H * W >= (1ll << 28)) return RGDA_ERR_UNSUPPORTED;
     if (stat_groups < 1) stat_groups = 1;
     if ((N % stat_groups) || (bne && stats)) return RGDA_ERR_ARG;
     const long long M = (long long)N * Ho * Wo;
@@ -1592,7 +1595,7 @@ static int stem_wgrad_rows(int N, int Ho, int Wo) {
 extern "C" size_t rgda_stem_wgrad_workspace(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    if (Wo % 64) return 0;
+    if ((Wo % 64) || (long long)3 * H * W >= (1ll << 28)) return 0;
     return (size_t)N * (Ho / stem_wgrad_rows(N, Ho, Wo)) * (Wo / 64) * 64 * 192 * sizeof(float);
 }
 
@@ -1601,6 +1604,7 @@ extern "C" int rgda_stem_wgrad(const float* img, const void* dy, int lddy, float
     if (!img || !dy || !dw || !ws || N <= 0 || H <= 0 || W <= 0 || (lddy & 7) || lddy < 64) return RGDA_ERR_ARG;
     if (Ho != (H + 6 - 7) / 2 + 1 || Wo != (W + 6 - 7) / 2 + 1) return RGDA_ERR_ARG;
     if (Wo % 64) return RGDA_ERR_UNSUPPORTED;           // rgda_stem_im2col + rgda_conv2d_wgrad serve these
+    if ((long long)3 * H * W >= (1ll << 28)) return RGDA_ERR_UNSUPPORTED;      // (offset packing, see stem_conv_launch)
     if (((uintptr_t)ws & 15) || ws_bytes < rgda_stem_wgrad_workspace(N, H, W)) return RGDA_ERR_WORKSPACE;
     const int rpw = stem_wgrad_rows(N, Ho, Wo);
     const long long blocks = (long long)N * (Ho / rpw) * (Wo / 64);
@@ -2328,7 +2332,12 @@ static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipS
     int counters = 0;
     for (int l = 0; l < g.n; ++l)
         if (g.a[l].splits > 1) counters += wgrad_tiles(g.a[l]) * (split_groups(g.a[l].splits) + 1);
-    if (need && (ws_bytes < RGDA_WGRAD_WS_COUNTERS + need || (size_t)counters * 4 > RGDA_WGRAD_WS_COUNTERS)) return RGDA_ERR_WORKSPACE;
+    if (need && (size_t)counters * 4 > RGDA_WGRAD_WS_COUNTERS) {
+        // more result tiles than tile counters: this launch runs unsplit (slower, never wrong) instead of failing
+        wgrad_plan_splits(kind, g, false);
+        return wgrad_launch(kind, g, nullptr, 0, st);
+    }
+    if (need && ws_bytes < RGDA_WGRAD_WS_COUNTERS + need) return RGDA_ERR_WORKSPACE;
     for (int l = 0; l < g.n; ++l) {
         WgradArgs& a = g.a[l];
         a.ws_part = (float*)((char*)ws + RGDA_WGRAD_WS_COUNTERS) + (size_t)(uintptr_t)a.ws_part;
@@ -2417,7 +2426,11 @@ extern "C" int rgda_conv2d_wgrad_grouped(const rgda_wgrad_desc* descs, int n, vo
     if (n < 0 || (n > 0 && !descs)) return RGDA_ERR_ARG;
     if (ws && (ws_bytes < RGDA_WGRAD_WS_COUNTERS || ((uintptr_t)ws & 15))) return RGDA_ERR_WORKSPACE;
     hipStream_t st = to_stream(stream);
-    return wgrad_for_each_launch(descs, n, [&](int kind, WgradGroup& g) { return wgrad_launch(kind, g, ws, ws_bytes, st); });
+    const int rc = wgrad_for_each_launch(descs, n, [&](int kind, WgradGroup& g) { return wgrad_launch(kind, g, ws, ws_bytes, st); });
+    // the split-K protocol relies on the tile counters being zero between launches: after a failed call (some launches of
+    // the list may have run, one did not) they are cleared behind whatever is in flight, so later calls start clean
+    if (rc != RGDA_OK && ws) (void)hipMemsetAsync(ws, 0, RGDA_WGRAD_WS_COUNTERS, st);
+    return rc;
 }
 
 extern "C" int rgda_conv2d_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, int N, int H, int W,

@@ -1055,7 +1055,7 @@ class Deeplabv2(nn.Module):
         B = self.bns
         H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         col_ready = None
-        if W1 % 64 == 0 and self.fused_stem:
+        if W1 % 64 == 0 and self.fused_stem and 3 * H * W < (1 << 28):      # (what rgda_stem_conv / rgda_stem_wgrad serve)
             a0, col_ready = self._stem_fwd(T, xs, Ng, H, W, H1, W1, main_stream)
         else:
             col = torch.empty(N * H1 * W1, STEM_KP, dtype=BF, device=dev)

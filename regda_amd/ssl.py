@@ -112,7 +112,7 @@ class SSLStep:
         if t is None:
             return None
         t.adopt_buffers(self.model)
-        t.refresh_from_master(mirror_is_fresh=not self.first)
+        t.refresh_from_master(mirror_is_fresh=(not self.first) and t.flat_p._version == t._synced_version)
         t.eval()
         return t
 
@@ -359,7 +359,9 @@ class SSLStep:
         t = self.teacher
         if snapshot:
             t.adopt_buffers(self.model)
-        t.refresh_from_master(mirror_is_fresh=True)       # make_teacher() and every sgd_step keep flat_pb current
+        # make_teacher() and every sgd_step keep flat_pb current; a write to the shadow from OUTSIDE the step (a resume
+        # that copies into teacher.flat_p or its parameter views) bumps the tensor's version and forces a re-cast
+        t.refresh_from_master(mirror_is_fresh=(t.flat_p._version == t._synced_version))
         t.eval()
         x1, x2, _ = t._forward_plan(images_t.contiguous().float(), None)
         return ops.teacher_probs(x1, x2, tuple(images_t.shape[-2:]))

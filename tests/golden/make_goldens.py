@@ -350,6 +350,80 @@ def gold_model():
          nbt=sdn['encoder.resnet.bn1.num_batches_tracked'].numpy(), probs=probs.numpy(), **grads)
 
 
+MID_GRADS = ['encoder.resnet.conv1.weight', 'encoder.resnet.bn1.weight', 'encoder.resnet.layer1.0.conv1.weight',
+             'encoder.resnet.layer1.2.bn3.weight', 'encoder.resnet.layer2.1.conv2.weight[:8]', 'encoder.resnet.layer2.3.bn3.bias',
+             'encoder.resnet.layer3.0.downsample.0.weight[:8]', 'encoder.resnet.layer3.5.conv2.weight[:4]',
+             'encoder.resnet.layer3.11.bn2.weight', 'encoder.resnet.layer3.17.conv1.weight[:16]',
+             'encoder.resnet.layer3.22.conv3.weight[:64]', 'encoder.resnet.layer4.0.conv2.weight[:2]',
+             'encoder.resnet.layer4.2.bn3.bias', 'layer5.ppm.3.1.weight[:8]', 'layer5.conv_last.0.weight[:1]',
+             'layer6.conv_last.1.weight', 'layer6.conv_last.4.weight']
+MID_RES_GAMMA = 0.02        # residual-branch gain of this fixture's weights (tests/golden/derive_tolerances.py: FULL_RES_GAMMA)
+
+
+def gold_model128():
+    """The reference's SSL step (tools/train_ssl_reg.py:198-241, composed as in gold_model) on ResNet-101 at 2 x 3 x 128 x 128
+    -- 8 x 8 feature maps: the deep BatchNorm layers see 128 values per channel and domain instead of the 32 of
+    model_small.npz -- with weights whose residual branches have gain 0.02 (oracle.model.init_state_dict(seed=3,
+    res_gamma=0.02)): the better-conditioned reference-minted fixture of the GPU suite.  Stores the inputs, both losses,
+    the gradient norm, refined soft labels (fp16), pseudo labels, prototypes and 17 gradient tensors (slices of the large
+    ones) spread over the depth of the network."""
+    m = build_ref_model()
+    sd = omodel.init_state_dict('resnet101', 6, seed=3, res_gamma=MID_RES_GAMMA)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    masks = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            i, o = inp[0].detach(), out.detach()
+            keep = ((o != 0).flatten(2).any(-1) | (i == 0).flatten(2).all(-1))
+            masks.setdefault(name, []).append(keep.numpy().astype(np.uint8))
+        return fn
+    m.layer5.conv_last[3].register_forward_hook(hook('m5'))
+    m.layer6.conv_last[3].register_forward_hook(hook('m6'))
+    g = torch.Generator().manual_seed(4242)
+    b, S = 2, 128
+    xs = torch.randn(b, 3, S, S, generator=g)
+    xt = torch.randn(b, 3, S, S, generator=g).clamp(max=1.0)
+    rng = np.random.default_rng(4242)
+    lab_s = torch.from_numpy(np.kron(rng.integers(-1, 6, size=(b, S // 16, S // 16)), np.ones((16, 16), np.int64)))
+    soft_t = torch.softmax(torch.randn(b, 6, S, S, generator=g) * 3, 1)
+    regs = torch.from_numpy(random_regions(rng, b, S, S, 24))[:, None]
+    protos = torch.randn(6, 2048, generator=g)
+    al = Aligner(logger=_Log(), feat_channels=2048, class_num=6, ignore_label=-1, decay=0.996, resume=None)
+    al.prototypes = protos.clone()
+    hom = Homogenizer(percent=0.5, class_num=6, ignore_label=-1)
+    ce = CrossEntropy(ignore_label=-1, class_balancer=None)
+    torch.manual_seed(4242)
+    s1, s2, fs = m(xs)
+    t1, t2, ft = m(xt)
+    soft2 = al.label_refine(None, ft, [t1, t2], soft_t, refine=True, mode='all', temp=2.0)
+    hard = pseudo_selection(soft2, 0.8, 0.6, 'tensor', -1)
+    hard2 = hom(hard, regs.squeeze(1))
+    al.update_prototype(fs, lab_s)
+    ls = loss_calc([s1, s2], lab_s, loss_fn=ce, multi=True)
+    lt = loss_calc([t1, t2], hard2, loss_fn=ce, multi=True)
+    (ls + lt).backward()
+    named = dict(m.named_parameters())
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values())).item()
+    grads = {}
+    for k in MID_GRADS:
+        name, _, sl = k.partition('[')
+        gk = named[name].grad
+        if sl:
+            gk = gk[:int(sl[1:-1])]
+        grads['grad:' + k] = gk.numpy()
+    sdn = m.state_dict()
+    save('model_mid.npz', xs=xs.numpy(), xt=xt.numpy(), lab_s=lab_s.numpy().astype(np.int8),
+         soft_t=soft_t.numpy(), regs=regs.numpy().astype(np.int32), protos=protos.numpy(),
+         m5=np.stack(masks['m5']), m6=np.stack(masks['m6']),
+         s1=s1.detach().numpy(), s2=s2.detach().numpy(), t1=t1.detach().numpy(), t2=t2.detach().numpy(),
+         soft2=soft2.detach().numpy().astype(np.float16), hard=hard.numpy().astype(np.int8), hard2=hard2.numpy().astype(np.int8),
+         protos_new=al.prototypes.numpy(), loss_s=ls.detach().numpy(), loss_t=lt.detach().numpy(),
+         grad_norm=np.float64(gn), bn1_rm=sdn['encoder.resnet.bn1.running_mean'].numpy(),
+         nbt=sdn['encoder.resnet.bn1.num_batches_tracked'].numpy(), **grads)
+
+
 def gold_align():
     """One stage-2 iteration on the reference model, composed exactly like tools/train_align_reg.py:144-196 (defaults
     --align-domain 0, --refine-label 1, --refine-mode all, --refine-temp 2, --sam-refine, --pcl-temp 8), same inputs as
@@ -499,6 +573,6 @@ def gold_aspp():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'tta', 'pcl', 'align', 'aspp', 'regions']
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'model128', 'tta', 'pcl', 'align', 'aspp', 'regions']
     for w in which:
         globals()['gold_' + w]()

@@ -168,6 +168,39 @@ def test_full_step_small(small_case):
     np.testing.assert_allclose(probs.numpy(), g['probs'], rtol=2e-3, atol=2e-5)
 
 
+def _slice_of(name, tensors):
+    """'a.b.weight[:8]' -> tensors['a.b.weight'][:8]."""
+    base, _, sl = name.partition('[')
+    t = tensors[base]
+    return t[:int(sl[1:-1])] if sl else t
+
+
+def test_full_step_mid_size(gold):
+    """oracle.step.CpuStep against the reference's step on the better-conditioned ResNet-101 fixture (model_mid.npz: minted
+    by make_goldens.gold_model128 at 2 x 3 x 128 x 128, residual gain 0.02): losses, refined soft labels, pseudo labels,
+    gradient norm, prototypes and all 17 stored gradient tensors over the depth of the network."""
+    g = gold('model_mid.npz')
+    sd = model.init_state_dict('resnet101', 6, seed=3, res_gamma=0.02)
+    t = lambda k: torch.from_numpy(g[k])
+    st = step.CpuStep(sd, t('protos'), lr=0.0)
+    m5, m6 = t('m5'), t('m6')
+    r = st.step(t('xs'), t('lab_s').long(), t('xt'), t('soft_t'), t('regs').long(), (m5[0], m6[0]), (m5[1], m6[1]))
+    np.testing.assert_allclose(r['preds'][2].numpy(), g['t1'], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(r['soft'].numpy(), g['soft2'].astype(np.float32), rtol=2e-3, atol=1e-3)     # stored as fp16
+    assert (r['hard'].numpy() != g['hard2'].astype(np.int64)).mean() < 2e-3
+    assert r['loss_source'] == pytest.approx(float(g['loss_s']), rel=1e-4)
+    assert r['loss_target'] == pytest.approx(float(g['loss_t']), rel=2e-3)
+    assert r['grad_norm'] == pytest.approx(float(g['grad_norm']), rel=5e-3)
+    np.testing.assert_allclose(st.prototypes.numpy(), g['protos_new'], rtol=1e-4, atol=1e-6)
+    keys = [k[5:] for k in g.files if k.startswith('grad:')]
+    assert len(keys) >= 12
+    for k in keys:
+        ref = g['grad:' + k]
+        got = _slice_of(k, r['grads']).numpy()
+        assert np.abs(got - ref).max() <= 1e-2 * np.abs(ref).max() + 1e-7, k
+    np.testing.assert_allclose(st.sd['encoder.resnet.bn1.running_mean'].numpy(), g['bn1_rm'], rtol=1e-4, atol=1e-6)
+
+
 def test_teacher_harness_oracle_vs_reference(gold):
     """oracle/teacher.py (pre_slide, tta_predict, soft-label resize) against the reference's own functions
     (tests/golden/tta.npz; ttach restated, see the oracle's header)."""

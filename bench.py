@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--serial', action='store_true', help='one stream only (clean per-kernel profiles)')
+    ap.add_argument('--grad-payload', default='fp32', choices=['fp32', 'bf16'], help="gradient exchange: 'fp32' bucketed all-reduce (default), 'bf16' all-to-all + fp32 accumulation + all-gather of bf16 payloads (half the bytes per link)")
     ap.add_argument('--no-comm-overlap', action='store_true', help='all-reduce the whole gradient after backward instead of bucket by bucket during it')
     ap.add_argument('--eager', action='store_true', help='one Python -> ctypes call per launch instead of the recorded launch plan (regda_amd/plan.py, the default)')
     ap.add_argument('--no-h2d', action='store_true', help='reuse one device-resident batch instead of staging a fresh pinned host batch per step over a copy stream')
@@ -377,7 +378,9 @@ def main():
         model.sync_weights()
     protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
     teacher = not args.no_teacher
-    step = SSLStep(model, protos, ema_decay=0.999 if teacher else None, overlap_wgrad=not args.serial, overlap_comm=not args.no_comm_overlap)
+    step = SSLStep(model, protos, ema_decay=0.999 if teacher else None, overlap_wgrad=not args.serial, overlap_comm=not args.no_comm_overlap,
+                   grad_payload=args.grad_payload)
+    step.measure_comm = world > 1 or bool(os.environ.get('RGDA_FORCE_DDP'))
     batch = make_batch(b=args.batch, size=args.size, seed=2333 + rank, with_soft=not teacher)
     soft = batch.get('soft_t')
     it = [0]
@@ -453,6 +456,23 @@ def main():
         torch.cuda.synchronize()
         dt_h2d = timed_steps()[0]       # the same K steps with the reference's per-iteration host -> device move
     losses = [float(x.item()) for x in out]
+    # exposed communication of the LAST timed step: how long the main stream stood at the join with the gradient exchange
+    # (HIP events around reducer.finish); every rank reports its own, rank 0 also the maximum
+    comm = None
+    if step.comm_events is not None:
+        torch.cuda.synchronize()
+        mine = step.comm_events[0].elapsed_time(step.comm_events[1])
+        print('rank %d: exposed gradient-exchange wait %.3f ms/step, rccl ranks %d, payload %s, %d buckets' % (
+            rank, mine, dist.get_world_size() if dist.is_initialized() else 1, args.grad_payload, len(step.reducer.buckets)),
+            file=sys.stderr, flush=True)
+        worst = mine
+        if world > 1:
+            t = torch.tensor([mine], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = float(t.item())
+        comm = {'rank0_ms': mine, 'max_over_ranks_ms': worst, 'payload': args.grad_payload,
+                'mb_per_step_per_rank': step.reducer.flat_g.numel() * (4 if args.grad_payload == 'fp32' else 2) / 1e6,
+                'what': 'main-stream stall at the join with the bucketed gradient exchange (HIP events around reducer.finish), last timed step'}
     # host cost of enqueueing ONE step, measured from an idle queue (in the timed loop above the GPU is the bottleneck and
     # the launch queue pushes back on the host, so that loop's host time mostly shows the back-pressure)
     t_iso = []
@@ -492,6 +512,7 @@ def main():
             'pairs_per_s': pairs / dt_h2d, 'ms_per_step': dt_h2d / args.steps * 1e3,
             'mb_per_step': pf[0].bytes_per_batch / 1e6},
         'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+        'comm_exposed_ms': comm,
         # whole-step MFMA fraction on the REFERENCE's convolution FLOPs (1268 GFLOP/pair with the teacher forward): an
         # "effective" figure -- the step executes fewer (the head conv is re-associated); the executed-FLOP
         # fraction is roofline.step_executed_mfma_frac

@@ -419,6 +419,12 @@ int rgda_weight_transpose_bf16(const float* w, void* wt, int Co, int T, int Ci, 
  * at first_block. */
 int rgda_weight_transpose_batched(const int64_t* table, int n, int64_t total_blocks, rgda_stream_t stream);
 int rgda_cast_bf16(const float* src, void* dst, int64_t n, rgda_stream_t stream);
+int rgda_cast_f32(const void* src_bf16, float* dst, int64_t n, rgda_stream_t stream);
+/* Gradient exchange with bf16 payloads and fp32 accumulation (regda_amd/ddp.py, payload 'bf16'; the reference has no
+ * data-parallel path): recv bf16 [world][shard_elems] = this rank's shard of a bucket as every rank sent
+ * it (all-to-all); out bf16 [shard_elems] = bf16(sum over ranks IN RANK ORDER of float(recv[r])) -- the same bits on
+ * every rank.  shard_elems % 8 == 0. */
+int rgda_ddp_accumulate_bf16(const void* recv, int world, void* out, int64_t shard_elems, rgda_stream_t stream);
 /* rows of K f32 -> rows of Kp bf16, zero padded (stem weights [64][147] -> [64][192]); and the
  * reverse accumulation dst[R][K] f32 += src[R][Kp] f32 for the stem weight gradient. */
 int rgda_pad_cast_bf16(const float* src, void* dst, int R, int K, int Kp, rgda_stream_t stream);

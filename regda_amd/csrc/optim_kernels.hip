@@ -127,6 +127,45 @@ extern "C" int rgda_cast_bf16(const float* src, void* dst, int64_t n, rgda_strea
     return RGDA_OK;
 }
 
+// ---- gradient exchange with bf16 payloads (regda_amd/ddp.py, payload = 'bf16'): every rank receives its shard of the
+// bucket from every rank as bf16 (all-to-all), adds the `world` copies in fp32 IN RANK ORDER (the same order on every rank,
+// whatever arrived first) and rounds the sum to bf16 once; the reduced shards are all-gathered as bf16 and widened back
+// into the fp32 gradient buffer the optimizer reads.  Half the bytes of an fp32 all-reduce on every link, fp32 accumulation.
+__global__ void __launch_bounds__(256) ddp_accumulate_bf16_kernel(const bf16_t* __restrict__ recv, int world, bf16_t* __restrict__ out,
+                                                                  long long s) {
+    const long long nv = s >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < world; ++r) {
+            const u16x8 v = *(const u16x8*)(recv + (size_t)r * s + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        }
+        uint4 pk;
+        pk.x = pack2bf(acc[0], acc[1]); pk.y = pack2bf(acc[2], acc[3]); pk.z = pack2bf(acc[4], acc[5]); pk.w = pack2bf(acc[6], acc[7]);
+        *(uint4*)(out + i * 8) = pk;
+    }
+}
+
+extern "C" int rgda_ddp_accumulate_bf16(const void* recv, int world, void* out, int64_t shard_elems, rgda_stream_t stream) {
+    if (!recv || !out || world < 1 || shard_elems <= 0 || (shard_elems & 7)) return RGDA_ERR_ARG;
+    const int blocks = min(cdiv(shard_elems >> 3, 256), 2048);
+    ddp_accumulate_bf16_kernel<<<blocks, 256, 0, to_stream(stream)>>>((const bf16_t*)recv, world, (bf16_t*)out, shard_elems);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+__global__ void __launch_bounds__(256) cast_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = bf2f(src[i]);
+}
+
+extern "C" int rgda_cast_f32(const void* src, float* dst, int64_t n, rgda_stream_t stream) {
+    if (!src || !dst || n <= 0) return RGDA_ERR_ARG;
+    cast_f32_kernel<<<min(cdiv(n, 256 * 8), 4096), 256, 0, to_stream(stream)>>>((const bf16_t*)src, dst, n);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
 // w [Co][T][Ci] f32 -> wt [Ci][T][Co] bf16, 32x32 LDS tiles per tap
 __global__ void __launch_bounds__(256) weight_transpose_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt, int Co,
                                                                int T, int Ci) {

@@ -4,8 +4,18 @@ on the GPU box, "gloo" in the CPU tests.
 
 The gradient is ONE flat tensor laid out in forward order, so backward finalises it from the END towards
 the start: buckets are contiguous ranges issued in reverse order as soon as the backward pass has moved
-below them (the last one, which nothing can overlap, is kept short), each as an async all-reduce (sum) that overlaps the remaining dgrad/wgrad kernels; the
+below them (the last one, which nothing can overlap, is kept short), each overlapping the remaining dgrad/wgrad kernels; the
 1/world scale is folded into the fused clip+SGD kernel (`gscale`), not applied as a separate pass.
+
+Two payloads (`payload=`):
+  'fp32' (default until an 8-GPU run says otherwise): one async all-reduce (sum) of the fp32 bucket -- 2 (N-1)/N x 4 bytes
+         per element over every rank's links.
+  'bf16': the bucket is cast to bf16 and exchanged in two phases -- all-to-all of the N shards (each rank receives ITS
+         shard from every rank), fp32 accumulation of the N copies on arrival in rank order, the bf16-rounded sums
+         all-gathered and widened back into the fp32 buffer: 2 (N-1)/N x 2 bytes per element, HALF the fp32 all-reduce at
+         every N, no bf16 addition anywhere (a bf16 all-reduce would round after each of its N-1 adds).  Every rank ends
+         with the same bits (its own shard goes through the same bf16 rounding as everyone else's copy of it).  The sum
+         differs from the fp32 all-reduce by at most half a bf16 ulp per contribution plus half an ulp of the result.
 """
 import torch
 import torch.distributed as dist
@@ -38,29 +48,81 @@ def make_buckets(boundaries, total, bucket_elems, tail_elems=None):
 
 
 class FlatGradReducer:
-    def __init__(self, flat_g, boundaries, bucket_elems=12 << 20, group=None):
+    def __init__(self, flat_g, boundaries, bucket_elems=12 << 20, group=None, payload='fp32'):
+        assert payload in ('fp32', 'bf16')
         self.flat_g = flat_g
         self.group = group
+        self.payload = payload
         import os
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = dist.is_initialized() and bool(os.environ.get('RGDA_FORCE_DDP'))   # single-GPU exercise of the path
         self.buckets = make_buckets(boundaries, flat_g.numel(), bucket_elems)
         self._next = 0
         self._works = []
+        self._stage = {}            # bf16 payload: per-bucket staging buffers, allocated once
+        self._comm_stream = None    # bf16 payload on a GPU: the two collectives and the kernels between them run here
 
     def reset(self):
         self._next = 0
         self._works = []
 
+    @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    # ---- bf16 payload
+    def _staging(self, a, b):
+        st = self._stage.get((a, b))
+        if st is None:
+            n, W = b - a, self.world
+            shard = -(-n // (W * 8)) * 8                    # elements per rank, a multiple of 8 (16-byte vectors)
+            dev = self.flat_g.device
+            z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+            st = dict(shard=shard, send=z(W * shard), recv=z(W * shard), red=z(shard), gath=z(W * shard))
+            self._stage[(a, b)] = st
+        return st
+
+    def _exchange_bf16(self, a, b):
+        st, W, g = self._staging(a, b), self.world, self.flat_g[a:b]
+        n = b - a
+        if g.is_cuda:
+            from . import ops
+            ops.cast_bf16(g, st['send'])                    # (the tail of `send` beyond n stays zero)
+            dist.all_to_all_single(st['recv'], st['send'], group=self.group)
+            ops.ddp_accumulate_bf16(st['recv'], W, st['red'])
+            dist.all_gather_into_tensor(st['gath'], st['red'], group=self.group)
+            ops.cast_f32(st['gath'], g)
+        else:       # gloo on CPU tensors (tests): the same arithmetic in torch
+            st['send'][:n].copy_(g)
+            dist.all_to_all_single(st['recv'], st['send'], group=self.group)
+            acc = torch.zeros(st['shard'])
+            for r in range(W):                              # rank order
+                acc += st['recv'][r * st['shard']:(r + 1) * st['shard']].float()
+            st['red'].copy_(acc)
+            dist.all_gather_into_tensor(st['gath'], st['red'], group=self.group)
+            g.copy_(st['gath'][:n])
+
     def ready_down_to(self, offset):
         """Backward has finished every gradient at element offset >= `offset`: launch the buckets that
         lie entirely above it."""
-        if self.world == 1 and not self.force:
+        if not self.active:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= offset:
             a, b = self.buckets[self._next]
-            self._works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True))
+            if self.payload == 'fp32':
+                self._works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                   async_op=True))
+            elif self.flat_g.is_cuda:
+                # a stream of its own: the collectives and the small kernels between them are ordered there, behind what
+                # the caller's stream has produced so far, and the caller's stream (weight gradients) runs on
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream(device=self.flat_g.device)
+                self._comm_stream.wait_stream(torch.cuda.current_stream())
+                from . import ops
+                with ops.use_stream(self._comm_stream):
+                    self._exchange_bf16(a, b)
+            else:
+                self._exchange_bf16(a, b)
             self._next += 1
 
     def finish(self):
@@ -69,6 +131,8 @@ class FlatGradReducer:
         for w in self._works:
             w.wait()
         self._works = []
+        if self._comm_stream is not None and self.active:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     @property
     def gscale(self):

@@ -549,6 +549,14 @@ def cast_bf16(src, dst):
     lib().call('rgda_cast_bf16', src.data_ptr(), dst.data_ptr(), src.numel(), _stream())
 
 
+def cast_f32(src, dst):
+    lib().call('rgda_cast_f32', src.data_ptr(), dst.data_ptr(), dst.numel(), _stream())
+
+
+def ddp_accumulate_bf16(recv, world, out):
+    lib().call('rgda_ddp_accumulate_bf16', recv.data_ptr(), world, out.data_ptr(), out.numel(), _stream())
+
+
 def pad_cast_bf16(src, dst, R, K, Kp):
     lib().call('rgda_pad_cast_bf16', src.data_ptr(), dst.data_ptr(), R, K, Kp, _stream())
 

@@ -21,7 +21,7 @@ class SSLStep:
                  max_norm=32.0, cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996, refine_temp=2.0,
                  sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=12 << 20,
                  process_group=None, overlap_wgrad=True, overlap_comm=True, class_balancer_s=None,
-                 class_balancer_t=None):
+                 class_balancer_t=None, grad_payload='fp32'):
         self.model = model
         self.C, self.ig = class_num, ignore_label
         self.momentum, self.wd, self.max_norm = momentum, weight_decay, max_norm
@@ -42,7 +42,11 @@ class SSLStep:
         if ema_decay is not None:
             self.teacher = model.make_teacher()
         bounds = model.param_boundaries()
-        self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group)
+        # grad_payload: 'fp32' = bucketed all-reduce of the fp32 gradient; 'bf16' = all-to-all + fp32 accumulation +
+        # all-gather of bf16 payloads, half the bytes on every link (regda_amd/ddp.py)
+        self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group, payload=grad_payload)
+        self.measure_comm = False   # bench: HIP events around the main stream's wait for the gradient exchange
+        self.comm_events = None
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
         self.source_side = overlap_wgrad    # source half of the label path on the second stream
         # --bcs / --bct of tools/train_ssl_reg.py:54-58,125-158: regda_amd.gast.balance.ClassBalance objects whose
@@ -283,7 +287,7 @@ class SSLStep:
                            ws=self.lrh_ws)
         if side is None:
             ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
-        if self.world > 1 or self.reducer.force:
+        if self.reducer.active:
             # keep the prototypes identical on every rank: averaged over the ranks.  Nothing of THIS step
             # reads them any more (label_refine is done), so the 48 KB all-reduce -- pure latency -- runs on the second
             # stream next to backward and the next step's label path waits for it
@@ -340,7 +344,18 @@ class SSLStep:
                     plan.host(lambda: self.reducer.ready_down_to(offset))
         m._backward_plan(T, g1, g2, on_progress=progress, gfeat=gfeat)
         self._mark('backward done (streams joined)')
-        plan.host(self.reducer.finish)
+        def finish_exchange():
+            # everything the main stream still has to wait for here is EXPOSED communication (the buckets were issued
+            # while backward ran); with measure_comm the stall is bracketed by events (bench.py: comm_exposed_ms)
+            if self.measure_comm and self.reducer.active:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.reducer.finish()
+                e1.record()
+                self.comm_events = (e0, e1)
+            else:
+                self.reducer.finish()
+        plan.host(finish_exchange)
         # ---- clip + SGD (+ EMA) in one pass over the flat buffers
         ops.sumsq(m.flat_g, self.gn, self.gn_ws)
         shadow = self.teacher.flat_p if self.teacher is not None else None

@@ -74,6 +74,59 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_bf16(rank, world, port, q):
+    """payload='bf16' against the fp32 all-reduce on the same gradients: every element within the rounding the scheme
+    states (half a bf16 ulp per contribution + half an ulp of the result), identical bits on both ranks, and exact where
+    the inputs are exactly representable."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n = 10007                                           # not a multiple of world * 8: the shard padding is exercised
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(n, generator=g) * torch.logspace(-6, 2, n)        # eight decades of magnitudes
+    bounds = [1000, 2500, 6000, 9000]
+    ref = mine.clone()
+    r32 = FlatGradReducer(ref, bounds, bucket_elems=2000)
+    r32.reset(); r32.finish()
+    ok = True
+    for rep in range(2):                                # the reducer (and its staging buffers) are reused every step
+        got = mine.clone()
+        r16 = FlatGradReducer(got, bounds, bucket_elems=2000, payload='bf16') if rep == 0 else r16
+        r16.flat_g = got
+        r16.reset()
+        for off in (9000, 6000, 2500, 1000):
+            r16.ready_down_to(off)
+        r16.finish()
+        parts = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        # one bf16 ulp of a value v is 2^-7 |v| at most (8 significant bits): half an ulp per contribution + half of the sum's
+        bound = sum(p.abs() for p in parts) * 2.0 ** -8 + ref.abs() * 2.0 ** -8 + 1e-30
+        ok = ok and bool(((got - ref).abs() <= bound).all())
+        both = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(both, got)
+        ok = ok and torch.equal(both[0], both[1])       # the same bits on every rank
+    # exactly representable inputs (small integers): the bf16 path is exact
+    ints = torch.arange(n).remainder(64).float() * (rank + 1)
+    e16 = ints.clone()
+    rr = FlatGradReducer(e16, bounds, bucket_elems=2000, payload='bf16')
+    rr.reset(); rr.finish()
+    ok = ok and torch.equal(e16, torch.arange(n).remainder(64).float() * sum(r + 1 for r in range(world)))
+    q.put((rank, bool(ok), len(r16.buckets)))
+    dist.destroy_process_group()
+
+
+def test_bf16_payload_matches_the_fp32_all_reduce_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_bf16, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+
+
 def test_flat_grad_reducer_gloo_world2():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()

@@ -148,3 +148,50 @@ def test_recorded_plan_replays_the_collectives(nccl_world1):
         assert op[0] == pytest.approx(oe[0], rel=5e-2) and op[2] == pytest.approx(oe[2], rel=0.3)
     assert ((m_p.flat_p - m_e.flat_p).norm() / m_e.flat_p.norm()).item() < 1e-3
     assert ((st_p.prototypes - st_e.prototypes).norm() / st_e.prototypes.norm()).item() < 5e-3
+
+
+def test_bf16_payload_exchange_through_rccl(nccl_world1):
+    """payload='bf16' on the GPU through RCCL at world size 1 (all-to-all, rgda_ddp_accumulate_bf16, all-gather,
+    rgda_cast_f32 on the reducer's own stream): with one rank the exchanged gradient is the bf16-rounded gradient, bit for
+    bit, and a full step with that payload stays within bf16 rounding of the plain step's losses."""
+    from regda_amd.ddp import FlatGradReducer
+    g = torch.randn(100003, device='cuda') * torch.logspace(-5, 3, 100003, device='cuda')
+    want = g.to(torch.bfloat16).float()
+    red = FlatGradReducer(g, [1000, 30000, 70000], bucket_elems=20000, payload='bf16')
+    assert red.force and red.active
+    red.reset()
+    for off in (70000, 30000, 1000):
+        red.ready_down_to(off)
+    red.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)
+    g2 = want.clone()                    # a second step reuses the staging buffers; bf16 values pass unchanged
+    red.flat_g = g2
+    red.reset()
+    red.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(g2, want)
+    # a whole step
+    from regda_amd.models.Encoder import Deeplabv2
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    outs = {}
+    for payload in ('fp32', 'bf16'):
+        m = Deeplabv2(dict(backbone=dict(resnet_type=rt, output_stride=16, pretrained=False), multi_layer=True,
+                           cascade=False, use_ppm=True, ppm=dict(num_classes=6, use_aux=False, fc_dim=2048),
+                           inchannels=2048, num_classes=6, is_ins_norm=True))
+        m.load_state_dict(omodel.init_state_dict(rt, 6, seed=2), strict=True)
+        ones = torch.ones(4, 512)
+        m.set_drop_masks(ones, ones)
+        b = make_batch(b=2, size=128, seed=13)
+        st = SSLStep(m, torch.randn(6, 2048, generator=torch.Generator().manual_seed(3)), bucket_elems=1 << 20, grad_payload=payload)
+        st.measure_comm = True
+        for _ in range(2):
+            out = st.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], lr=1e-3)
+        torch.cuda.synchronize()
+        assert st.comm_events is not None and st.comm_events[0].elapsed_time(st.comm_events[1]) >= 0.0
+        outs[payload] = ([float(x.item()) for x in out], m.flat_p.clone())
+    (l32, p32), (l16, p16) = outs['fp32'], outs['bf16']
+    assert l16[0] == pytest.approx(l32[0], rel=2e-3) and l16[1] == pytest.approx(l32[1], rel=2e-3, abs=2e-3)
+    assert float((p16 - p32).norm() / p32.norm()) < 1e-4

@@ -87,6 +87,17 @@ int rgda_lrh(const int64_t* labels, const int64_t* regions, int64_t* out, int b,
              int class_num, int ignore_label, float percent, int max_regions, void* ws,
              size_t ws_bytes, rgda_stream_t stream);
 
+/* pseudo_selection followed by Homogenizer.forward in one pass over the soft labels -- the chain of the SSL step
+ * (tools/train_ssl_reg.py:224-228): out = LRH(pseudo_selection(soft), regions) exactly as the two calls above give it
+ * (bit-exact), without the intermediate int64 label tensor.  classmax: f32 [b][c] per-image per-class maxima of `soft`
+ * (what rgda_label_refine leaves in its workspace, or rgda_pseudo_select's ws[0 .. b*c)).  class_num == 6, hw % 4 == 0,
+ * max_regions <= 65535 (RGDA_ERR_UNSUPPORTED otherwise: use the two calls).  ws: rgda_pseudo_lrh_workspace bytes,
+ * 16-byte aligned: int32 hist[b][R][C], int32 ids[b][R], int32 flag (bit0: a region id outside [0, R)), then scratch. */
+size_t rgda_pseudo_lrh_workspace(int b, int hw, int max_regions, int class_num);
+int rgda_pseudo_lrh(const float* soft, const float* classmax, const int64_t* regions, int64_t* out, int b, int hw,
+                    int class_num, float cutoff_top, float cutoff_low, int ignore_label, float percent,
+                    int max_regions, void* ws, size_t ws_bytes, rgda_stream_t stream);
+
 /* SAM.get_local_regions, the region-map assembly only   regda/utils/local_region_homog.py:51-56.
  * masks: uint8 [K][HW] (non-zero = inside), the automatic mask generator's masks in ITS order; areas int64 [K];
  * regions int32 [HW] out: 1 + the last mask index with area >= area_threshold covering the pixel, 0 where none does

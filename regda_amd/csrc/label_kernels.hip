@@ -224,9 +224,8 @@ extern "C" int rgda_lrh(const int64_t* labels, const int64_t* regions, int64_t* 
     int* hist = (int*)ws;
     int* ids = hist + (size_t)b * R * C;
     int* flag = ids + (size_t)b * R;
-    size_t hist_bytes = (size_t)b * R * C * 4;
-    if (hipMemsetAsync(hist, 0, hist_bytes, st) != hipSuccess) return RGDA_ERR_LAUNCH;
-    if (hipMemsetAsync(flag, 0, 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    // one clear for the histogram and the flag word (the id table between them is rewritten anyway)
+    if (hipMemsetAsync(hist, 0, ((size_t)b * R * C + (size_t)b * R + 1) * 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
     int lds_regions = min(R, (48 * 1024) / (C * 4));
     // pixels per workgroup: enough workgroups to fill the chip (a 16 K chunk left half of the CUs idle and made every
     // workgroup a chain of 64 dependent load round trips), few enough that the LDS flush stays small
@@ -240,6 +239,173 @@ extern "C" int rgda_lrh(const int64_t* labels, const int64_t* regions, int64_t* 
     RGDA_CHECK_LAUNCH();
     dim3 g3(min(cdiv(hw, 256), 1024), b);
     lrh_gather_kernel<<<g3, 256, 0, st>>>(labels, regions, ids, out, hw, R, ignore_label);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// pseudo_selection + LRH in ONE pass over the soft labels (the SSL step's chain, tools/train_ssl_reg.py:224-228 ->
+// regda/gast/pseudo_generation.py:76-88 -> regda/utils/local_region_homog.py:125-152): the selected hard label is never
+// written as an int64 tensor and read back.
+//   pick_hist : per pixel the thresholded argmax (registers) -> the (region, class) histogram as in lrh_hist_kernel, plus
+//               the label as ONE byte and the region id as 16 bits for the gather (3 B per pixel instead of 16);
+//               the LAST workgroup of an image to finish (a counter per image; the histogram is read back with
+//               device-scope loads) decides that image's region -> label table: no decide launch.
+//   gather    : 3 B per pixel in, the int64 label out.
+// Four pixels per lane (16-byte loads of every soft plane, 2 x 16 bytes of region ids); lane j-th pixels of neighbouring
+// lanes are 4 pixels apart, inside one region almost always, so the wavefront run-length merge still removes most atomics.
+// --------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4l;
+#define RGDA_LBL_SC1 16     /* sc1: device-scope (coherent across the XCDs' L2s) buffer access */
+
+template <int C>
+__global__ void __launch_bounds__(256) pick_hist_kernel(const float* __restrict__ soft, const float* __restrict__ classmax,
+                                                        const int64_t* __restrict__ regions, unsigned char* __restrict__ lab8,
+                                                        unsigned short* __restrict__ reg16, int* hist, int* ids, int* flag,
+                                                        int* counters, int hw, int chunk, float top, float low,
+                                                        int ignore_label, float percent, int R, int lds_regions) {
+    extern __shared__ int lds_hist[];
+    __shared__ int s_last;
+    const int b = blockIdx.y;
+    const int lds_bins = lds_regions * C;
+    for (int i = threadIdx.x; i < lds_bins; i += 256) lds_hist[i] = 0;
+    float thr[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) thr[k] = fmaxf(__fmul_rn(classmax[b * C + k], top), low);
+    __syncthreads();
+    const float* base = soft + (size_t)b * C * hw;
+    const int64_t* reg = regions + (size_t)b * hw;
+    int* gh = hist + (size_t)b * R * C;
+    const int beg = blockIdx.x * chunk, end = min(hw, beg + chunk);      // chunk % 1024 == 0, hw % 4 == 0
+    int bad = 0;
+    for (int i0 = beg; i0 < end; i0 += 1024) {                           // wave-uniform bound: lrh_add sees full waves
+        const int i = i0 + threadIdx.x * 4;
+        const bool in = i < end;
+        float4 v[C];
+        long long r4[4] = {0, 0, 0, 0};
+        if (in) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) v[k] = *(const float4*)(base + (size_t)k * hw + i);
+            const longlong2 ra = *(const longlong2*)(reg + i), rb = *(const longlong2*)(reg + i + 2);
+            r4[0] = ra.x; r4[1] = ra.y; r4[2] = rb.x; r4[3] = rb.y;
+        }
+        unsigned lpack = 0;
+        unsigned short rs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int cnt = 0, first = 0;
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const float x = j == 0 ? v[k].x : j == 1 ? v[k].y : j == 2 ? v[k].z : v[k].w;
+                const bool pass = in && x > thr[k];
+                if (pass && cnt == 0) first = k;
+                cnt += pass ? 1 : 0;
+            }
+            const bool labelled = cnt == 1;
+            const long long r = r4[j];
+            const bool rok = (r >= 0) && (r < R);
+            if (in && !rok) bad |= 1;
+            const bool valid = in && rok && labelled;
+            lrh_add(valid ? ((int)r * C + first) : -1, valid, lds_hist, lds_bins, gh);
+            lpack |= (labelled ? (unsigned)first : 0xffu) << (8 * j);
+            rs[j] = rok ? (unsigned short)r : (unsigned short)0xffff;
+        }
+        if (in) {
+            *(unsigned*)(lab8 + (size_t)b * hw + i) = lpack;
+            *(uint2*)(reg16 + (size_t)b * hw + i) = uint2{(unsigned)rs[0] | ((unsigned)rs[1] << 16), (unsigned)rs[2] | ((unsigned)rs[3] << 16)};
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < lds_bins; i += 256) {
+        const int x = lds_hist[i];
+        if (x) atomicAdd(&gh[i], x);
+    }
+    if (bad) atomicOr(flag, bad);
+    // ---- the last workgroup of this image decides the image's table
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&counters[b], 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gh, 0, R * C * 4, 0x00020000);
+    for (int r = threadIdx.x; r < R; r += 256) {
+        int h[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) h[c] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (r * C + c) * 4, 0, RGDA_LBL_SC1);
+        int n = 0, m = h[0], arg = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            n += h[c];
+            if (h[c] > m) { m = h[c]; arg = c; }           // strict > keeps the FIRST maximum (torch.max)
+        }
+        const float ratio = __fdiv_rn((float)m, __fadd_rn((float)n, 1e-5f));     // local_region_homog.py:143, fp32, IEEE divide
+        ids[(size_t)b * R + r] = (ratio < percent) ? ignore_label : arg;
+    }
+    if (threadIdx.x == 0) counters[b] = 0;                  // (the workspace is cleared per call anyway)
+#endif
+}
+
+__global__ void __launch_bounds__(256) lrh_gather8_kernel(const unsigned char* __restrict__ lab8,
+                                                          const unsigned short* __restrict__ reg16,
+                                                          const int* __restrict__ ids, int64_t* __restrict__ out, int hw,
+                                                          int R, int ignore_label) {
+    const int b = blockIdx.y;
+    const int* id = ids + (size_t)b * R;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < hw; i += gridDim.x * 1024) {
+        const unsigned lp = *(const unsigned*)(lab8 + (size_t)b * hw + i);
+        const uint2 rp = *(const uint2*)(reg16 + (size_t)b * hw + i);
+        const unsigned rr[4] = {rp.x & 0xffffu, rp.x >> 16, rp.y & 0xffffu, rp.y >> 16};
+        long long o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned l8 = (lp >> (8 * j)) & 0xffu;
+            const long long l = (l8 == 0xffu) ? (long long)ignore_label : (long long)l8;
+            long long v = ignore_label;
+            if (rr[j] > 0 && rr[j] < (unsigned)R) v = id[rr[j]];         // region 0 = background: left alone
+            o[j] = (v == ignore_label) ? l : v;
+        }
+        *(longlong2*)(out + (size_t)b * hw + i) = longlong2{o[0], o[1]};
+        *(longlong2*)(out + (size_t)b * hw + i + 2) = longlong2{o[2], o[3]};
+    }
+}
+
+extern "C" size_t rgda_pseudo_lrh_workspace(int b, int hw, int max_regions, int class_num) {
+    // int32 hist[b][R][C], int32 ids[b][R], int32 flag, int32 counters[b] (+ pad), uint16 reg16[b][hw], uint8 lab8[b][hw]
+    size_t head = ((size_t)b * max_regions * class_num + (size_t)b * max_regions + 1 + (size_t)b) * 4;
+    head = (head + 15) & ~(size_t)15;
+    return head + (size_t)b * hw * 3 + 16;
+}
+
+extern "C" int rgda_pseudo_lrh(const float* soft, const float* classmax, const int64_t* regions, int64_t* out, int b, int hw,
+                               int class_num, float cutoff_top, float cutoff_low, int ignore_label, float percent,
+                               int max_regions, void* ws, size_t ws_bytes, rgda_stream_t stream) {
+    if (!soft || !classmax || !regions || !out || !ws || b <= 0 || hw < 0 || max_regions <= 0 || max_regions > 65535)
+        return RGDA_ERR_ARG;
+    if (class_num != 6 || (hw & 3)) return RGDA_ERR_UNSUPPORTED;       // (the two-call route serves everything else)
+    if (((uintptr_t)ws & 15) || ws_bytes < rgda_pseudo_lrh_workspace(b, hw, max_regions, class_num)) return RGDA_ERR_WORKSPACE;
+    if (hw == 0) return RGDA_OK;
+    hipStream_t st = to_stream(stream);
+    const int R = max_regions, C = class_num;
+    int* hist = (int*)ws;
+    int* ids = hist + (size_t)b * R * C;
+    int* flag = ids + (size_t)b * R;
+    int* counters = flag + 1;
+    size_t head = ((size_t)b * R * C + (size_t)b * R + 1 + (size_t)b) * 4;
+    if (hipMemsetAsync(ws, 0, head, st) != hipSuccess) return RGDA_ERR_LAUNCH;     // ONE clear: histogram, flag, counters
+    head = (head + 15) & ~(size_t)15;
+    unsigned short* reg16 = (unsigned short*)((char*)ws + head);
+    unsigned char* lab8 = (unsigned char*)(reg16 + (size_t)b * hw);
+    const int lds_regions = min(R, (48 * 1024) / (C * 4));
+    int chunk = 16384;
+    while (chunk > 2048 && (long long)cdiv(hw, chunk) * b < 512) chunk >>= 1;
+    dim3 g1(cdiv(hw, chunk), b);
+    pick_hist_kernel<6><<<g1, 256, (size_t)lds_regions * C * 4, st>>>(soft, classmax, regions, lab8, reg16, hist, ids, flag, counters,
+                                                                       hw, chunk, cutoff_top, cutoff_low, ignore_label, percent, R,
+                                                                       lds_regions);
+    RGDA_CHECK_LAUNCH();
+    dim3 g3(min(cdiv(hw, 1024), 512), b);
+    lrh_gather8_kernel<<<g3, 256, 0, st>>>(lab8, reg16, ids, out, hw, R, ignore_label);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -123,6 +123,24 @@ def lrh(labels, regions, percent, class_num, ignore_label, max_regions=4096, che
     return out
 
 
+def pseudo_lrh(soft, classmax_ws, regions, cutoff_top, cutoff_low, percent, class_num, ignore_label, max_regions=4096, ws=None):
+    """LRH(pseudo_selection(soft), regions) in one pass (rgda_pseudo_lrh): soft (b,c,h,w) f32, classmax_ws = the workspace
+    holding the per-class maxima (label_refine(return_ws=True) / pseudo_select), regions (b,h,w) int64 -> (b,h,w) int64,
+    and the workspace (flag word at byte offset (b*R*C + b*R)*4, as for lrh)."""
+    _need_cuda(soft, regions)
+    soft, regions = soft.contiguous(), regions.contiguous()
+    b, c, h, w = soft.shape
+    assert regions.shape == (b, h, w) and regions.dtype == torch.int64 and soft.dtype == torch.float32
+    out = torch.empty((b, h, w), dtype=torch.int64, device=soft.device)
+    L = lib()
+    need = L.size('rgda_pseudo_lrh_workspace', b, h * w, max_regions, class_num)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, soft.device)
+    L.call('rgda_pseudo_lrh', soft.data_ptr(), classmax_ws.data_ptr(), regions.data_ptr(), out.data_ptr(), b, h * w, class_num,
+           cutoff_top, cutoff_low, ignore_label, float(percent), max_regions, ws.data_ptr(), ws.numel(), _stream())
+    return out, ws
+
+
 def masks_to_regions(masks, areas, area_threshold=1024):
     """masks (K,H,W) uint8 / bool, areas (K,) int64 -> (H,W) int32 region map (local_region_homog.py:51-56)."""
     _need_cuda(masks, areas)

@@ -262,9 +262,17 @@ class SSLStep:
             with ops.use_stream(side):
                 loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig,
                                                    self._class_weights(self.class_balancer_s, label_s), True)
+        # pseudo_selection + LRH in ONE pass over the refined soft labels (rgda_pseudo_lrh: the selected label is never
+        # written as an int64 tensor and read back) where the chain is the default one; tests that look at the selected
+        # labels (keep_debug) and the other configurations take the two calls
+        regs = (regs_t.squeeze(1) if regs_t.dim() == 4 else regs_t) if self.sam_refine else None
+        fuse_lrh = (self.refine_label and self.sam_refine and not self.keep_debug and self.C == 6 and self.max_regions <= 65535
+                    and (soft_t.shape[-1] * soft_t.shape[-2]) % 4 == 0)
+        hard = None
         if self.refine_label:
             soft, cm = ops.label_refine(feat_t, self.prototypes, t1, t2, soft_t, self.temp, return_ws=True)
-            hard = ops.pseudo_select(soft, self.top, self.low, self.ig, classmax_ws=cm, check=False)
+            if not fuse_lrh:
+                hard = ops.pseudo_select(soft, self.top, self.low, self.ig, classmax_ws=cm, check=False)
         else:
             soft = soft_t
             hard = ops.pseudo_select(soft_t, self.top, self.low, self.ig, check=False)
@@ -278,13 +286,16 @@ class SSLStep:
             self.debug = dict(t1=t1, t2=t2, s1=s1, s2=s2, feat_t=feat_t, feat_s=feat_s, soft_in=soft_t, soft=soft,
                               hard_selected=hard)
         if self.sam_refine:
-            regs = regs_t.squeeze(1) if regs_t.dim() == 4 else regs_t
             self._lrh_flag_off = (regs.shape[0] * self.max_regions * (self.C + 1)) * 4
-            need = self._lrh_flag_off + 16
-            if self.lrh_ws is None or self.lrh_ws.numel() < need:
-                self.lrh_ws = torch.empty(need, dtype=torch.uint8, device=m.device)
-            hard = ops.lrh(hard, regs.contiguous(), self.percent, self.C, self.ig, self.max_regions, check=False,
-                           ws=self.lrh_ws)
+            if fuse_lrh:
+                hard, self.lrh_ws = ops.pseudo_lrh(soft, cm, regs, self.top, self.low, self.percent, self.C, self.ig,
+                                                   self.max_regions, ws=self.lrh_ws)
+            else:
+                need = self._lrh_flag_off + 16
+                if self.lrh_ws is None or self.lrh_ws.numel() < need:
+                    self.lrh_ws = torch.empty(need, dtype=torch.uint8, device=m.device)
+                hard = ops.lrh(hard, regs.contiguous(), self.percent, self.C, self.ig, self.max_regions, check=False,
+                               ws=self.lrh_ws)
         if side is None:
             ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
         if self.reducer.active:

@@ -355,7 +355,7 @@ MID_GRADS = ['encoder.resnet.conv1.weight', 'encoder.resnet.bn1.weight', 'encode
              'encoder.resnet.layer3.0.downsample.0.weight[:8]', 'encoder.resnet.layer3.5.conv2.weight[:4]',
              'encoder.resnet.layer3.11.bn2.weight', 'encoder.resnet.layer3.17.conv1.weight[:16]',
              'encoder.resnet.layer3.22.conv3.weight[:64]', 'encoder.resnet.layer4.0.conv2.weight[:2]',
-             'encoder.resnet.layer4.2.bn3.bias', 'layer5.ppm.3.1.weight[:8]', 'layer5.conv_last.0.weight[:1]',
+             'encoder.resnet.layer4.2.bn3.bias', 'layer5.ppm.3.1.weight[:8]', 'layer5.conv_last.0.weight[:8]',
              'layer6.conv_last.1.weight', 'layer6.conv_last.4.weight']
 MID_RES_GAMMA = 0.02        # residual-branch gain of this fixture's weights (tests/golden/derive_tolerances.py: FULL_RES_GAMMA)
 
@@ -412,7 +412,9 @@ def gold_model128():
         gk = named[name].grad
         if sl:
             gk = gk[:int(sl[1:-1])]
-        grads['grad:' + k] = gk.numpy()
+        # (single output channels are a poor statistic -- per-channel cosines under bf16 noise spread from 0.89 to 0.999 --
+        #  so slices keep several; the large head-conv slice is stored as fp16)
+        grads['grad:' + k] = gk.numpy().astype(np.float16) if gk.numel() > 100000 else gk.numpy()
     sdn = m.state_dict()
     save('model_mid.npz', xs=xs.numpy(), xt=xt.numpy(), lab_s=lab_s.numpy().astype(np.int8),
          soft_t=soft_t.numpy(), regs=regs.numpy().astype(np.int32), protos=protos.numpy(),

@@ -236,3 +236,50 @@ def test_sam_region_map_assembly_bit_exact(mods, gold):
     reg = SAM(Gen()).get_local_regions(np.zeros((33, 17, 3), np.uint8), area_thrshold=thr)
     assert reg.dtype == np.int32 and np.array_equal(reg, oreg.regions_from_masks(masks, areas, thr))
     assert int(regions_from_anns([], (8, 8)).abs().sum()) == 0
+
+
+@pytest.mark.parametrize('shape,nreg,conf', [((8, 512, 512), 250, 3.0), ((2, 512, 512), 3000, 6.0), ((3, 100, 36), 60, 4.0), ((1, 4, 4), 2, 5.0)])
+def test_fused_pseudo_selection_lrh_bit_exact(shape, nreg, conf):
+    """rgda_pseudo_lrh (pseudo_selection + Homogenizer in one pass over the soft labels, the SSL step's chain:
+    tools/train_ssl_reg.py:224-228) against the two entry points it replaces and against the oracle -- bit for bit, ties
+    and region 0 included, at the golden sizes' scale and at the full 8 x 512 x 512."""
+    from regda_amd import ops
+    rng = np.random.default_rng(7)
+    b, h, w = shape
+    g = torch.Generator().manual_seed(11)
+    blocks = torch.randn(b, 6, (h + 15) // 16, (w + 15) // 16, generator=g).repeat_interleave(16, 2).repeat_interleave(16, 3)[:, :, :h, :w]
+    soft = torch.softmax(conf * blocks + torch.randn(b, 6, h, w, generator=g), 1).contiguous()
+    regs = np.zeros(shape, np.int64)
+    for i in range(b):
+        for r in range(1, nreg + 1):
+            y0, x0 = rng.integers(0, h), rng.integers(0, w)
+            regs[i, y0:y0 + rng.integers(1, max(2, h // 4)), x0:x0 + rng.integers(1, max(2, w // 4))] = r
+    sc, rc = soft.cuda(), torch.from_numpy(regs).cuda()
+    cmax = sc.amax((2, 3)).contiguous()
+    out, ws = ops.pseudo_lrh(sc, cmax, rc, 0.8, 0.6, 0.5, 6, -1, max_regions=4096)
+    two = ops.lrh(ops.pseudo_select(sc, 0.8, 0.6, -1), rc, 0.5, 6, -1, max_regions=4096)
+    assert torch.equal(out, two)
+    hard = olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1)
+    assert np.array_equal(out.cpu().numpy(), olab.homogenize(hard, regs, 0.5, 6, -1))
+    assert 0.02 < float((out >= 0).float().mean()) < 0.98            # the case exercises both outcomes
+    off = (b * 4096 * 7) * 4
+    assert int(ws[off:off + 4].view(torch.int32).item()) == 0
+    # a second call reuses the workspace (the counters and the histogram are cleared per call)
+    out2, _ = ops.pseudo_lrh(sc, cmax, rc, 0.8, 0.6, 0.5, 6, -1, max_regions=4096, ws=ws)
+    assert torch.equal(out2, out)
+
+
+def test_fused_pseudo_selection_lrh_flags_and_limits():
+    from regda_amd import ops
+    soft = torch.softmax(4.0 * torch.randn(1, 6, 8, 8, generator=torch.Generator().manual_seed(0)), 1).cuda()
+    regs = torch.zeros(1, 8, 8, dtype=torch.int64, device='cuda')
+    regs[0, :4] = 9                                     # outside [0, max_regions = 8): left unchanged, flag bit 0
+    regs[0, 4:, :4] = 3
+    cmax = soft.amax((2, 3)).contiguous()
+    out, ws = ops.pseudo_lrh(soft, cmax, regs, 0.8, 0.6, 0.5, 6, -1, max_regions=8)
+    off = (1 * 8 * 7) * 4
+    assert int(ws[off:off + 4].view(torch.int32).item()) & 1
+    sel = ops.pseudo_select(soft, 0.8, 0.6, -1)
+    assert torch.equal(out[0, :4], sel[0, :4])
+    with pytest.raises(ValueError):                     # hw % 4 != 0: the two-call route serves it
+        ops.pseudo_lrh(soft[:, :, :3, :3].contiguous(), cmax, regs[:, :3, :3].contiguous(), 0.8, 0.6, 0.5, 6, -1)

@@ -551,7 +551,10 @@ def test_resnet101_step_vs_reference_minted_step_128(gold, capsys):
     at 2 x 3 x 128 x 128, residual gain 0.02: 8 x 8 feature maps, 128 values per channel and domain in the deep BatchNorm
     layers).  17 gradient tensors spread over the depth; per-tensor bounds 1 - 3 (1 - N_k) from the CPU rounding model
     ("resnet101_step_mid": N_k 0.949 - 0.980 in the backbone -> bounds 0.85 - 0.94; 0.985 - 0.9998 in the heads ->
-    0.955 - 0.999; the 64 x 64 fixture's single bound was 0.65)."""
+    0.955 - 0.999; the 64 x 64 fixture's single bound was 0.65).  Slices of the large tensors keep several output
+    channels: a single channel is a poor statistic (per-channel cosines of the head convolution's gradient spread from 0.89
+    to 0.999 around a median of 0.995 under bf16 noise, in the emulating oracle and in the HIP path alike:
+    scripts/dev/headgrad_diag.py)."""
     from regda_amd.ssl import SSLStep
     g = gold('model_mid.npz')
     F = 'resnet101_step_mid'
@@ -591,21 +594,8 @@ def test_resnet101_step_vs_reference_minted_step_128(gold, capsys):
     mine = olab.homogenize(olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1), g['regs'].astype(np.int64).squeeze(1), 0.5, 6, -1)
     assert np.array_equal(mine, hard)
     assert len(cos) >= 12
-    # The head's 3x3 convolution (4096 -> 512): input channels 0 .. 2047 are the instance-normalised features (an ordinary
-    # convolution here too), 2048 .. 4095 the four upsampled PPM branches, which this build never materialises -- their
-    # weight gradient is formed at s x s resolution from dZ = V^T dc, a tensor that is rounded to bf16
-    # once more than anything the rounding model (which emulates the reference's dataflow) rounds.  The derived bound is
-    # asserted on the feature half; the PPM half is held to a stated floor of 0.95.
-    kh = 'layer5.conv_last.0.weight[:1]'
-    ref = torch.from_numpy(g['grad:' + kh]).float()
-    got = _sliced(kh, m._gviews).detach().float().cpu().reshape(ref.shape)
-    c_ = lambda a, b: float(a.flatten().double() @ b.flatten().double() / (a.norm().double() * b.norm().double() + 1e-300))
-    cos_feat, cos_ppm = c_(got[:, :2048], ref[:, :2048]), c_(got[:, 2048:], ref[:, 2048:])
-    with capsys.disabled():
-        print('   head conv: feature half cos %.4f (bound %.4f), PPM half %.4f (floor 0.95)' % (cos_feat, bound[kh], cos_ppm))
-    assert cos_feat > bound[kh] and cos_ppm > 0.95
     for k in cos:
-        assert k == kh or cos[k] > bound[k], (k, cos[k], bound[k])
+        assert cos[k] > bound[k], (k, cos[k], bound[k])
     assert min(bound[k] for k in cos if k.startswith('encoder.')) > 0.84
 
 

@@ -440,6 +440,15 @@ int rgda_ddp_accumulate_bf16(const void* recv, int world, void* out, int64_t sha
  * reverse accumulation dst[R][K] f32 += src[R][Kp] f32 for the stem weight gradient. */
 int rgda_pad_cast_bf16(const float* src, void* dst, int R, int K, int Kp, rgda_stream_t stream);
 int rgda_unpad_acc_f32(const float* src, float* dst, int R, int K, int Kp, rgda_stream_t stream);
+/* The small chores of a step as kernels of this library (so that a step launches nothing from torch or the runtime's
+ * blit kernels): clear a buffer (16-byte aligned); up to four device -> device copies in one launch (16-byte aligned,
+ * sizes multiples of 16; dsts / srcs / bytes are HOST arrays); one f32 word (the learning rate the optimizer reads from
+ * device memory); Dropout2d(p) keep masks, scaled by 1 / (1 - p) (regda/models/Encoder.py:39), from a counter-based
+ * generator: element i depends on (seed, i) only. */
+int rgda_fill_zero(void* p, size_t bytes, rgda_stream_t stream);
+int rgda_copy_multi(int n, void* const* dsts, const void* const* srcs, const size_t* bytes, rgda_stream_t stream);
+int rgda_set_f32(float* p, float value, rgda_stream_t stream);
+int rgda_dropout_mask(float* out, int64_t n, float p, uint64_t seed, rgda_stream_t stream);
 /* out = a + b (bf16, PxC) */
 int rgda_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t M,
                   int C, rgda_stream_t stream);

@@ -330,6 +330,79 @@ extern "C" int rgda_unpad_acc_f32(const float* src, float* dst, int R, int K, in
     return RGDA_OK;
 }
 
+
+// ---- the small host-side chores of a step as kernels of this library (a step then launches nothing from torch or the
+// runtime's blit kernels: DESIGN.md 3): buffer clears, device -> device copies of the BatchNorm buffers / the stem's
+// image copies, the learning rate word, the Dropout2d keep masks.
+__global__ void __launch_bounds__(256) fill_zero_kernel(uint4* __restrict__ p, long long n16, unsigned char* tail, int ntail) {
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+extern "C" int rgda_fill_zero(void* p, size_t bytes, rgda_stream_t stream) {
+    if (!p || ((uintptr_t)p & 15)) return RGDA_ERR_ARG;
+    if (bytes == 0) return RGDA_OK;
+    const long long n16 = (long long)(bytes >> 4);
+    fill_zero_kernel<<<(int)min((long long)cdiv(n16 > 0 ? n16 : 1, 256 * 4), 4096ll), 256, 0, to_stream(stream)>>>(
+        (uint4*)p, n16, (unsigned char*)p + (n16 << 4), (int)(bytes & 15));
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+struct CopyJobs { const uint4* src[4]; uint4* dst[4]; long long n16[4]; int first[5]; };
+__global__ void __launch_bounds__(256) copy_multi_kernel(CopyJobs j, int njobs) {
+    int k = 0;
+    while (k + 1 < njobs && (int)blockIdx.x >= j.first[k + 1]) ++k;
+    const int nb = j.first[k + 1] - j.first[k], bid = blockIdx.x - j.first[k];
+    for (long long i = (long long)bid * 256 + threadIdx.x; i < j.n16[k]; i += (long long)nb * 256) j.dst[k][i] = j.src[k][i];
+}
+
+// up to four device -> device copies in one launch (16-byte aligned, sizes multiples of 16): dsts / srcs / bytes HOST arrays
+extern "C" int rgda_copy_multi(int n, void* const* dsts, const void* const* srcs, const size_t* bytes, rgda_stream_t stream) {
+    if (n < 1 || n > 4 || !dsts || !srcs || !bytes) return RGDA_ERR_ARG;
+    CopyJobs j;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!dsts[k] || !srcs[k] || ((uintptr_t)dsts[k] & 15) || ((uintptr_t)srcs[k] & 15) || (bytes[k] & 15)) return RGDA_ERR_ARG;
+        j.src[k] = (const uint4*)srcs[k]; j.dst[k] = (uint4*)dsts[k]; j.n16[k] = (long long)(bytes[k] >> 4);
+        j.first[k] = blocks;
+        blocks += (int)min((long long)cdiv(j.n16[k] > 0 ? j.n16[k] : 1, 256 * 4), 2048ll);
+    }
+    for (int k = n; k <= 4; ++k) j.first[k] = blocks;
+    copy_multi_kernel<<<blocks, 256, 0, to_stream(stream)>>>(j, n);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+__global__ void set_f32_kernel(float* p, float v) { *p = v; }
+extern "C" int rgda_set_f32(float* p, float value, rgda_stream_t stream) {
+    if (!p) return RGDA_ERR_ARG;
+    set_f32_kernel<<<1, 1, 0, to_stream(stream)>>>(p, value);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// Dropout2d(p) keep masks, already scaled (regda/models/Encoder.py:39): out[i] = (u_i >= p) / (1 - p), u_i uniform in [0, 1)
+// from a counter-based generator (SplitMix64 of seed and index: every element independent of the launch geometry)
+__global__ void __launch_bounds__(256) dropout_mask_kernel(float* __restrict__ out, long long n, float p, unsigned long long seed) {
+    const float keep = 1.f / (1.f - p);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const float u = (float)(z >> 40) * 0x1p-24f;
+        out[i] = (u >= p) ? keep : 0.f;
+    }
+}
+extern "C" int rgda_dropout_mask(float* out, int64_t n, float p, uint64_t seed, rgda_stream_t stream) {
+    if (!out || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return RGDA_ERR_ARG;
+    dropout_mask_kernel<<<min(cdiv(n, 256), 1024), 256, 0, to_stream(stream)>>>(out, n, p, seed);
+    RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
 __global__ void __launch_bounds__(256) add_bf16_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
                                                        int ldb, bf16_t* __restrict__ o, int ldo, long long M, int vpr) {
     long long total = M * vpr;

@@ -361,7 +361,7 @@ class Deeplabv2(nn.Module):
         self.flat_g = torch.zeros(n_param, device=dev)             # fp32 gradients
         self.flat_pb = torch.zeros(n_param, dtype=BF, device=dev)  # bf16 mirror (same offsets)
         self.flat_buf = torch.zeros(n_buf, device=dev)             # BN running statistics
-        self.flat_nbt = torch.zeros(n_nbt, dtype=torch.int64, device=dev)
+        self.flat_nbt = torch.zeros((n_nbt + 1) // 2 * 2, dtype=torch.int64, device=dev)    # (whole 16-byte vectors: rgda_copy_multi)
         self.n_param_elems = sum(math.prod(s) for _, k, s in entries if k in ('convw', 'vec'))
         self._views, self._gviews = {}, {}
         self.convs, self.bns = {}, {}
@@ -583,9 +583,11 @@ class Deeplabv2(nn.Module):
         return r
 
     def new_tape(self, groups=1):
-        return {'groups': groups, 'keep': [],
-                'stats_pool': _StatsPool(sum(groups * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64,
-                                         self.device)}
+        # ONE zeroed arena per step for every BatchNorm's forward statistics and backward sums (one clear instead of two)
+        n = sum(groups * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64
+        buf = torch.empty(2 * n, dtype=torch.int64, device=self.device)
+        ops.fill_zero(buf)
+        return {'groups': groups, 'keep': [], 'stats_pool': _StatsPool(buf[:n]), 'sums_pool_next': _StatsPool(buf[n:])}
 
     def param_boundaries(self):
         """Element offsets (into flat_p / flat_g) where a residual block / head starts: legal bucket cuts."""
@@ -612,11 +614,7 @@ class Deeplabv2(nn.Module):
 
     def adopt_buffers(self, other):
         """Copy `other`'s BatchNorm running statistics (one flat buffer each) on the current stream."""
-        def copy():
-            with torch.no_grad():
-                self.flat_buf.copy_(other.flat_buf)
-                self.flat_nbt.copy_(other.flat_nbt)
-        plan.host(copy)
+        ops.copy_multi([(self.flat_buf, other.flat_buf), (self.flat_nbt, other.flat_nbt)])
 
     def refresh_from_master(self, mirror_is_fresh=False):
         """bf16 mirror + padded stem weights only (a forward-only model needs no transposed copies).
@@ -952,6 +950,7 @@ class Deeplabv2(nn.Module):
                 for gi, xg in enumerate(x):
                     ops.stem_wgrad(xg, dc[gi * Ng * Ho * Wo:(gi + 1) * Ng * Ho * Wo], conv.g.view(64, 147), Ng, H, W, Ho, Wo)
             else:
+                ops.fill_zero(self.grad_arena)          # fp32 landing buffer of the padded [64][192] gradient
                 ops.conv2d_wgrad(x, dc, self.stem_gtmp, N, Ho, Wo, Ho, Wo, 1, 1, 1, 0, 1)
                 ops.unpad_acc_f32(self.stem_gtmp, conv.g, 64, 147, STEM_KP)
             return None, gm
@@ -1017,8 +1016,8 @@ class Deeplabv2(nn.Module):
                 # the weight gradient reads the images again at the END of backward (rgda_stem_wgrad): private copies, so
                 # the caller's buffers are free for the next batch once the forward has read them (25 MB, beside the forward)
                 col = tuple(torch.empty_like(xg) for xg in xs)
-                for xc, xg in zip(col, xs):
-                    plan.host(lambda xc=xc, xg=xg: xc.copy_(xg))
+                for i in range(0, len(xs), 4):
+                    ops.copy_multi(list(zip(col[i:i + 4], xs[i:i + 4])))
             else:
                 col = torch.empty(M, STEM_KP, dtype=BF, device=dev)
                 for gi, xg in enumerate(xs):
@@ -1135,8 +1134,8 @@ class Deeplabv2(nn.Module):
                 if self._drop_override is not None:
                     for mk, m in zip(masks, self._drop_override):
                         mk.copy_(m.to(dev).float().repeat(N // m.shape[0], 1) / 0.9)
-                else:                       # three in-place kernels for both heads (ten when drawn head by head)
-                    both.uniform_().ge_(0.1).mul_(1.0 / 0.9)
+                else:       # one kernel for both heads; the seed comes from torch's (host) generator, so torch.manual_seed governs it
+                    ops.dropout_mask(both, 0.1, int(torch.randint(0, 2 ** 62, (1,)).item()))
             plan.host(draw)
         else:
             masks = [None, None]
@@ -1198,9 +1197,8 @@ class Deeplabv2(nn.Module):
                 self._wt_ready = None
         plan.host(wait_transposed_weights)
         T['on_progress'] = on_progress
-        plan.host(self.grad_arena.zero_)
         T['wgrad_pending'], T['wgrad_pending_flop'], T['wgrad_post'] = [], 0.0, []
-        T['sums_pool'] = _StatsPool(sum(T['groups'] * NREP * 2 * _pad64(b.c) for b in self.bns.values()) + 64, dev)
+        T['sums_pool'] = T['sums_pool_next']
         C, B = self.convs, self.bns
         y4, imi, (N, h, w) = T['inorm']
         HW, M = h * w, N * h * w
@@ -1315,9 +1313,8 @@ class _StatsPool:
     """One zero-initialised arena per forward for every BatchNorm's (sum, sumsq) accumulator (rgda_stat_t: 64-bit
     fixed point, order-independent totals -- include/rgda_hip.h)."""
 
-    def __init__(self, n, device):
-        self.buf = torch.empty(n, dtype=torch.int64, device=device)
-        plan.host(self.buf.zero_)
+    def __init__(self, buf):
+        self.buf = buf              # zeroed by the caller (Deeplabv2.new_tape)
         self.off = 0
 
     def take(self, n):

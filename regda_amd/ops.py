@@ -213,8 +213,35 @@ def proto_update(feat, label, protos, scale=16, ignore_label=-1, min_ratio=0.75,
     return ds
 
 
-def upsample_ce(p1, p2, label, ignore_label=-1, class_weight=None, want_grad=True):
-    """-> (loss f32[1], g1, g2) ; g = d loss / d p (None if not want_grad)."""
+def fill_zero(t):
+    """t.zero_() as a kernel of this library (contiguous tensor, 16-byte aligned storage)."""
+    assert t.is_contiguous()
+    lib().call('rgda_fill_zero', t.data_ptr(), t.numel() * t.element_size(), _stream())
+
+
+def copy_multi(pairs):
+    """[(dst, src), ...] (<= 4 pairs of contiguous tensors of equal byte size, multiples of 16) in ONE launch."""
+    n = len(pairs)
+    for d, s_ in pairs:
+        assert d.is_contiguous() and s_.is_contiguous() and d.numel() * d.element_size() == s_.numel() * s_.element_size()
+    D = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    S = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in pairs])
+    B = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+    lib().call('rgda_copy_multi', n, ctypes.cast(D, ctypes.c_void_p), ctypes.cast(S, ctypes.c_void_p), ctypes.cast(B, ctypes.c_void_p),
+               _stream())
+
+
+def set_f32(t, value):
+    lib().call('rgda_set_f32', t.data_ptr(), float(value), _stream())
+
+
+def dropout_mask(out, p, seed):
+    """out (f32, contiguous) = Dropout keep mask scaled by 1 / (1 - p), drawn from (seed, element index)."""
+    lib().call('rgda_dropout_mask', out.data_ptr(), out.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+
+
+def upsample_ce(p1, p2, label, ignore_label=-1, class_weight=None, want_grad=True, g1=None, g2=None):
+    """-> (loss f32[1], g1, g2) ; g = d loss / d p (None if not want_grad; written into the given g1 / g2 when passed)."""
     _need_cuda(p1, p2, label)
     p1, p2 = p1.contiguous().float(), p2.contiguous().float()
     label = label.contiguous()
@@ -222,8 +249,12 @@ def upsample_ce(p1, p2, label, ignore_label=-1, class_weight=None, want_grad=Tru
     b, c, h, w = p1.shape
     H, W = label.shape[-2:]
     loss = torch.empty(1, dtype=torch.float32, device=p1.device)
-    g1 = torch.empty_like(p1) if want_grad else None
-    g2 = torch.empty_like(p2) if want_grad else None
+    if want_grad:
+        g1 = torch.empty_like(p1) if g1 is None else g1
+        g2 = torch.empty_like(p2) if g2 is None else g2
+        assert g1.is_contiguous() and g2.is_contiguous() and g1.shape == p1.shape and g2.shape == p2.shape
+    else:
+        g1 = g2 = None
     L = lib()
     ws = _ws(L.size('rgda_upsample_ce_workspace', b, c, h, w, H, W), p1.device)
     cw = None if class_weight is None else class_weight.contiguous().float()

@@ -71,7 +71,7 @@ class SSLStep:
             return self._replay(images_s, label_s, images_t, soft_t, regs_t, lr)
         if self._plan is not None:
             return self._replay_plan(images_s, label_s, images_t, soft_t, regs_t, lr)
-        self.lr_dev.fill_(float(lr))
+        ops.set_f32(self.lr_dev, lr)
         with ops.use_stream(torch.cuda.current_stream()):
             return self._step(images_s, label_s, images_t, soft_t, regs_t)
 
@@ -131,7 +131,7 @@ class SSLStep:
         assert self._graph is None and self._plan is None
         self._static = self._static_inputs(images_s, label_s, images_t, soft_t, regs_t)
         if lr is not None:          # recording IS a real step: run it with this learning rate (default: the last one)
-            self.lr_dev.fill_(float(lr))
+            ops.set_f32(self.lr_dev, lr)
         torch.cuda.synchronize()
         self._plan_stream = torch.cuda.current_stream()
         p = plan.Plan()
@@ -169,7 +169,7 @@ class SSLStep:
                 assert (dst is None) == (src is None), 'a recorded step keeps its input signature (soft labels or not)'
                 if dst is not None and src is not dst:
                     dst.copy_(src, non_blocking=True)
-            self.lr_dev.fill_(float(lr))
+            ops.set_f32(self.lr_dev, lr)
             m = self.model
             if not m.training:
                 m.train()
@@ -184,7 +184,7 @@ class SSLStep:
         for dst, src in zip(self._static, (images_s, label_s, images_t, soft_t, regs_t)):
             if dst is not None and src is not dst:
                 dst.copy_(src, non_blocking=True)
-        self.lr_dev.fill_(float(lr))
+        ops.set_f32(self.lr_dev, lr)
         self._graph.replay()
         return self._out
 
@@ -235,12 +235,14 @@ class SSLStep:
                 self._mark('teacher forward done (side)', self.wgrad_stream)
                 # the gradient buffer is cleared here, behind the teacher and next to the student's forward (nothing
                 # writes it before the main stream has joined this one), instead of ahead of the student's first kernel
-                plan.host(m.flat_g.zero_)
+                ops.fill_zero(m.flat_g)
         else:
-            plan.host(m.flat_g.zero_)
+            ops.fill_zero(m.flat_g)
         x1, x2, feat = m._forward_plan([images_s.contiguous().float(), images_t.contiguous().float()], T)
         self._mark('student forward done')
         s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
+        # d(loss) / d(logits) of both heads, source rows then target rows: the two loss kernels write their halves in place
+        g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
         feat_s, feat_t = feat[:nb], feat[nb:]
         if teacher_on_side:
             plan.wait_stream(main, self.wgrad_stream)
@@ -260,8 +262,8 @@ class SSLStep:
         if side is not None:
             plan.wait_event(side, plan.record_event(main))
             with ops.use_stream(side):
-                loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig,
-                                                   self._class_weights(self.class_balancer_s, label_s), True)
+                loss_s, _, _ = ops.upsample_ce(s1, s2, label_s, self.ig,
+                                               self._class_weights(self.class_balancer_s, label_s), True, g1[:nb], g2[:nb])
         # pseudo_selection + LRH in ONE pass over the refined soft labels (rgda_pseudo_lrh: the selected label is never
         # written as an int64 tensor and read back) where the chain is the default one; tests that look at the selected
         # labels (keep_debug) and the other configurations take the two calls
@@ -314,21 +316,16 @@ class SSLStep:
                 plan.host(lambda: setattr(self, '_proto_ready', pside.record_event() if pside is not main else None))
         # ---- losses + d(loss)/d(logits)
         if side is None:
-            loss_s, gs1, gs2 = ops.upsample_ce(s1, s2, label_s, self.ig,
-                                               self._class_weights(self.class_balancer_s, label_s), True)
-        loss_t, gt1, gt2 = ops.upsample_ce(t1, t2, hard, self.ig, self._class_weights(self.class_balancer_t, hard), True)
+            loss_s, _, _ = ops.upsample_ce(s1, s2, label_s, self.ig,
+                                           self._class_weights(self.class_balancer_s, label_s), True, g1[:nb], g2[:nb])
+        loss_t, _, _ = ops.upsample_ce(t1, t2, hard, self.ig, self._class_weights(self.class_balancer_t, hard), True,
+                                       g1[nb:], g2[nb:])
         if side is not None:
             plan.wait_event(main, source_done)       # source loss, its logit gradients, the new prototypes
         self._mark('label path + losses done')
         # from here on the step no longer reads its input tensors (images: stem im2col of student and teacher; labels,
         # soft labels and region maps: the label path and the losses): an input prefetcher may overwrite them
         self._inputs_done = plan.record_event(main)
-        g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
-
-        def gather_logit_grads():
-            torch.cat([gs1, gt1], out=g1)
-            torch.cat([gs2, gt2], out=g2)
-        plan.host(gather_logit_grads)
         self._backward_and_update(T, main, g1, g2)
         self.last_hard = hard
         return loss_s, loss_t, self.gn

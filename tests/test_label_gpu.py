@@ -261,7 +261,8 @@ def test_fused_pseudo_selection_lrh_bit_exact(shape, nreg, conf):
     assert torch.equal(out, two)
     hard = olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1)
     assert np.array_equal(out.cpu().numpy(), olab.homogenize(hard, regs, 0.5, 6, -1))
-    assert 0.02 < float((out >= 0).float().mean()) < 0.98            # the case exercises both outcomes
+    if h * w >= 1024:
+        assert 0.02 < float((out >= 0).float().mean()) < 0.98        # the case exercises both outcomes
     off = (b * 4096 * 7) * 4
     assert int(ws[off:off + 4].view(torch.int32).item()) == 0
     # a second call reuses the workspace (the counters and the histogram are cleared per call)

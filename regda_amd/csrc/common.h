@@ -181,4 +181,10 @@ static __device__ __forceinline__ void bn_operand_table(const BnOperand& b, int 
 #define TUNE_ENV(name) ((const char*)nullptr)
 #endif
 static inline hipStream_t to_stream(rgda_stream_t s) { return (hipStream_t)s; }
+// clear a workspace region from inside an entry point: the library's own fill kernel (rgda_fill_zero) where the pointer is
+// 16-byte aligned -- hipMemsetAsync runs as one or two of the runtime's blit kernels per call
+static inline int zero_bytes(void* p, size_t bytes, rgda_stream_t stream) {
+    if (!((uintptr_t)p & 15)) return rgda_fill_zero(p, bytes, stream);
+    return hipMemsetAsync(p, 0, bytes, (hipStream_t)stream) == hipSuccess ? RGDA_OK : RGDA_ERR_LAUNCH;
+}
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

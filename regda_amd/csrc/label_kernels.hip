@@ -82,7 +82,7 @@ extern "C" int rgda_pseudo_select(const float* soft, int64_t* out, int b, int c,
     float* classmax = (float*)ws;
     int* flag = (int*)(classmax + (size_t)b * c);
     if (!classmax_ready) {
-        if (hipMemsetAsync(ws, 0, (size_t)b * c * 4 + 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+        if (zero_bytes(ws, (size_t)b * c * 4 + 4, stream) != RGDA_OK) return RGDA_ERR_LAUNCH;
         int chunk = 16384;
         dim3 grid(cdiv(hw, chunk), b * c);
         pseudo_max_kernel<<<grid, 256, 0, st>>>(soft, classmax, flag, hw, chunk);
@@ -123,6 +123,28 @@ static __device__ __forceinline__ void lrh_add(int key, bool valid, int* lds_his
             atomicAdd(&lds_hist[key], len);
         else
             atomicAdd(&ghist[key], len);
+    }
+}
+
+// the same merge with `w` pixels per lane (all of one key): a run of lanes adds the sum of its lanes' weights
+static __device__ __forceinline__ void lrh_add_w(int key, int w, bool valid, int* lds_hist, int lds_bins, int* ghist) {
+    const int lane = threadIdx.x & 63;
+    int prev = __shfl_up(key, 1, 64);
+    bool pvalid = __shfl_up((int)valid, 1, 64);
+    bool head = valid && (lane == 0 || !pvalid || prev != key);
+    unsigned long long heads = __ballot(head);
+    unsigned long long valids = __ballot(valid);
+    unsigned long long w4 = __ballot(valid && w == 4);         // every valid lane carries 4 pixels or fewer: count the 4s
+    if (head) {
+        unsigned long long stop = (heads | ~valids) >> lane >> 1;
+        int len = stop ? (__builtin_ctzll(stop) + 1) : (64 - lane);
+        const unsigned long long run = (len == 64 ? ~0ull : ((1ull << len) - 1)) << lane;
+        // lanes of the run with weight 4 add 4, the others (weight 1 .. 3) are handled by the caller's slow path
+        int total = 4 * __builtin_popcountll(run & w4);
+        if (key < lds_bins)
+            atomicAdd(&lds_hist[key], total);
+        else
+            atomicAdd(&ghist[key], total);
     }
 }
 
@@ -225,7 +247,7 @@ extern "C" int rgda_lrh(const int64_t* labels, const int64_t* regions, int64_t* 
     int* ids = hist + (size_t)b * R * C;
     int* flag = ids + (size_t)b * R;
     // one clear for the histogram and the flag word (the id table between them is rewritten anyway)
-    if (hipMemsetAsync(hist, 0, ((size_t)b * R * C + (size_t)b * R + 1) * 4, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    if (zero_bytes(hist, ((size_t)b * R * C + (size_t)b * R + 1) * 4, stream) != RGDA_OK) return RGDA_ERR_LAUNCH;
     int lds_regions = min(R, (48 * 1024) / (C * 4));
     // pixels per workgroup: enough workgroups to fill the chip (a 16 K chunk left half of the CUs idle and made every
     // workgroup a chain of 64 dependent load round trips), few enough that the LDS flush stays small
@@ -291,6 +313,7 @@ __global__ void __launch_bounds__(256) pick_hist_kernel(const float* __restrict_
         }
         unsigned lpack = 0;
         unsigned short rs[4];
+        int key[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int cnt = 0, first = 0;
@@ -305,10 +328,19 @@ __global__ void __launch_bounds__(256) pick_hist_kernel(const float* __restrict_
             const long long r = r4[j];
             const bool rok = (r >= 0) && (r < R);
             if (in && !rok) bad |= 1;
-            const bool valid = in && rok && labelled;
-            lrh_add(valid ? ((int)r * C + first) : -1, valid, lds_hist, lds_bins, gh);
+            key[j] = (in && rok && labelled) ? ((int)r * C + first) : -1;
             lpack |= (labelled ? (unsigned)first : 0xffu) << (8 * j);
             rs[j] = rok ? (unsigned short)r : (unsigned short)0xffff;
+        }
+        // Labels and regions are piecewise constant: in most waves every lane's four pixels share one key (or none is
+        // counted at all).  Those waves make ONE merged add per lane instead of four (the kernel is bound by these
+        // shuffles / ballots / LDS atomics, not by its 35 B per pixel); any other wave takes the pixel-by-pixel path.
+        const bool same = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
+        if (__all(same)) {
+            if (__any(key[0] >= 0)) lrh_add_w(key[0], 4, key[0] >= 0, lds_hist, lds_bins, gh);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lrh_add(key[j], key[j] >= 0, lds_hist, lds_bins, gh);
         }
         if (in) {
             *(unsigned*)(lab8 + (size_t)b * hw + i) = lpack;
@@ -403,7 +435,7 @@ extern "C" int rgda_pseudo_lrh(const float* soft, const float* classmax, const i
     int* flag = ids + (size_t)b * R;
     int* counters = flag + 1;
     size_t head = ((size_t)b * R * C + (size_t)b * R + 1 + (size_t)b) * 4;
-    if (hipMemsetAsync(ws, 0, head, st) != hipSuccess) return RGDA_ERR_LAUNCH;     // ONE clear: histogram, flag, counters
+    if (zero_bytes(ws, head, stream) != RGDA_OK) return RGDA_ERR_LAUNCH;            // ONE clear: histogram, flag, counters
     head = (head + 15) & ~(size_t)15;
     unsigned short* reg16 = (unsigned short*)((char*)ws + head);
     unsigned char* lab8 = (unsigned char*)(reg16 + (size_t)b * hw);
@@ -677,7 +709,7 @@ extern "C" int rgda_label_refine_views(const float* feat, const float* protos, c
     float* pstd = (float*)(base + off);
     off += align256((size_t)c * 4);
     float* pc = (float*)(base + off);
-    if (hipMemsetAsync(classmax, 0, (size_t)b * c * 4 + 16, st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    if (zero_bytes(classmax, (size_t)b * c * 4 + 16, stream) != RGDA_OK) return RGDA_ERR_LAUNCH;
     const int hw = h * w;
     if (pview) {
     proto_center_kernel<<<c, 256, 0, st>>>(protos, pc, pstd, k);
@@ -904,7 +936,7 @@ extern "C" int rgda_proto_update(const float* feat, const int64_t* label, float*
     float* sums = (float*)ws;
     float* cnt = sums + (size_t)c * k;
     int* flag = (int*)(cnt + c);
-    if (hipMemsetAsync(ws, 0, rgda_proto_update_workspace(c, k), st) != hipSuccess) return RGDA_ERR_LAUNCH;
+    if (zero_bytes(ws, rgda_proto_update_workspace(c, k), stream) != RGDA_OK) return RGDA_ERR_LAUNCH;
     if (scale == 16 && c <= 6 && !(w & 1))
         downscale_label16_kernel<<<dim3(cdiv(w * 8, 256), b * h), 256, 0, st>>>(label, label_ds, cnt, flag, h, w, c, ignore_label, min_ratio);
     else

@@ -94,8 +94,20 @@ def test_gener_target_pseudo_writes_the_soft_label_files(tmp_path, gold):
         assert t.device.type == 'cpu' and t.dtype == torch.float32 and tuple(t.shape) == (5, 64, 48)
         ref = teacher.soft_label(teacher.pre_slide(cpu_model, im, num_classes=5, tile_size=(512, 512), tta=True), (64, 48))
         np.testing.assert_allclose(t.numpy(), ref.numpy(), rtol=0, atol=3e-6)
-    with pytest.raises(NotImplementedError):
-        gener_target_pseudo(Cfg, model, loader, out, save_prob=False)
+    # save_prob=False (pseudo_generation.py:143-150): the selected hard labels + 1 as a uint8 image named <fname>
+    from PIL import Image
+    from oracle import labels as olab
+    hard_dir = str(tmp_path / 'pseudo_hard')
+    for select in (True, False):
+        Cfg.PSEUDO_SELECT = select
+        gener_target_pseudo(Cfg, model, loader, hard_dir, slide=True, save_prob=False, size=(40, 24), ignore_label=-1)   # (no resize on this branch: size = the tile's)
+        for i, im in enumerate(imgs):
+            arr = np.array(Image.open(os.path.join(hard_dir, f'tile_{i}.tif')))
+            assert arr.dtype == np.uint8 and arr.shape == (40, 24)
+            probs = teacher.pre_slide(cpu_model, im, num_classes=5, tile_size=(512, 512), tta=True)
+            want = olab.pseudo_selection(probs.numpy(), 0.8, 0.6, -1) if select else probs.argmax(1).numpy()
+            # (probabilities within 3e-6 of the oracle's: a pixel sitting exactly on a threshold / an exact tie may flip)
+            assert (arr != (want + 1).reshape(40, 24)).mean() < 2e-3
 
 
 def test_batched_tta_equals_view_by_view_on_the_real_network():

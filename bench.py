@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--eager', action='store_true', help='one Python -> ctypes call per launch instead of the recorded launch plan (regda_amd/plan.py, the default)')
     ap.add_argument('--no-h2d', action='store_true', help='reuse one device-resident batch instead of staging a fresh pinned host batch per step over a copy stream')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (measured slower than the recorded plan on ROCm 7.2: 22.4 vs 21.0 ms/step)')
+    ap.add_argument('--bn-operand', default=None, help="tuning: which BatchNorm units run on their consumer's operand path, e.g. 'stem+bn1+bn2' (model default), 'none'; ':1' appended = wherever served, not only where it pays")
     ap.add_argument('--relu-mask', type=int, default=None, help='tuning: keep ReLU sign bits for units with at least this many channels (model default: all units)')
     ap.add_argument('--wgrad-group-gflop', type=float, default=None, help='tuning: weight gradients are queued and launched in groups of at least this much work (model default: 500)')
     ap.add_argument('--cpu-batch', type=int, default=2)
@@ -367,6 +368,11 @@ def main():
     with torch.no_grad():
         for head in ('layer5', 'layer6'):
             model.convs[f'{head}.conv_last.4'].w.mul_(40.0)
+    if args.bn_operand is not None:
+        units, _, level = args.bn_operand.partition(':')
+        model.bn_operand_units = set(units.split('+')) - {'none'}
+        if level:
+            model.bn_operand_level = int(level)
     if args.relu_mask is not None:
         model.relu_sign_mask = args.relu_mask
     if args.wgrad_group_gflop is not None:

@@ -861,8 +861,10 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
             if constexpr (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the previous step's in-place transform
             __builtin_amdgcn_s_barrier();
             pend = 0;
+            if (!(TSKIP(a) & 1)) {      // (tuning builds: 1 = no DMA inside the loop, 8 = fragments read once, 2 = no reads / MFMAs)
             if (q + 2 < KT) { issue_w(q + 2, wstage >= 1 ? wstage - 1 : 2); pend += 2; }
             if (more && tp < PXW) { issue_h(sl + 1, tp); pend += 1; }
+            }
             if constexpr (XF) {
                 if (more && !(TSKIP(a) & 512)) {
                     if (tp == 1) xf_load(sl + 1);
@@ -870,8 +872,10 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
                 }
             }
             const unsigned char* wb = swb + wstage * WS;
+            if (!(TSKIP(a) & 8) || q == 0) {
             read_half(wb, xb, tp, 0, fa0, fb0);
             read_half(wb, xb, tp, 1, fa1, fb1);
+            }
             mfma_half(fa0, fb0);
             mfma_half(fa1, fb1);
             wstage = (wstage == 2) ? 0 : wstage + 1;

@@ -311,8 +311,8 @@ class Deeplabv2(nn.Module):
         # convolution / the max-pool) wherever a kernel carries the transform: the activation is never written in the
         # forward pass (ops.conv2d_bnin).  False = one rgda_bn_train_apply pass per unit (the cross-check)
         self.bn_on_operand = True
-        self.bn_operand_units = set(os.environ.get('RGDA_BN_OPERAND', 'stem+bn1+bn2').split('+'))   # (A/B experiments)
-        self.bn_operand_level = int(os.environ.get('RGDA_BN_OPERAND_LEVEL', '2'))    # 2: only where it pays; 1: wherever served
+        self.bn_operand_units = {'stem', 'bn1', 'bn2'}   # which units may be deferred (A/B experiments: bench.py --bn-operand)
+        self.bn_operand_level = 2      # 2: only where rgda_conv2d_bnin_supported() says the transform pays; 1: wherever it is served
         self._head_stream = None
         self._mat_cache = {}
         self._synced_version = -1

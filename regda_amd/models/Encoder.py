@@ -1134,6 +1134,10 @@ class Deeplabv2(nn.Module):
                 if self._drop_override is not None:
                     for mk, m in zip(masks, self._drop_override):
                         mk.copy_(m.to(dev).float().repeat(N // m.shape[0], 1) / 0.9)
+                elif torch.cuda.is_current_stream_capturing():
+                    # inside a hipGraph capture a kernel argument is frozen: torch's graph-safe generator (its Philox offset
+                    # advances at every replay) draws the masks there
+                    both.uniform_().ge_(0.1).mul_(1.0 / 0.9)
                 else:       # one kernel for both heads; the seed comes from torch's (host) generator, so torch.manual_seed governs it
                     ops.dropout_mask(both, 0.1, int(torch.randint(0, 2 ** 62, (1,)).item()))
             plan.host(draw)

@@ -641,3 +641,34 @@ def test_twenty_step_loss_curve_tracks_the_oracle(capsys):
     assert got[-1][0] < 0.2 * got[0][0] and got[-1][1] < 0.7 * got[0][1]
     # the oracle here reproduces the committed fp32 curve (another thread count re-associates its sums)
     assert np.allclose([r[0] for r in ref], T['ref_loss_source'], rtol=0.05, atol=0.02)
+
+
+def test_operand_path_batchnorm_against_the_apply_pass_route():
+    """Deeplabv2.bn_on_operand (bn1 / bn2 + ReLU of every bottleneck and the stem's bn1 applied on the consumer's operand
+    path) against the same step with one rgda_bn_train_apply pass per unit: the two routes round at the same
+    places (the activation is bf16 either way) and differ by the apply formula's last fp32 bit, so losses, gradient norm and
+    BatchNorm buffers agree far inside the bf16 noise of the fixture, and the deferred route runs fewer apply launches."""
+    from regda_amd.ssl import SSLStep
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet50'
+    sd = omodel.init_state_dict(rt, 6, seed=14)
+    b = make_batch(b=8, size=256, seed=41)        # 16 images of 256 x 256: 16 x 16 feature maps, every kernel family engaged
+    ones = torch.ones(16, 512)
+    res = {}
+    for mode in ('apply', 'operand'):
+        m = build(rt)
+        m.load_state_dict(sd, strict=True)
+        m.set_drop_masks(ones, ones)
+        m.bn_on_operand = mode == 'operand'
+        m.bn_operand_level = 1                      # wherever a kernel serves it, not only where it pays
+        st = SSLStep(m, torch.randn(6, 2048, generator=torch.Generator().manual_seed(6)))
+        ls, lt, gn = st.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], 1e-3)
+        torch.cuda.synchronize()
+        res[mode] = (ls.item(), lt.item(), gn.sqrt().item(), m.flat_buf.clone(), m.flat_g.clone(), st.last_hard.clone())
+    a, o = res['apply'], res['operand']
+    assert o[0] == pytest.approx(a[0], rel=2e-3) and o[1] == pytest.approx(a[1], rel=2e-3, abs=2e-3)
+    assert o[2] == pytest.approx(a[2], rel=1e-2)
+    torch.testing.assert_close(o[3], a[3], rtol=1e-3, atol=1e-4)               # running statistics
+    cos = float((o[4].double() @ a[4].double()) / (o[4].double().norm() * a[4].double().norm()))
+    assert cos > 0.99, cos
+    assert float((o[5] != a[5]).float().mean()) < 5e-3

@@ -100,11 +100,13 @@ def test_gener_target_pseudo_writes_the_soft_label_files(tmp_path, gold):
     hard_dir = str(tmp_path / 'pseudo_hard')
     for select in (True, False):
         Cfg.PSEUDO_SELECT = select
-        gener_target_pseudo(Cfg, model, loader, hard_dir, slide=True, save_prob=False, size=(40, 24), ignore_label=-1)   # (no resize on this branch: size = the tile's)
+        # slide=False: the 40 x 24 fixture is smaller than pre_slide's 512 x 512 tile, for which the reference's window
+        # arithmetic yields no window at all (NaN probabilities, reproduced by the soft-label leg above)
+        gener_target_pseudo(Cfg, model, loader, hard_dir, slide=False, save_prob=False, size=(40, 24), ignore_label=-1)   # (no resize on this branch: size = the tile's)
         for i, im in enumerate(imgs):
             arr = np.array(Image.open(os.path.join(hard_dir, f'tile_{i}.tif')))
             assert arr.dtype == np.uint8 and arr.shape == (40, 24)
-            probs = teacher.pre_slide(cpu_model, im, num_classes=5, tile_size=(512, 512), tta=True)
+            probs = cpu_model(im)
             want = olab.pseudo_selection(probs.numpy(), 0.8, 0.6, -1) if select else probs.argmax(1).numpy()
             # (probabilities within 3e-6 of the oracle's: a pixel sitting exactly on a threshold / an exact tie may flip)
             assert (arr != (want + 1).reshape(40, 24)).mean() < 2e-3

@@ -1063,7 +1063,13 @@ def test_conv_with_batchnorm_relu_on_the_operand_path(ops, case):
     # the data-gradient convolution with the fused BatchNorm-backward sums of this unit (relu == 2: sign from c)
     dyn = rbf(torch.randn(N, Cout, Ho, Wo, generator=gen) * 0.1)
     ar = a_ref.clone().requires_grad_(True)
-    F.conv2d(ar, w, None, s, p, d).backward(dyn)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(ar, wr, None, s, p, d).backward(dyn)
+    # the consumer's WEIGHT gradient from the activation the backward apply wrote (its operand in the model: Encoder._cbr_bwd)
+    dw = torch.zeros(Cout, k * k, Cin, device='cuda')
+    ops.conv2d_wgrad(act, to_pxc(dyn), dw, N, H, W, Ho, Wo, k, k, s, p, d)
+    assert relerr(dw.cpu(), wr.grad.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin)) < 1e-2, 'wgrad from the side output'
+    w = w.detach()
     wt = w.permute(1, 2, 3, 0).reshape(Cin, k * k, Cout).to(BF).cuda().contiguous()
     da = torch.zeros(N * H * W, Cin, dtype=BF, device='cuda')
     fsums = ops.new_stats(G, 8, 2, Cin)

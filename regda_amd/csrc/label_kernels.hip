@@ -107,12 +107,19 @@ extern "C" int rgda_pseudo_select(const float* soft, int64_t* out, int b, int c,
 //   pass 2: per region: n, m, first argmax, fp32 ratio test -> id table.
 //   pass 3: gather.
 // --------------------------------------------------------------------------------------
+// key of the previous lane (-1 for lane 0): a DPP wavefront shift, one VALU instruction -- `__shfl_up` is a ds_bpermute
+// through the LDS crossbar, and the histogram kernels are bound by exactly these merges.  Callers pass key = -1 for lanes
+// that do not count, so "previous lane valid and equal" is one comparison.
+static __device__ __forceinline__ int prev_lane_key(int key) {
+    return __builtin_amdgcn_update_dpp(-1, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
 static __device__ __forceinline__ void lrh_add(int key, bool valid, int* lds_hist, int lds_bins, int* ghist) {
     // merge runs of equal keys across the 64 lanes: only run heads issue an atomic
     const int lane = threadIdx.x & 63;
-    int prev = __shfl_up(key, 1, 64);
-    bool pvalid = __shfl_up((int)valid, 1, 64);
-    bool head = valid && (lane == 0 || !pvalid || prev != key);
+    if (!valid) key = -1;
+    const int prev = prev_lane_key(key);
+    bool head = valid && prev != key;
     unsigned long long heads = __ballot(head);
     unsigned long long valids = __ballot(valid);
     if (head) {
@@ -129,9 +136,9 @@ static __device__ __forceinline__ void lrh_add(int key, bool valid, int* lds_his
 // the same merge with `w` pixels per lane (all of one key): a run of lanes adds the sum of its lanes' weights
 static __device__ __forceinline__ void lrh_add_w(int key, int w, bool valid, int* lds_hist, int lds_bins, int* ghist) {
     const int lane = threadIdx.x & 63;
-    int prev = __shfl_up(key, 1, 64);
-    bool pvalid = __shfl_up((int)valid, 1, 64);
-    bool head = valid && (lane == 0 || !pvalid || prev != key);
+    if (!valid) key = -1;
+    const int prev = prev_lane_key(key);
+    bool head = valid && prev != key;
     unsigned long long heads = __ballot(head);
     unsigned long long valids = __ballot(valid);
     unsigned long long w4 = __ballot(valid && w == 4);         // every valid lane carries 4 pixels or fewer: count the 4s
@@ -300,17 +307,31 @@ __global__ void __launch_bounds__(256) pick_hist_kernel(const float* __restrict_
     int* gh = hist + (size_t)b * R * C;
     const int beg = blockIdx.x * chunk, end = min(hw, beg + chunk);      // chunk % 1024 == 0, hw % 4 == 0
     int bad = 0;
-    for (int i0 = beg; i0 < end; i0 += 1024) {                           // wave-uniform bound: lrh_add sees full waves
+    constexpr int LB = 2;                       // 1024-pixel slabs whose loads are issued together (the kernel is latency-bound:
+                                                // 512 workgroups of four slabs each)
+    for (int i00 = beg; i00 < end; i00 += 1024 * LB) {                    // wave-uniform bounds: lrh_add sees full waves
+        float4 vv[LB][C];
+        long long rr[LB][4];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int i = i00 + u * 1024 + threadIdx.x * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rr[u][j] = 0;
+            if (i < end) {
+#pragma unroll
+                for (int k = 0; k < C; ++k) vv[u][k] = *(const float4*)(base + (size_t)k * hw + i);
+                const longlong2 ra = *(const longlong2*)(reg + i), rb = *(const longlong2*)(reg + i + 2);
+                rr[u][0] = ra.x; rr[u][1] = ra.y; rr[u][2] = rb.x; rr[u][3] = rb.y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+        const int i0 = i00 + u * 1024;
+        if (i0 >= end) break;                                             // wave-uniform
         const int i = i0 + threadIdx.x * 4;
         const bool in = i < end;
-        float4 v[C];
-        long long r4[4] = {0, 0, 0, 0};
-        if (in) {
-#pragma unroll
-            for (int k = 0; k < C; ++k) v[k] = *(const float4*)(base + (size_t)k * hw + i);
-            const longlong2 ra = *(const longlong2*)(reg + i), rb = *(const longlong2*)(reg + i + 2);
-            r4[0] = ra.x; r4[1] = ra.y; r4[2] = rb.x; r4[3] = rb.y;
-        }
+        const float4 (&v)[C] = vv[u];
+        const long long (&r4)[4] = rr[u];
         unsigned lpack = 0;
         unsigned short rs[4];
         int key[4];
@@ -345,6 +366,7 @@ __global__ void __launch_bounds__(256) pick_hist_kernel(const float* __restrict_
         if (in) {
             *(unsigned*)(lab8 + (size_t)b * hw + i) = lpack;
             *(uint2*)(reg16 + (size_t)b * hw + i) = uint2{(unsigned)rs[0] | ((unsigned)rs[1] << 16), (unsigned)rs[2] | ((unsigned)rs[3] << 16)};
+        }
         }
     }
     __syncthreads();

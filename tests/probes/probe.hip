@@ -191,3 +191,37 @@ extern "C" int probe_run_grid_barrier(void* counter, void* out, int blocks, int 
     probe_grid_barrier<<<blocks, 256, 0, (hipStream_t)stream>>>((unsigned*)counter, (unsigned long long*)out, rounds);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// The same barrier, hierarchical: workgroup b arrives at the counter of ITS XCD (b % 8: workgroups are dispatched round-robin
+// over the XCDs), the last arriver of an XCD arrives at the global counter, the last of those publishes the round number in
+// eight flag words (one 128-byte line per XCD) and every workgroup spins on its XCD's flag only -- 32 pollers per line
+// instead of 256 on one, 8 + 8 serialised read-modify-writes instead of 256.
+// state: unsigned [8 XCD counters x 32 words apart][global counter][8 flags x 32 words apart]
+__global__ void __launch_bounds__(256) probe_grid_barrier_hier(unsigned* state, unsigned long long* out, int rounds) {
+    const unsigned n = gridDim.x, xcd = blockIdx.x & 7;
+    const unsigned n_xcd = n / 8 + ((blockIdx.x & 7) < (n & 7) ? 1u : 0u);      // workgroups of this XCD
+    unsigned* cnt_x = state + xcd * 32;
+    unsigned* cnt_g = state + 8 * 32;
+    unsigned* flags = state + 9 * 32;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < rounds; ++r) {
+        if (threadIdx.x == 0) {
+            const unsigned round = (unsigned)(r + 1);
+            if (__hip_atomic_fetch_add(cnt_x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == round * n_xcd - 1) {
+                const unsigned groups = n < 8 ? n : 8;
+                if (__hip_atomic_fetch_add(cnt_g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == round * groups - 1) {
+                    for (unsigned x = 0; x < groups; ++x)
+                        __hip_atomic_store(flags + x * 32, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            while (__hip_atomic_load(flags + xcd * 32, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_readcyclecounter() - t0;
+}
+
+extern "C" int probe_run_grid_barrier_hier(void* state, void* out, int blocks, int rounds, void* stream) {
+    probe_grid_barrier_hier<<<blocks, 256, 0, (hipStream_t)stream>>>((unsigned*)state, (unsigned long long*)out, rounds);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

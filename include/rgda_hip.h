@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 6
+#define RGDA_ABI_VERSION 7
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore rgda_stat_t[RGDA_STAT_REPLICAS][2][C], zeroed by the caller.
@@ -125,6 +125,23 @@ int rgda_label_refine_views(const float* feat, const float* protos, const float*
                             const float* soft, float* out, int b, int k, int c, int h, int w, int H,
                             int W, float temp, int views, void* ws, size_t ws_bytes,
                             rgda_stream_t stream);
+
+/* label_refine WITH the superpixel view (label_t_sup given, alignment.py:238-258): label_t_sup (b, H*W) int64 superpixel
+ * ids in [0, max_regions).  Per (image, superpixel, class) the maximum of `soft` over the superpixel's pixels (the
+ * reference's torch_scatter.scatter(reduce='max')), gathered back per pixel, softmax_T(., temp) over the classes divided by
+ * its per-pixel maximum + 1e-7 = sup_weight; the pixels of the superpixel with the LARGEST id of the whole batch are
+ * `ignored` and keep the weight of the other views.  views: 3 = mode 'all' (weight * sup_weight), 0 = mode 's' (sup_weight
+ * alone; feat / protos / p1 / p2 may be NULL and h, w are not used -- pass 1); 1 / 2 are served too (the reference's modes
+ * 'p' / 'l' do not look at label_t_sup).  Workspace: rgda_label_refine's, then the maxima table, then two int32 at
+ * rgda_label_refine_sup_flag_offset: [0] the largest id met, [1] non-zero when an id lay outside [0, max_regions) (such
+ * pixels are treated as `ignored`; the reference would fault in scatter).  The per-class maxima of `out` are left at
+ * rgda_label_refine_classmax_offset as by rgda_label_refine. */
+size_t rgda_label_refine_sup_workspace(int b, int c, int h, int w, int max_regions);
+size_t rgda_label_refine_sup_flag_offset(int b, int c, int h, int w, int max_regions);
+int rgda_label_refine_sup(const float* feat, const float* protos, const float* p1, const float* p2,
+                          const float* soft, const int64_t* label_t_sup, float* out, int b, int k, int c,
+                          int h, int w, int H, int W, float temp, int views, int max_regions, void* ws,
+                          size_t ws_bytes, rgda_stream_t stream);
 
 /* Aligner.update_prototype(feat, label)  regda/gast/alignment.py:86-90,300-327,456-481.
  * feat NCHW f32 (b,k,h,w); label (b,H,W) int64 with H = 16h, W = 16w;

@@ -37,8 +37,24 @@ def softmax_T(x, temp=1.0, dim=1):
     return torch.softmax(x / temp, dim=dim)       # alignment.py:283-286
 
 
-def label_refine(feat_t, prototypes, preds_t, label_t_soft, refine=True, mode='all', temp=2.0):
-    """alignment.py:194-265 with label_t_sup=None (train_ssl_reg.py:214)."""
+def superpixel_weight(label_t_sup, label_t_soft, temp):
+    """alignment.py:238-253 -> (sup_weight (b,c,H,W), ignored (b,1,H,W) bool).  The reference's
+    torch_scatter.scatter(src, index, dim=1, reduce='max') (third party, requirement.txt: torch-scatter, not vendored) is the
+    per-(image, superpixel, class) maximum over the pixels carrying that id; entries no pixel indexes are never gathered."""
+    b, c, H, W = label_t_soft.shape
+    ids = label_t_sup.reshape(b, -1).long()                                # (b, HW)
+    sup_cnt = int(ids.max())                                               # :241, over the whole batch
+    src = label_t_soft.permute(0, 2, 3, 1).reshape(b, -1, c)               # (b, HW, c)
+    table = torch.full((b, sup_cnt + 1, c), float('-inf'))
+    table.scatter_reduce_(1, ids.unsqueeze(-1).expand(-1, -1, c), src, reduce='amax')          # :245
+    prob = torch.gather(table, 1, ids.unsqueeze(-1).expand(-1, -1, c))     # :248
+    prob = prob.reshape(b, H, W, c).permute(0, 3, 1, 2)
+    prob = softmax_T(prob, temp, 1)                                        # :252
+    return prob / (prob.max(dim=1, keepdim=True)[0] + 1e-7), (ids == sup_cnt).reshape(b, 1, H, W)      # :253, :242
+
+
+def label_refine(feat_t, prototypes, preds_t, label_t_soft, refine=True, mode='all', temp=2.0, label_t_sup=None):
+    """alignment.py:194-265; label_t_sup=None is what train_ssl_reg.py:214 passes."""
     if not refine:
         return label_t_soft
     b, k, h, w = feat_t.shape
@@ -61,6 +77,12 @@ def label_refine(feat_t, prototypes, preds_t, label_t_soft, refine=True, mode='a
             lw = softmax_T(F.interpolate(preds_t, (H, W), mode='bilinear', align_corners=True), temp, 1)   # :233-234
         lw = lw / (lw.max(dim=1, keepdim=True)[0] + 1e-7)                # :235
         weight = weight + lw
+    if label_t_sup is not None and mode in ('all', 's'):                 # superpixel view, :238-258
+        sw, ignored = superpixel_weight(label_t_sup, label_t_soft, temp)
+        if mode == 'all':
+            weight = torch.where(ignored, weight, weight * sw)
+        else:
+            weight = torch.where(ignored, torch.ones_like(sw), sw)
     if isinstance(weight, int):
         return label_t_soft                                              # modes 's' / 'n' without superpixels, :260-261
     soft = weight * label_t_soft                                         # :263

@@ -588,12 +588,67 @@ __global__ void __launch_bounds__(PX * SL) pearson_sim_kernel(const float* __res
     }
 }
 
-constexpr int REFINE_ROWS = 8;
+// ---- superpixel view (alignment.py:238-258): per (image, superpixel, class) the MAXIMUM of the soft labels over the
+// superpixel's pixels (torch_scatter.scatter(reduce='max')), gathered back per pixel, softmax_T(., temp) over the classes,
+// divided by its per-pixel maximum + 1e-7; pixels of the superpixel with the largest id OF THE BATCH are `ignored`.
+// The maxima are kept as order-preserving unsigned keys so that one integer atomicMax serves any sign.
+__device__ __forceinline__ unsigned fkey(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+struct SupView {
+    const long long* sup;      // (b, H*W) superpixel ids
+    unsigned* tbl;             // (b, max_regions, C) keys of the maxima
+    int* cnt;                  // [0] the largest id of the batch, [1] flag: an id outside [0, max_regions)
+    int max_regions;
+};
+
 template <int C>
+__global__ void __launch_bounds__(256) sup_max_kernel(const float* __restrict__ soft, SupView sv, size_t HW) {
+    const int b = blockIdx.y;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = p < HW;
+    long long id = in ? sv.sup[(size_t)b * HW + p] : -1;
+    const bool ok = in && id >= 0 && id < sv.max_regions;
+    if (in && !ok) atomicOr(sv.cnt + 1, 1);
+    const int idm = wave_max_i32(ok ? (int)id : -1);
+    if ((threadIdx.x & 63) == 0 && idm >= 0) atomicMax(sv.cnt, idm);
+    unsigned key[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) key[c] = ok ? fkey(soft[((size_t)b * C + c) * HW + p]) : 0u;
+    // superpixels are compact: most waves lie inside one, and then one lane carries the wave's maxima
+    const int id0 = __builtin_amdgcn_readfirstlane((int)id);
+    if (__all(ok && (int)id == id0)) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const unsigned m = wave_max_u32(key[c]);
+            if ((threadIdx.x & 63) == 0) atomicMax(sv.tbl + ((size_t)b * sv.max_regions + id0) * C + c, m);
+        }
+    } else if (ok) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) atomicMax(sv.tbl + ((size_t)b * sv.max_regions + id) * C + c, key[c]);
+    }
+}
+
+constexpr int REFINE_ROWS = 8;
+template <int C, bool SUP = false>
 __global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restrict__ sim, const float* __restrict__ p1,
                                                            const float* __restrict__ p2, const float* __restrict__ soft,
                                                            float* __restrict__ out, float* classmax, int h, int w,
-                                                           int H, int W, float temp, int views) {
+                                                           int H, int W, float temp, int views, SupView spx = {}) {
     // a workgroup walks REFINE_ROWS output rows: the per-class maxima leave as one atomic per class and workgroup
     // (one per row-workgroup was 49 K same-address memory-side atomics, a large part of this kernel's time)
     const int b = blockIdx.z;
@@ -659,12 +714,36 @@ __global__ void __launch_bounds__(256) refine_apply_kernel(const float* __restri
             z1[c] = (z1[c] / s1 + z2[c] / s2) * 0.5f;               // (softmax + softmax) * 0.5
             pmax = fmaxf(pmax, a[c]); lmax = fmaxf(lmax, z1[c]);
         }
+        float supw[C];
+        bool sup_on = false;
+        if constexpr (SUP) {
+            const long long id = spx.sup[(size_t)b * HW + (size_t)Y * W + X];
+            // `ignored`: the superpixel with the batch's largest id (alignment.py:241-243); an id outside the table was
+            // flagged by sup_max_kernel and is left alone
+            sup_on = id >= 0 && id < spx.max_regions && id != (long long)spx.cnt[0];
+            if (sup_on) {
+                float m = -INFINITY, ssum = 0.f, smax = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    supw[c] = __fdiv_rn(fkey_inv(spx.tbl[((size_t)b * spx.max_regions + id) * C + c]), temp);
+                    m = fmaxf(m, supw[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) { supw[c] = expf(supw[c] - m); ssum += supw[c]; }
+#pragma unroll
+                for (int c = 0; c < C; ++c) { supw[c] = supw[c] / ssum; smax = fmaxf(smax, supw[c]); }
+#pragma unroll
+                for (int c = 0; c < C; ++c) supw[c] = supw[c] / (smax + 1e-7f);
+            }
+        }
         float tot = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            // mode 'all': both views; 'p' / 'l': `weight = 0 + view` (alignment.py:212,223,236)
+            // mode 'all': both views; 'p' / 'l': `weight = 0 + view` (alignment.py:212,223,236); no view (mode 's' with
+            // superpixels): ones (:257)
             float wgt = (views == 3) ? a[c] / (pmax + 1e-7f) + z1[c] / (lmax + 1e-7f)
-                                     : ((views & 1) ? a[c] / (pmax + 1e-7f) : z1[c] / (lmax + 1e-7f));
+                                     : ((views & 1) ? a[c] / (pmax + 1e-7f) : ((views & 2) ? z1[c] / (lmax + 1e-7f) : 1.f));
+            if constexpr (SUP) wgt = sup_on ? wgt * supw[c] : wgt;      // :254-258
             float v = wgt * sv[c];
             o[c] = v;
             tot += v;
@@ -712,16 +791,45 @@ extern "C" int rgda_label_refine(const float* feat, const float* protos, const f
     return rgda_label_refine_views(feat, protos, p1, p2, soft, out, b, k, c, h, w, H, W, temp, 3, ws, ws_bytes, stream);
 }
 
+static int refine_run(const float* feat, const float* protos, const float* p1, const float* p2, const float* soft,
+                      const long long* sup, int max_regions, float* out, int b, int k, int c, int h, int w, int H, int W,
+                      float temp, int views, void* ws, size_t ws_bytes, rgda_stream_t stream);
+
 extern "C" int rgda_label_refine_views(const float* feat, const float* protos, const float* p1, const float* p2,
                                        const float* soft, float* out, int b, int k, int c, int h, int w, int H, int W,
                                        float temp, int views, void* ws, size_t ws_bytes, rgda_stream_t stream) {
-    if (views < 1 || views > 3 || !soft || !out || !ws) return RGDA_ERR_ARG;
+    if (views < 1 || views > 3) return RGDA_ERR_ARG;
+    return refine_run(feat, protos, p1, p2, soft, nullptr, 0, out, b, k, c, h, w, H, W, temp, views, ws, ws_bytes, stream);
+}
+
+extern "C" size_t rgda_label_refine_sup_workspace(int b, int c, int h, int w, int max_regions) {
+    // the workspace of rgda_label_refine | keys[b][max_regions][c] | largest id, flag
+    return rgda_label_refine_workspace(b, c, h, w) + align256((size_t)b * max_regions * c * 4) + 256;
+}
+extern "C" size_t rgda_label_refine_sup_flag_offset(int b, int c, int h, int w, int max_regions) {
+    return rgda_label_refine_workspace(b, c, h, w) + align256((size_t)b * max_regions * c * 4);
+}
+
+extern "C" int rgda_label_refine_sup(const float* feat, const float* protos, const float* p1, const float* p2,
+                                     const float* soft, const int64_t* label_t_sup, float* out, int b, int k, int c,
+                                     int h, int w, int H, int W, float temp, int views, int max_regions, void* ws,
+                                     size_t ws_bytes, rgda_stream_t stream) {
+    if (views < 0 || views > 3 || !label_t_sup || max_regions <= 0) return RGDA_ERR_ARG;
+    return refine_run(feat, protos, p1, p2, soft, (const long long*)label_t_sup, max_regions, out, b, k, c, h, w, H, W, temp, views, ws,
+                      ws_bytes, stream);
+}
+
+static int refine_run(const float* feat, const float* protos, const float* p1, const float* p2, const float* soft,
+                      const long long* sup, int max_regions, float* out, int b, int k, int c, int h, int w, int H, int W,
+                      float temp, int views, void* ws, size_t ws_bytes, rgda_stream_t stream) {
+    if (!soft || !out || !ws) return RGDA_ERR_ARG;
     const bool pview = views & 1, lview = views & 2;
     if ((pview && (!feat || !protos)) || (lview && (!p1 || !p2))) return RGDA_ERR_ARG;
     if (c != 6) return RGDA_ERR_UNSUPPORTED;   // ISPRS: 6 classes (regda/datasets/isprsda.py:18-26)
     if (b <= 0 || (pview && (k < 2 || k > 4096 || (k & 3))) || h <= 0 || w <= 0 || H <= 0 || W <= 0 || !(temp > 0.f))
         return RGDA_ERR_ARG;
-    if (ws_bytes < rgda_label_refine_workspace(b, c, h, w)) return RGDA_ERR_WORKSPACE;
+    if (ws_bytes < (sup ? rgda_label_refine_sup_workspace(b, c, h, w, max_regions) : rgda_label_refine_workspace(b, c, h, w)))
+        return RGDA_ERR_WORKSPACE;
     hipStream_t st = to_stream(stream);
     char* base = (char*)ws;
     float* sim = (float*)base;
@@ -747,7 +855,22 @@ extern "C" int rgda_label_refine_views(const float* feat, const float* protos, c
     RGDA_CHECK_LAUNCH();
     }
     dim3 g2(cdiv(W, 256), cdiv(H, REFINE_ROWS), b);
-    refine_apply_kernel<6><<<g2, 256, 0, st>>>(sim, p1, p2, soft, out, classmax, h, w, H, W, temp, views);
+    if (!sup) {
+        refine_apply_kernel<6><<<g2, 256, 0, st>>>(sim, p1, p2, soft, out, classmax, h, w, H, W, temp, views);
+        RGDA_CHECK_LAUNCH();
+        return RGDA_OK;
+    }
+    SupView sv;
+    sv.sup = sup;
+    sv.max_regions = max_regions;
+    const size_t tbl_bytes = align256((size_t)b * max_regions * c * 4);
+    sv.tbl = (unsigned*)(base + rgda_label_refine_workspace(b, c, h, w));
+    sv.cnt = (int*)((char*)sv.tbl + tbl_bytes);
+    if (zero_bytes(sv.tbl, tbl_bytes + 256, stream) != RGDA_OK) return RGDA_ERR_LAUNCH;     // key 0 = below every float
+    const size_t HW = (size_t)H * W;
+    sup_max_kernel<6><<<dim3(cdiv(HW, (size_t)256), b), 256, 0, st>>>(soft, sv, HW);
+    RGDA_CHECK_LAUNCH();
+    refine_apply_kernel<6, true><<<g2, 256, 0, st>>>(sim, p1, p2, soft, out, classmax, h, w, H, W, temp, views, sv);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -1,6 +1,6 @@
 """Aligner (prototype EMA + online soft-label re-weighting) -- mirror of the parts of
-regda/gast/alignment.py that sit on the SSL path: label_refine (:194-265, with
-label_t_sup=None as tools/train_ssl_reg.py:214 calls it; every `mode`), update_prototype (:86-90),
+regda/gast/alignment.py that sit on the SSL path: label_refine (:194-265,
+with and without the superpixel view; every `mode`), update_prototype (:86-90),
 DownscaleLabel (:456-481).  Stage-2 alignment losses are out of scope.
 """
 import torch
@@ -49,24 +49,30 @@ class Aligner:
         return ops.proto_update(feat.detach(), label, self.prototypes, 16, self.ignore_label, 0.75, self.decay)
 
     def label_refine(self, label_t_sup, feat_t, preds_t, label_t_soft, refine=True, mode='all', temp=2.0):
-        """alignment.py:194-265.  Built: every `mode` with label_t_sup=None (the SSL path passes None,
-        tools/train_ssl_reg.py:214) and one or two prediction tensors.  The superpixel view (label_t_sup given, modes
-        'all' / 's') is not."""
+        """alignment.py:194-265: every `mode`, one or two prediction tensors, with or without the superpixel view
+        (label_t_sup (b,1,H,W) int64 given and mode 'all' / 's', :238-258; the SSL path passes None,
+        tools/train_ssl_reg.py:214).  `max_superpixels` (attribute, default 65536) bounds the ids: the table of
+        per-superpixel maxima is sized by it instead of by a read-back of label_t_sup.max()."""
         assert mode in ['all', 's', 'p', 'n', 'l']
         if not refine:
             return label_t_soft
-        if label_t_sup is not None and mode in ('all', 's'):
-            raise NotImplementedError('the superpixel view of label_refine (label_t_sup given) is not built; '
-                                      'see DESIGN.md "out of scope"')
-        if mode in ('s', 'n'):
+        sup = label_t_sup is not None and mode in ('all', 's')
+        if mode == 'n' or (mode == 's' and not sup):
             return label_t_soft                  # no view contributes: `weight` stays the int 0 (alignment.py:260-261)
-        if isinstance(preds_t, (list, tuple)):
-            assert len(preds_t) == 2
-            p1, p2 = preds_t
+        views = {'all': 3, 'p': 1, 'l': 2, 's': 0}[mode]
+        p1 = p2 = None
+        if views & 2:
+            if isinstance(preds_t, (list, tuple)):
+                assert len(preds_t) == 2
+                p1, p2 = preds_t
+            else:
+                p1 = p2 = preds_t                # (s + s) * 0.5 == s: the single-tensor branch, alignment.py:232-234
+            p1, p2 = p1.detach(), p2.detach()
+        feat = feat_t.detach() if views & 1 else None
+        if sup:
+            out, cm = ops.label_refine_sup(feat, self.prototypes, p1, p2, label_t_soft, label_t_sup.long(), temp, views,
+                                           max_regions=getattr(self, 'max_superpixels', 65536), return_ws=True)
         else:
-            p1 = p2 = preds_t                    # (s + s) * 0.5 == s: the single-tensor branch, alignment.py:232-234
-        views = {'all': 3, 'p': 1, 'l': 2}[mode]
-        out, cm = ops.label_refine(feat_t.detach(), self.prototypes, p1.detach() if views & 2 else None,
-                                   p2.detach() if views & 2 else None, label_t_soft, temp, return_ws=True, views=views)
+            out, cm = ops.label_refine(feat, self.prototypes, p1, p2, label_t_soft, temp, return_ws=True, views=views)
         self._classmax_ws = cm       # per-image per-class maxima of the result (reused by the fused trainer)
         return out

@@ -194,6 +194,49 @@ def label_refine(feat, protos, p1, p2, soft, temp=2.0, out=None, return_ws=False
     return out
 
 
+def label_refine_sup(feat, protos, p1, p2, soft, label_t_sup, temp=2.0, views=3, max_regions=65536, out=None, check=True,
+                     return_ws=False):
+    """label_refine with the superpixel view (rgda_label_refine_sup; alignment.py:238-258).  label_t_sup: int64 ids, b*H*W
+    of them in any shape; views 3 = mode 'all', 0 = mode 's' (no other inputs needed).  check=True reads the range flag back
+    (one host sync)."""
+    pview, lview = bool(views & 1), bool(views & 2)
+    assert views in (0, 1, 2, 3)
+    soft = soft.contiguous().float()
+    _need_cuda(soft, label_t_sup)
+    b, c = soft.shape[:2]
+    H, W = soft.shape[-2:]
+    assert label_t_sup.dtype == torch.int64 and label_t_sup.numel() == b * H * W
+    label_t_sup = label_t_sup.contiguous()
+    k, h, w = 4, 1, 1
+    if pview:
+        _need_cuda(feat, protos)
+        feat, protos = feat.contiguous().float(), protos.contiguous().float()
+        k = feat.shape[1]
+        h, w = feat.shape[-2:]
+        assert feat.shape[0] == b and protos.shape == (c, k)
+    if lview:
+        _need_cuda(p1, p2)
+        p1, p2 = p1.contiguous().float(), p2.contiguous().float()
+        h, w = p1.shape[-2:]
+        assert p1.shape == (b, c, h, w) and p2.shape == (b, c, h, w)
+        assert not pview or feat.shape[-2:] == (h, w)
+    if out is None:
+        out = torch.empty_like(soft)
+    L = lib()
+    ws = _ws(L.size('rgda_label_refine_sup_workspace', b, c, h, w, max_regions), soft.device)
+    L.call('rgda_label_refine_sup', _p(feat if pview else None), _p(protos if pview else None), _p(p1 if lview else None),
+           _p(p2 if lview else None), soft.data_ptr(), label_t_sup.data_ptr(), out.data_ptr(), b, k, c, h, w, H, W,
+           float(temp), views, max_regions, ws.data_ptr(), ws.numel(), _stream())
+    if check:
+        off = L.size('rgda_label_refine_sup_flag_offset', b, c, h, w, max_regions)
+        if int(ws[off + 4:off + 8].view(torch.int32).item()):
+            raise ValueError(f'label_refine: a superpixel id is outside [0, max_regions={max_regions})')
+    if return_ws:
+        off = L.size('rgda_label_refine_classmax_offset', b, c, h, w)
+        return out, ws[off:]
+    return out
+
+
 def proto_update(feat, label, protos, scale=16, ignore_label=-1, min_ratio=0.75, decay=0.996):
     """In-place EMA update of `protos`; returns the downscaled label (b,1,h,w) int64."""
     _need_cuda(feat, label, protos)

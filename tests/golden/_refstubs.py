@@ -7,7 +7,8 @@ or by the tests: the GPU box has no /root/reference.
 What is stubbed and why it does not touch arithmetic is tabulated in
 SURVEY.md section 8(c) / Appendix C.  The one stub that *is* arithmetic is
 torch_scatter.scatter(reduce='sum') on int64, restated with scatter_add_
-(an integer sum has exactly one right answer).
+(an integer sum has exactly one right answer), and reduce='max' on fp32, restated with scatter_reduce_('amax') (a maximum
+has exactly one right answer too; slots nothing indexes read 0 as in torch_scatter and are never gathered by the reference).
 """
 import sys
 import types
@@ -70,10 +71,14 @@ class _Registry(dict):
 
 
 def _scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum'):
-    assert reduce in ('sum', 'add')
+    assert reduce in ('sum', 'add', 'max')
     index = index.expand_as(src)
     size = list(src.shape)
     size[dim] = int(index.max()) + 1 if dim_size is None else dim_size
+    if reduce == 'max':
+        # torch_scatter's scatter_max: the maximum of the entries sharing an index; slots nothing indexes read 0
+        out = torch.full(size, float('-inf'), dtype=src.dtype).scatter_reduce_(dim, index, src, reduce='amax')
+        return torch.where(torch.isinf(out) & (out < 0), torch.zeros_like(out), out)
     return torch.zeros(size, dtype=src.dtype).scatter_add_(dim, index, src)
 
 

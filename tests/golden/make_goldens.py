@@ -186,6 +186,35 @@ def gold_refine():
          protos_new=al.prototypes.numpy())
 
 
+def gold_refine_sup():
+    """label_refine WITH the superpixel view (alignment.py:238-258), modes 'all' and 's', from the reference's own Aligner
+    (torch_scatter stubbed, _refstubs.py).  Same inputs as gold_refine (refine.npz holds them) plus a superpixel map: painted rectangles over a
+    zero background; image 0 does not hold the batch's largest id, image 1 does (its pixels are `ignored`)."""
+    torch.manual_seed(5)
+    b, k, h, w, C = 2, 64, 4, 4, 6
+    al = Aligner(logger=_Log(), feat_channels=k, class_num=C, ignore_label=-1, decay=0.996, resume=None)
+    protos = torch.randn(C, k)
+    al.prototypes = protos.clone()
+    feat_t = torch.randn(b, k, h, w)
+    feat_t[0, :, 0, 0] = protos[2]
+    p1, p2 = torch.randn(b, C, h, w) * 2, torch.randn(b, C, h, w) * 2
+    soft = torch.softmax(torch.randn(b, C, 64, 64) * 3, 1)
+    rng = np.random.default_rng(17)
+    sup = random_regions(rng, b, 64, 64, 23, zero_frac=0.1)
+    sup[0][sup[0] == sup.max()] = 1
+    sup[1, 40:50, 8:30] = 31                     # the largest id of the batch: ignored
+    sup[0, :2, :] = np.arange(64)[None, :] % 29   # single-pixel superpixels / ids changing inside a wave
+    sup_t = torch.from_numpy(sup).reshape(b, 1, 64, 64)
+    out_all = al.label_refine(sup_t, feat_t, [p1, p2], soft, refine=True, mode='all', temp=2.0)
+    out_s = al.label_refine(sup_t, feat_t, [p1, p2], soft, refine=True, mode='s', temp=1.5)
+    out_p = al.label_refine(sup_t, feat_t, [p1, p2], soft, refine=True, mode='p', temp=2.0)      # does not look at sup
+    assert torch.equal(out_p, al.label_refine(None, feat_t, [p1, p2], soft, refine=True, mode='p', temp=2.0))
+    base = np.load(os.path.join(HERE, 'refine.npz'))             # same seed, same draws: the inputs are refine.npz's
+    for key, val in (('feat_t', feat_t), ('protos', protos), ('p1', p1), ('p2', p2), ('soft', soft)):
+        assert np.array_equal(base[key], val.numpy()), key
+    save('refine_sup.npz', sup=sup.astype(np.int8), out_all=out_all.numpy(), out_s=out_s.numpy())
+
+
 def gold_regions():
     """SAM.get_local_regions (regda/utils/local_region_homog.py:41-64) -- the reference's OWN assembly of the region map
     from the mask generator's output: masks in generator order, those with area >= area_thrshold painted one over the
@@ -575,6 +604,6 @@ def gold_aspp():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'model128', 'tta', 'pcl', 'align', 'aspp', 'regions']
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'model128', 'tta', 'pcl', 'align', 'aspp', 'regions', 'refine_sup']
     for w in which:
         globals()['gold_' + w]()

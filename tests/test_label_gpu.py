@@ -131,8 +131,62 @@ def test_label_refine_other_modes_golden(mods, gold):
     for mode in ('n', 's'):
         assert al.label_refine(None, feat, [p1, p2], soft, True, mode, 2.0) is soft      # no view: returned as is
     assert al.label_refine(None, feat, [p1, p2], soft, False, 'all', 2.0) is soft
-    with pytest.raises(NotImplementedError):                                              # superpixel view: not built
-        al.label_refine(torch.zeros(2, 1, 64, 64, dtype=torch.int64, device='cuda'), feat, [p1, p2], soft, True, 'all')
+
+
+def test_label_refine_superpixel_view_golden(mods, gold):
+    """label_refine with label_t_sup given (regda/gast/alignment.py:238-258), modes 'all' and 's', against outputs of the
+    reference's own Aligner (make_goldens.gold_refine_sup; inputs shared with refine.npz): superpixels that do and do not
+    fill a wave, single-pixel superpixels, and the batch's largest id (`ignored`) present in one image only."""
+    g, gs = gold('refine.npz'), gold('refine_sup.npz')
+    al = mods.Aligner(None, feat_channels=64, class_num=6, ignore_label=-1, decay=0.996)
+    al.prototypes = cu(g['protos']).clone()
+    feat, p1, p2, soft = cu(g['feat_t']), cu(g['p1']), cu(g['p2']), cu(g['soft'])
+    sup = cu(gs['sup'].astype(np.int64), torch.int64).reshape(2, 1, 64, 64)
+    for key, mode, temp in (('out_all', 'all', 2.0), ('out_s', 's', 1.5)):
+        out = al.label_refine(sup, feat, [p1, p2], soft, True, mode, temp)
+        np.testing.assert_allclose(out.cpu().numpy(), gs[key], rtol=2e-4, atol=2e-6, err_msg=key)
+        cm = al._classmax_ws[:2 * 6 * 4].view(torch.float32).cpu().reshape(2, 6)
+        assert torch.equal(cm, out.cpu().flatten(2).max(-1)[0])
+    # mode 's' needs neither features nor predictions
+    assert torch.equal(al.label_refine(sup, None, None, soft, True, 's', 1.5), al.label_refine(sup, feat, [p1, p2], soft, True, 's', 1.5))
+    # modes 'p' / 'l' do not look at the superpixels, 'n' returns its input
+    for mode in ('p', 'l'):
+        assert torch.equal(al.label_refine(sup, feat, [p1, p2], soft, True, mode, 2.0),
+                           al.label_refine(None, feat, [p1, p2], soft, True, mode, 2.0))
+    assert al.label_refine(sup, feat, [p1, p2], soft, True, 'n', 2.0) is soft
+    # an id outside the table: reported
+    al.max_superpixels = 16
+    with pytest.raises(ValueError):
+        al.label_refine(sup, feat, [p1, p2], soft, True, 'all', 2.0)
+    with pytest.raises(ValueError):
+        al.label_refine(-sup - 1, feat, [p1, p2], soft, True, 's', 2.0)
+
+
+def test_label_refine_superpixel_view_full_size_vs_oracle(mods):
+    """2 x 6 x 512 x 512 with a SLIC-like map (a 16 x 16 grid of cells with ragged borders, ids up to 1088): the
+    per-superpixel maxima are exact (a maximum has one answer), the rest carries the tolerance of the other views."""
+    g = torch.Generator().manual_seed(12)
+    b, k, h, w, H = 2, 256, 32, 32, 512
+    feat = torch.randn(b, k, h, w, generator=g)
+    protos = torch.randn(6, k, generator=g)
+    p1, p2 = torch.randn(b, 6, h, w, generator=g) * 2, torch.randn(b, 6, h, w, generator=g) * 2
+    soft = torch.softmax(torch.randn(b, 6, H, H, generator=g) * 3, 1)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(H), indexing='ij')
+    jit = torch.randint(-3, 4, (b, H, H), generator=g)
+    sup = (((yy + jit).clamp(0, H - 1) // 16) * 32 + (xx + jit.flip(-1)).clamp(0, H - 1) // 16).long()      # ids 0 .. 1023
+    sup[1, 300:340, 100:200] = 1088                                          # the batch's largest id: ignored
+    sup = sup.reshape(b, 1, H, H)
+    al = mods.Aligner(None, feat_channels=k, class_num=6, ignore_label=-1, decay=0.996)
+    al.prototypes = protos.cuda()
+    for mode, temp in (('all', 2.0), ('s', 2.0)):
+        ref = opath.label_refine(feat, protos, [p1, p2], soft, True, mode, temp, label_t_sup=sup)
+        out = al.label_refine(sup.cuda(), feat.cuda(), [p1.cuda(), p2.cuda()], soft.cuda(), True, mode, temp).cpu()
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=5e-4, atol=1e-6, err_msg=mode)
+    # the ignored superpixel keeps the weight of the other views: equal to the run without superpixels there
+    plain = al.label_refine(None, feat.cuda(), [p1.cuda(), p2.cuda()], soft.cuda(), True, 'all', 2.0).cpu()
+    withs = al.label_refine(sup.cuda(), feat.cuda(), [p1.cuda(), p2.cuda()], soft.cuda(), True, 'all', 2.0).cpu()
+    ign = (sup == 1088).expand(-1, 6, -1, -1)
+    assert torch.equal(plain[ign], withs[ign]) and not torch.equal(plain[~ign], withs[~ign])
 
 
 def test_label_refine_full_size_vs_oracle(mods):

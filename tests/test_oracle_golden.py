@@ -77,6 +77,22 @@ def test_label_refine_and_prototypes(gold):
     np.testing.assert_allclose(new.numpy(), g['protos_new'], rtol=1e-5, atol=1e-6)
 
 
+def test_label_refine_superpixel_view(gold):
+    """The superpixel view (alignment.py:238-258), modes 'all' and 's', against outputs of the reference's own Aligner
+    (make_goldens.gold_refine_sup; the inputs are refine.npz's)."""
+    g, gs = gold('refine.npz'), gold('refine_sup.npz')
+    t = lambda k: torch.from_numpy(g[k])
+    sup = torch.from_numpy(gs['sup'].astype(np.int64)).reshape(2, 1, 64, 64)
+    for key, mode, temp in (('out_all', 'all', 2.0), ('out_s', 's', 1.5)):
+        o = labelpath.label_refine(t('feat_t'), t('protos'), [t('p1'), t('p2')], t('soft'), True, mode, temp, label_t_sup=sup)
+        np.testing.assert_allclose(o.numpy(), gs[key], rtol=2e-5, atol=1e-6, err_msg=key)
+    # modes 'p' / 'l' / 'n' do not look at the superpixels
+    for mode in ('p', 'l', 'n'):
+        a = labelpath.label_refine(t('feat_t'), t('protos'), [t('p1'), t('p2')], t('soft'), True, mode, 2.0, label_t_sup=sup)
+        b = labelpath.label_refine(t('feat_t'), t('protos'), [t('p1'), t('p2')], t('soft'), True, mode, 2.0)
+        assert torch.equal(a, b)
+
+
 def test_loss_and_grad(gold):
     g = gold('loss.npz')
     p1 = torch.from_numpy(g['p1']).requires_grad_(True)

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 struct ConvArgs {
     const bf16_t* x;
@@ -132,41 +133,31 @@ static __device__ __forceinline__ f32x2 bf2f_pair(unsigned u) {
 }
 static __device__ __forceinline__ unsigned pack2bf(f32x2 v) { return pack2bf(v.x, v.y); }
 
-template <int BC, int BP, int NT, int KIND>
-static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const unsigned char* smem, int m0, int c0,
-                                                     float (&s)[8], float (&q)[8]) {
-    constexpr int CSTR = BC * 2 + 16;
-    constexpr int VPR = BC / 8, RPP = NT / VPR, NIT = BP / RPP;
-    constexpr int CH = NIT < 4 ? NIT : 4;                  // rows in flight per thread
-    static_assert(NIT % CH == 0, "row passes");
-    const int t = threadIdx.x;
-    const int cv = t % VPR, rr = t / VPR;
-    const int co = c0 + cv * 8;
-    const bool cok = co < a.Cout;
-    f32x2 k0[4], k1[4];                                     // EV: scale, shift;  BNX: invstd, mean
-    f32x2 k2[4], k3[4];                                     // BNX with bn_relu == 2: scale, shift of the forward operand path
-    f32x2 s2[4], q2[4];
+// the per-channel constants of a fused epilogue for this thread's 8-channel vector: EV: k0 = scale, k1 = shift; BNX: k0 =
+// invstd, k1 = mean; BNX2 also k2, k3 = scale, shift of the forward operand path
+struct EpiParams { f32x2 k0[4], k1[4], k2[4], k3[4]; };
+template <int KIND>
+static __device__ __forceinline__ void epilogue_params(const ConvArgs& a, int m0, int co, bool cok, EpiParams& P) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        k0[e] = f32x2{0.f, 0.f}; k1[e] = f32x2{0.f, 0.f};
-        k2[e] = f32x2{0.f, 0.f}; k3[e] = f32x2{0.f, 0.f};
-        s2[e] = f32x2{s[2 * e], s[2 * e + 1]}; q2[e] = f32x2{q[2 * e], q[2 * e + 1]};
+        P.k0[e] = f32x2{0.f, 0.f}; P.k1[e] = f32x2{0.f, 0.f};
+        P.k2[e] = f32x2{0.f, 0.f}; P.k3[e] = f32x2{0.f, 0.f};
     }
     constexpr bool BNX = KIND == EPI_BNX || KIND == EPI_BNX2;
     if (BNX && cok) {
         const float* mi = a.bn_mi + (size_t)(m0 / a.rows_per_group) * 2 * a.Cout + co;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            k1[e] = f32x2{mi[2 * e], mi[2 * e + 1]};
-            k0[e] = f32x2{mi[a.Cout + 2 * e], mi[a.Cout + 2 * e + 1]};
+            P.k1[e] = f32x2{mi[2 * e], mi[2 * e + 1]};
+            P.k0[e] = f32x2{mi[a.Cout + 2 * e], mi[a.Cout + 2 * e + 1]};
         }
         if constexpr (KIND == EPI_BNX2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float sc, sh;
-                bn_scale_shift(k1[e >> 1][e & 1], k0[e >> 1][e & 1], a.bn_gamma[co + e], a.bn_beta[co + e], sc, sh);
-                k2[e >> 1][e & 1] = sc;
-                k3[e >> 1][e & 1] = sh;
+                bn_scale_shift(P.k1[e >> 1][e & 1], P.k0[e >> 1][e & 1], a.bn_gamma[co + e], a.bn_beta[co + e], sc, sh);
+                P.k2[e >> 1][e & 1] = sc;
+                P.k3[e >> 1][e & 1] = sh;
             }
         }
     }
@@ -174,10 +165,33 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float sc = a.ev_gamma[co + e] / sqrtf(a.ev_rv[co + e] + a.ev_eps);
-            k0[e >> 1][e & 1] = sc;
-            k1[e >> 1][e & 1] = a.ev_beta[co + e] - a.ev_rm[co + e] * sc;
+            P.k0[e >> 1][e & 1] = sc;
+            P.k1[e >> 1][e & 1] = a.ev_beta[co + e] - a.ev_rm[co + e] * sc;
         }
     }
+}
+
+// FULL: every row and channel of the tile exists (the caller's host side guarantees it): no per-lane conditions, exactly
+// NIT row stores per thread.  pre: the constants, prepared once by a caller that runs many tiles of one channel tile and
+// one statistics group (conv1x1_stream_kernel); nullptr: prepared here.
+template <int BC, int BP, int NT, int KIND, bool FULL = false>
+static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const unsigned char* smem, int m0, int c0,
+                                                     float (&s)[8], float (&q)[8], const EpiParams* pre = nullptr) {
+    constexpr int CSTR = BC * 2 + 16;
+    constexpr int VPR = BC / 8, RPP = NT / VPR, NIT = BP / RPP;
+    constexpr int CH = NIT < 4 ? NIT : 4;                  // rows in flight per thread
+    static_assert(NIT % CH == 0, "row passes");
+    const int t = threadIdx.x;
+    const int cv = t % VPR, rr = t / VPR;
+    const int co = c0 + cv * 8;
+    const bool cok = FULL || co < a.Cout;
+    EpiParams P;
+    if (pre) P = *pre; else epilogue_params<KIND>(a, m0, co, cok, P);
+    f32x2 (&k0)[4] = P.k0, (&k1)[4] = P.k1, (&k2)[4] = P.k2, (&k3)[4] = P.k3;
+    f32x2 s2[4], q2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s2[e] = f32x2{s[2 * e], s[2 * e + 1]}; q2[e] = f32x2{q[2 * e], q[2 * e + 1]}; }
+    constexpr bool BNX = KIND == EPI_BNX || KIND == EPI_BNX2;
     const bool has_res = (KIND == EPI_RES || KIND == EPI_RES_STATS) || ((KIND == EPI_EV || BNX) && a.res);
     const bool res_gate = (KIND != EPI_EV) && has_res && a.res_mask;
     constexpr bool STATS = KIND == EPI_STATS || KIND == EPI_RES_STATS;
@@ -191,7 +205,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
         for (int i = 0; i < CH; ++i) {
             const int row = rr + (p0 + i) * RPP;
             const int m = m0 + row;
-            ok[i] = cok && m < a.M;
+            ok[i] = FULL || (cok && m < a.M);
             val[i] = *(const uint4*)(smem + row * CSTR + cv * 16);
             rv[i] = uint4{0u, 0u, 0u, 0u}; xv[i] = rv[i]; yv[i] = rv[i]; rmb[i] = 0xffu; bmb[i] = 0xffu;
             if (ok[i]) {
@@ -279,7 +293,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
                         q2[e] += g * ((bf2f_pair(xw[e]) - k1[e]) * k0[e]);
                     }
                 }
-                if (!(TSKIP(a) & 128)) *(uint4*)(a.y + (size_t)m * a.ldy + co) = uint4{ow[0], ow[1], ow[2], ow[3]};
+                if (FULL || !(TSKIP(a) & 128)) *(uint4*)(a.y + (size_t)m * a.ldy + co) = uint4{ow[0], ow[1], ow[2], ow[3]};
             }
         }
     }
@@ -291,10 +305,13 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
 // bytes + the reduction scratch behind it) -> 16-byte rows to memory, with the fused residual / inference BatchNorm /
 // BatchNorm statistics / BatchNorm-backward sums.  s, q: the per-channel sums of this thread's channel vector,
 // carried by the caller; flush: reduce them over the workgroup and add them to statistics replica `replica`.
-template <int BC, int BP, int WC, int WP>
+// KIND >= 0: the caller was compiled for one fused variant (conv1x1_stream_kernel: with the seven variants inside its tile
+// loop the compiler merges their pending-load states at the back edge and opens every tile with `s_waitcnt vmcnt(0)`, and
+// the kernel carries 193 registers instead of 114); KIND < 0: chosen here from the arguments.
+template <int BC, int BP, int WC, int WP, bool RAW = false, int KIND = -1>
 static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BC / WC / 32][BP / WP / 32],
                                                      unsigned char* smem, int m0, int c0, float (&s)[8], float (&q)[8],
-                                                     bool flush, int replica) {
+                                                     bool flush, int replica, const EpiParams* pre = nullptr) {
     constexpr int NW = WC * WP, NT = 64 * NW;
     constexpr int FI = BC / WC / 32, FJ = BP / WP / 32;
     constexpr int CSTR = BC * 2 + 16;
@@ -317,12 +334,20 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
                 *(uint2*)(smem + px * CSTR + co * 2) = pk;
             }
         }
-    __syncthreads();
+    if constexpr (RAW) {
+        // LDS only: `__syncthreads()` also waits for every memory operation in flight (conv1x1_stream_kernel: the tiles
+        // prefetched for the next iterations and the previous tile's row stores)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();
+    }
     if (TDBG(a) && t == 0) TDBG(a)[(16384 + blockIdx.x) * 4 + 0] = __builtin_readcyclecounter();
     constexpr int VPR = BC / 8;              // 16-byte vectors per C row
     const int cv = t % VPR;
     // the row pass, specialised per fused variant (uniform branches; each variant is one straight block)
-    if (a.ev_rm) epilogue_rows<BC, BP, NT, EPI_EV>(a, smem, m0, c0, s, q);
+    if constexpr (KIND >= 0) epilogue_rows<BC, BP, NT, KIND, RAW>(a, smem, m0, c0, s, q, pre);
+    else if (a.ev_rm) epilogue_rows<BC, BP, NT, EPI_EV>(a, smem, m0, c0, s, q);
     else if (a.bn_x) {
         if (a.bn_relu == 2) epilogue_rows<BC, BP, NT, EPI_BNX2>(a, smem, m0, c0, s, q);
         else epilogue_rows<BC, BP, NT, EPI_BNX>(a, smem, m0, c0, s, q);
@@ -890,6 +915,118 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 1x1 / stride 1 convolutions with a SHORT K (64 or 128 input channels) on large maps (layer 1's 64 -> 256, layer 2's
+// 128 -> 512: forward, the data gradients of the 256 -> 64 / 512 -> 128 convolutions, the teacher).  One or two K tiles per
+// output tile: conv_igemm_kernel has no steady state there -- a workgroup is prologue (index arithmetic, the first DMA and
+// its full memory latency) and epilogue, 2.7-3.2 TB/s of the traffic that is all such a convolution is (64 -> 256: 1 byte
+// read per 4 written), and every 128-pixel tile sends its 256 statistics atomics.  Here a persistent workgroup (one per CU)
+// owns ONE channel tile and a CHUNK of consecutive pixel tiles: its 128 x K weights stay in registers (A fragments straight
+// from memory, 32 / 64 VGPRs), the pixel tiles stream through a two-stage LDS ring one tile AHEAD of the tile being
+// multiplied and stored, and the statistics leave once per workgroup.  64 -> 256 on 16 x 128 x 128 with statistics:
+// 58 -> 37 us (4.6 TB/s); 128 -> 512 on 16 x 64 x 64: 36 -> 27 us.
+//   Ordering (vmcnt retires in order, loads AND stores on gfx9): a tile ends with its SC = 4 row stores per thread (FULL
+//   epilogue: every row and channel exists, the host guarantees it) and `s_waitcnt vmcnt(SC)` -- everything older than those
+//   stores is complete: the epilogue's own loads (so the compiler carries no pending-load state into the next tile: with
+//   conditional loads in the loop it opens every tile with `s_waitcnt vmcnt(0)`) AND the DMA of the next tile, issued at
+//   the end of the previous one.  The tile after next is issued behind that wait, into the stage the MFMAs have just left.
+//   The DMA is issued from inline assembly: through the builtin the compiler would put `s_waitcnt vmcnt(0)` in front of
+//   the epilogue's LDS stores.  One instantiation per fused epilogue KIND (with all seven in one loop: 193 registers
+//   instead of 106-158).
+// Requires: 1x1, stride 1, no padding, Cin = 64 KC, Cout % 128 == 0, M % (128 a.tpw) == 0, a chunk inside one statistics
+// group; a.tpw = pixel tiles per workgroup, grid = tiles_c * tiles_p / a.tpw.
+template <int KC, int KIND>
+__global__ void __launch_bounds__(512) conv1x1_stream_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BC = 128, BP = 128, WC = 2, WP = 4, NW = 8, FI = 2, NS = 2;
+    constexpr int XL = BP / (NW * 8);                      // DMA instructions per wave and 64-channel sub-tile (1 KiB each)
+    constexpr int SUB = BP * 128;                          // bytes of one sub-tile: 128 pixels x 64 channels
+    constexpr int STAGE = KC * SUB;
+    constexpr int CSTR = BC * 2 + 16;
+    constexpr int EPI = BP * CSTR + NW * BC * 2 * 4;
+    constexpr int SC = BP * BC * 2 / 16 / (64 * NW);       // row stores per thread and tile (4)
+    __shared__ __attribute__((aligned(256))) unsigned char smem[NS * STAGE + EPI];
+    unsigned char* se = smem + NS * STAGE;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave % WC, wp = wave / WC;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int lrow8 = lane >> 3, lslot = lane & 7;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int c0 = (logical % a.tiles_c) * BC;             // channel tiles of one chunk are neighbours: they share the pixels in L2
+    const int T = a.tpw;
+    const int mbase = (logical / a.tiles_c) * T * BP;
+
+    // the wave's 64 weight rows stay in registers for the whole chunk
+    bf16x8 fa[KC * 4][FI];
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+        const bf16_t* wrow = a.w + (size_t)(c0 + wc * (BC / WC) + i * 32 + lrow) * a.Cin + lk * 8;
+#pragma unroll
+        for (int kk = 0; kk < KC * 4; ++kk) fa[kk][i] = *(const bf16x8*)(wrow + kk * 16);
+    }
+    // the weights are waited for HERE: left to the compiler, the wait lands at their first use inside the loop and, being
+    // in a loop, becomes `s_waitcnt vmcnt(0)` on every tile
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int kk = 0; kk < KC * 4; ++kk) asm volatile("" ::"v"(fa[kk][i]));
+    const i32x4 rs_x = dma_rsrc(a.x, (unsigned)((((size_t)a.M - 1) * a.ldx + a.Cin) * 2));
+    int xvo[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int r = (i * NW + wave) * 8 + lrow8;
+        xvo[i] = r * a.ldx * 2 + (lslot ^ ((r >> 1) & 7)) * 16;
+    }
+    auto issue = [&](int tile, int stage) {
+        const int so = (mbase + tile * BP) * a.ldx * 2;
+#pragma unroll
+        for (int kt = 0; kt < KC; ++kt)
+#pragma unroll
+            for (int i = 0; i < XL; ++i)
+                dma16_to_lds(rs_x, smem + stage * STAGE + kt * SUB + (i * NW + wave) * 1024, xvo[i], so + kt * 128);
+    };
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    // the epilogue's per-channel constants (inference BatchNorm scale / shift, BatchNorm-backward mean / invstd ...): once,
+    // not once per tile -- their loads would sit in front of every row pass and, retiring in order, pull the prefetch in
+    EpiParams P;
+    epilogue_params<KIND>(a, mbase, c0 + (t % (BC / 8)) * 8, true, P);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(P.k0[e]), "v"(P.k1[e]), "v"(P.k2[e]), "v"(P.k3[e]));
+    issue(0, 0);
+    if (T > 1) { issue(1, 1); WAIT_VMCNT(XL * KC); } else WAIT_VMCNT(0);          // tile 0 has landed
+    for (int i = 0; i < T; ++i) {
+        const int stage = i & 1;
+        __builtin_amdgcn_s_barrier();                      // every wave's pieces of tile i are in LDS; tile i-1's C image is consumed
+        f32x16 acc[FI][1];
+#pragma unroll
+        for (int ii = 0; ii < FI; ++ii)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ii][0][r] = 0.f;
+        const int rb = wp * (BP / WP) + lrow;
+        const unsigned char* xb = smem + stage * STAGE + rb * 128;
+        bf16x8 fb[KC * 4];
+#pragma unroll
+        for (int kk = 0; kk < KC * 4; ++kk)
+            fb[kk] = *(const bf16x8*)(xb + (kk >> 2) * SUB + ((((kk & 3) * 2 + lk) ^ ((rb >> 1) & 7)) << 4));
+#pragma unroll
+        for (int kk = 0; kk < KC * 4; ++kk)
+#pragma unroll
+            for (int ii = 0; ii < FI; ++ii)
+                acc[ii][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][ii], fb[kk], acc[ii][0], 0, 0, 0);
+        // (the barrier inside the epilogue, behind its accumulator -> LDS writes, also says: every wave has read its fragments
+        // of this stage)
+        conv_epilogue<BC, BP, WC, WP, true, KIND>(a, acc, se, mbase + i * BP, c0, s, q, i + 1 == T, blockIdx.x & (NREP - 1), &P);
+        // all but the SC youngest memory operations (this tile's row stores) are complete: tile i+1 is in LDS, and the
+        // compiler knows the epilogue's loads are done.  vmcnt = SC, expcnt / lgkmcnt untouched (gfx9 encoding)
+        __builtin_amdgcn_s_waitcnt(SC | (7 << 4) | (15 << 8));
+        if (i + 2 < T) issue(i + 2, stage);
+    }
+#endif
+}
+
 // layer1's 3x3 convolutions: 64 -> 64 channels, stride 1, on 128-wide maps (forward, data gradient, teacher).
 // With K = 576 and a 64 x 64 tile the implicit-GEMM kernel above spends its time loading operands: 4096 workgroups
 // each pull all 72 KB of weights plus nine shifted copies of their pixels from L2 (600 MB into LDS for 67 MB of
@@ -1196,6 +1333,41 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         else RGDA_LAUNCH("conv3x3_halo_kernel<2, 8, false>", conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a));
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
+    }
+    // short-K 1x1 convolutions on large maps: the persistent streaming kernel, `wgs` workgroups of T pixel tiles each
+    {
+        int stream_on = 1, wpc = 1;
+        if (const char* e = TUNE_ENV("RGDA_STREAM")) stream_on = atoi(e);                   // tuning experiments only
+        if (const char* e = TUNE_ENV("RGDA_STREAM_WPC")) wpc = atoi(e);                     // tuning experiments only
+        if (stream_on && kh == 1 && kw == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W && (Cin == 64 || Cin == 128) &&
+            !(Cout & 127) && !(M & 127)) {
+            const int tiles_c = Cout / 128;
+            const long long tiles_p = M / 128;
+            int chunks = (256 * wpc) / tiles_c;
+            while (chunks > 1 && ((tiles_p % chunks) || (a.rows_per_group % (int)(tiles_p / chunks * 128)))) chunks >>= 1;
+            const long long T = chunks >= 1 ? tiles_p / chunks : 0;
+            if (chunks >= 1 && T >= 4 && T <= 4096 && !(tiles_p % chunks) && !(a.rows_per_group % (int)(T * 128))) {
+                a.tiles_c = tiles_c; a.tiles_p = (int)tiles_p; a.tpw = (int)T;
+                const int grid = tiles_c * chunks;
+                // one instantiation per fused epilogue (the choice conv_epilogue makes from the arguments)
+                const int kind = a.ev_rm ? EPI_EV : a.bn_x ? (a.bn_relu == 2 ? EPI_BNX2 : EPI_BNX)
+                               : a.res ? (a.stats ? EPI_RES_STATS : EPI_RES) : (a.stats ? EPI_STATS : EPI_PLAIN);
+#define RGDA_STREAM(KC, KIND)                                                                                  \
+    case KIND: RGDA_LAUNCH("conv1x1_stream_kernel<" #KC ", " #KIND ">",                                         \
+                           conv1x1_stream_kernel<KC, KIND><<<grid, 512, 0, st>>>(a)); break
+#define RGDA_STREAM_ALL(KC)                                                                                    \
+    switch (kind) {                                                                                            \
+        RGDA_STREAM(KC, 0); RGDA_STREAM(KC, 1); RGDA_STREAM(KC, 2); RGDA_STREAM(KC, 3);                         \
+        RGDA_STREAM(KC, 4); RGDA_STREAM(KC, 5); RGDA_STREAM(KC, 6);                                             \
+    }
+                if (Cin == 64) { RGDA_STREAM_ALL(1) }
+                else { RGDA_STREAM_ALL(2) }
+#undef RGDA_STREAM_ALL
+#undef RGDA_STREAM
+                RGDA_CHECK_LAUNCH();
+                return RGDA_OK;
+            }
+        }
     }
     int bc, bp, stages;
     if (pick_tile(M, Cout, (long long)kh * kw * Cin, (stats && stat_groups > 1) ? a.rows_per_group : 0, bc, bp, stages))

@@ -743,16 +743,19 @@ def test_factored_ppm_maps_equal_the_one_pass_maps_per_op():
 
 # ---------------------------------------------------------------- the 1x1 layers of layer1 / layer2 at full size
 # thousands of tiles per launch, several statistics groups per workgroup wave: every fused epilogue is checked at such a
-# size against torch on the same bf16 operands.
+# size against torch on the same bf16 operands.  64 / 128 input channels with >= 1024 tiles go through
+# conv1x1_stream_kernel (persistent workgroups, T consecutive pixel tiles each, one instantiation per fused epilogue);
+# the others through conv_igemm_kernel.
 STREAM = [  # N, H, W, Cin, Cout
-    (4, 128, 128, 64, 256),        # layer1 conv3: one K slab, two channel tiles
-    (8, 128, 128, 256, 64),        # layer1 conv1: BC = 64, four K slabs
-    (4, 64, 64, 128, 1024),        # eight channel tiles, two K slabs
-    (6, 128, 128, 64, 128),        # tiles_p = 768: uneven tiles per workgroup
-    # conv1x1_resident_kernel (pixel operand resident in LDS, epilogue under the next channel tile's K loop):
-    (16, 32, 32, 256, 1024),       # layer3 conv3 / conv1's data gradient: four K tiles, 2 x 4 channel tiles per pixel tile
-    (16, 64, 64, 128, 512),        # layer2: two K tiles, one workgroup per pixel tile
-    (8, 32, 32, 256, 1024),        # the teacher's batch: two channel tiles per workgroup
+    (4, 128, 128, 64, 256),        # layer1 conv3: stream kernel, T = 4 tiles per workgroup
+    (16, 128, 128, 64, 256),       # ... at the step's 8 + 8 batch: T = 16
+    (6, 128, 128, 64, 256),        # T = 6 (not a power of two), 384 tiles per statistics group
+    (8, 128, 128, 256, 64),        # layer1 conv1: BC = 64, four K slabs (conv_igemm_kernel)
+    (4, 64, 64, 128, 1024),        # stream kernel with two K sub-tiles, eight channel tiles, T = 4
+    (6, 128, 128, 64, 128),        # tiles_p = 768, one channel tile: three tiles per workgroup would be too few -> conv_igemm_kernel
+    (16, 32, 32, 256, 1024),       # layer3 conv3 / conv1's data gradient: four K tiles (conv_igemm_kernel)
+    (16, 64, 64, 128, 512),        # layer2 conv3 / conv1's data gradient: stream kernel, T = 8
+    (8, 32, 32, 256, 1024),        # the teacher's batch
 ]
 
 
@@ -780,6 +783,19 @@ def test_large_1x1_conv_plain_residual_and_statistics(ops, N, H, W, Ci, Co):
     y3 = torch.empty_like(y)
     ops.conv2d(x, w, y3, N, H, W, H, W, 1, 1, 1, 0, 1, 0, res, None)
     assert relerr(y3.float().cpu(), (ref + res.float()).cpu()) < 8e-3      # the conv is rounded to bf16 before the add
+    # residual + statistics of the stored sum
+    st3 = ops.new_stats(groups, 8, 2, Co)
+    y4 = torch.empty_like(y)
+    ops.conv2d(x, w, y4, N, H, W, H, W, 1, 1, 1, 0, 1, 0, res, stats=st3, stat_groups=groups)
+    assert torch.equal(y4, y3)
+    y3g = y3.float().view(groups, M // groups, Co)
+    torch.testing.assert_close(ops.stats_value(st3).sum(1)[:, 0].float().cpu(), y3g.sum(1).cpu(), rtol=1e-4, atol=0.5)
+    torch.testing.assert_close(ops.stats_value(st3).sum(1)[:, 1].float().cpu(), (y3g * y3g).sum(1).cpu(), rtol=1e-4, atol=0.5)
+    # the same call twice: bit-identical output and accumulators (order-independent statistics)
+    st4 = ops.new_stats(groups, 8, 2, Co)
+    y5 = torch.empty_like(y)
+    ops.conv2d(x, w, y5, N, H, W, H, W, 1, 1, 1, 0, 1, 0, res, stats=st4, stat_groups=groups)
+    assert torch.equal(y5, y4) and torch.equal(ops.stats_value(st4).sum(1), ops.stats_value(st3).sum(1))
     # strided views on both sides
     xs = torch.randn(M, Ci + 64, generator=g).to(BF).cuda()
     ybig = torch.zeros(M, Co + 8, dtype=BF, device='cuda')
@@ -791,7 +807,7 @@ def test_large_1x1_conv_plain_residual_and_statistics(ops, N, H, W, Ci, Co):
 @pytest.mark.parametrize('N,H,W,Cb,Cf,use_mask', [(4, 128, 128, 64, 256, False), (16, 32, 32, 256, 1024, False),
                                                   (16, 32, 32, 256, 1024, True), (16, 64, 64, 128, 512, True)])
 def test_large_1x1_conv_fused_bn_backward_sums_and_masks(ops, N, H, W, Cb, Cf, use_mask):
-    """The data-gradient form at layer1 / layer3 / layer2 size (the latter two: conv1x1_resident_kernel): residual gated by
+    """The data-gradient form at layer1 / layer3 / layer2 size (64 / 128 input channels: conv1x1_stream_kernel): residual gated by
     a sign mask + the consumer BatchNorm's backward sums (ReLU from y or from its sign mask), against the unfused kernels
     (rgda_bn_bwd_reduce on the stored gradient)."""
     g = torch.Generator().manual_seed(77)
@@ -817,6 +833,17 @@ def test_large_1x1_conv_fused_bn_backward_sums_and_masks(ops, N, H, W, Cb, Cf, u
     ops.bn_bwd_reduce(dx, cy, cx, mi, want, M, Cf, True, groups=groups)
     torch.testing.assert_close(ops.stats_value(sums, backward=True).sum(1).float().cpu(),
                                ops.stats_value(want, backward=True).sum(1).float().cpu(), rtol=2e-4, atol=0.5)
+    # the ReLU sign recomputed from the raw convolution output (relu = 2: the consumer's activation was never written)
+    gamma, beta = (torch.rand(Cf, generator=g) + 0.5).cuda(), (torch.randn(Cf, generator=g) * 0.3).cuda()
+    dx2 = torch.empty_like(dx)
+    sums2 = ops.new_stats(groups, 8, 2, Cf)
+    ops.conv2d_bnbwd(dy, wt, dx2, N, H, W, H, W, 1, 1, 1, 0, 1, 1, res, sums2, groups, None, cx, mi, 2, res_mask=rmask,
+                     bn_gamma=gamma, bn_beta=beta)
+    assert torch.equal(dx2, dx)                                # the stored gradient does not depend on the ReLU source
+    want2 = ops.new_stats(groups, 8, 2, Cf)
+    ops.bn_bwd_reduce(dx, None, cx, mi, want2, M, Cf, 2, groups=groups, gamma=gamma, beta=beta)
+    torch.testing.assert_close(ops.stats_value(sums2, backward=True).sum(1).float().cpu(),
+                               ops.stats_value(want2, backward=True).sum(1).float().cpu(), rtol=2e-4, atol=0.5)
 
 
 @pytest.mark.parametrize('N,H,W,Ci,Co', [(4, 128, 128, 64, 256), (8, 32, 32, 256, 1024), (8, 64, 64, 128, 512)])

@@ -293,7 +293,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
                         q2[e] += g * ((bf2f_pair(xw[e]) - k1[e]) * k0[e]);
                     }
                 }
-                if (FULL || !(TSKIP(a) & 128)) *(uint4*)(a.y + (size_t)m * a.ldy + co) = uint4{ow[0], ow[1], ow[2], ow[3]};
+                if (!(TSKIP(a) & 128)) *(uint4*)(a.y + (size_t)m * a.ldy + co) = uint4{ow[0], ow[1], ow[2], ow[3]};
             }
         }
     }
@@ -932,18 +932,25 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
 //   The DMA is issued from inline assembly: through the builtin the compiler would put `s_waitcnt vmcnt(0)` in front of
 //   the epilogue's LDS stores.  One instantiation per fused epilogue KIND (with all seven in one loop: 193 registers
 //   instead of 106-158).
-// Requires: 1x1, stride 1, no padding, Cin = 64 KC, Cout % 128 == 0, M % (128 a.tpw) == 0, a chunk inside one statistics
+//   Tiles: 128 channels x 128 pixels, 8 waves as 2 x 4, two accumulators each.  (The template also builds 128 x 64 tiles
+//   with the waves as 4 x 2 for 256 input channels -- layer 3's 256 -> 1024, whose 128-pixel stage would be 64 KB.  Measured
+//   and NOT dispatched: 20.0 us against conv_igemm_kernel's 20.3 plain, 22.0 against 25.3 with statistics, the step
+//   unchanged.  With neither DMA nor row stores that variant still takes 13.5 us: eight lockstep waves per CU walk a chain
+//   of barrier -> fragment reads -> 16 dependent MFMAs -> accumulators to LDS -> barrier -> row pass per 64-pixel unit,
+//   ~1.3 us each, and nothing else is resident to fill it.  The 64 / 128 channel shapes are bound by their row stores.)
+// Requires: 1x1, stride 1, no padding, Cin = 64 KC, Cout % 128 == 0, M % (BP a.tpw) == 0, a chunk inside one statistics
 // group; a.tpw = pixel tiles per workgroup, grid = tiles_c * tiles_p / a.tpw.
-template <int KC, int KIND>
+template <int KC, int BP, int WC, int WP, int KIND>
 __global__ void __launch_bounds__(512) conv1x1_stream_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BC = 128, BP = 128, WC = 2, WP = 4, NW = 8, FI = 2, NS = 2;
+    constexpr int BC = 128, NW = 8, FI = BC / WC / 32, NS = 2;
+    static_assert(WC * WP == NW && BP / WP == 32, "one 32-pixel fragment column per wave");
     constexpr int XL = BP / (NW * 8);                      // DMA instructions per wave and 64-channel sub-tile (1 KiB each)
-    constexpr int SUB = BP * 128;                          // bytes of one sub-tile: 128 pixels x 64 channels
+    constexpr int SUB = BP * 128;                          // bytes of one sub-tile: BP pixels x 64 channels
     constexpr int STAGE = KC * SUB;
     constexpr int CSTR = BC * 2 + 16;
     constexpr int EPI = BP * CSTR + NW * BC * 2 * 4;
-    constexpr int SC = BP * BC * 2 / 16 / (64 * NW);       // row stores per thread and tile (4)
+    constexpr int SC = BP * BC * 2 / 16 / (64 * NW);       // row stores per thread and tile (4 / 2)
     __shared__ __attribute__((aligned(256))) unsigned char smem[NS * STAGE + EPI];
     unsigned char* se = smem + NS * STAGE;
 
@@ -957,7 +964,7 @@ __global__ void __launch_bounds__(512) conv1x1_stream_kernel(ConvArgs a) {
     const int T = a.tpw;
     const int mbase = (logical / a.tiles_c) * T * BP;
 
-    // the wave's 64 weight rows stay in registers for the whole chunk
+    // the wave's BC / WC weight rows stay in registers for the whole chunk
     bf16x8 fa[KC * 4][FI];
 #pragma unroll
     for (int i = 0; i < FI; ++i) {
@@ -1005,24 +1012,26 @@ __global__ void __launch_bounds__(512) conv1x1_stream_kernel(ConvArgs a) {
         for (int ii = 0; ii < FI; ++ii)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ii][0][r] = 0.f;
-        const int rb = wp * (BP / WP) + lrow;
+        const int rb = wp * 32 + lrow;
         const unsigned char* xb = smem + stage * STAGE + rb * 128;
-        bf16x8 fb[KC * 4];
 #pragma unroll
-        for (int kk = 0; kk < KC * 4; ++kk)
-            fb[kk] = *(const bf16x8*)(xb + (kk >> 2) * SUB + ((((kk & 3) * 2 + lk) ^ ((rb >> 1) & 7)) << 4));
+        for (int kt = 0; kt < KC; ++kt) {
+            bf16x8 fb[4];
 #pragma unroll
-        for (int kk = 0; kk < KC * 4; ++kk)
+            for (int kk = 0; kk < 4; ++kk) fb[kk] = *(const bf16x8*)(xb + kt * SUB + (((kk * 2 + lk) ^ ((rb >> 1) & 7)) << 4));
 #pragma unroll
-            for (int ii = 0; ii < FI; ++ii)
-                acc[ii][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][ii], fb[kk], acc[ii][0], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ii = 0; ii < FI; ++ii)
+                    acc[ii][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kt * 4 + kk][ii], fb[kk], acc[ii][0], 0, 0, 0);
+        }
         // (the barrier inside the epilogue, behind its accumulator -> LDS writes, also says: every wave has read its fragments
         // of this stage)
         conv_epilogue<BC, BP, WC, WP, true, KIND>(a, acc, se, mbase + i * BP, c0, s, q, i + 1 == T, blockIdx.x & (NREP - 1), &P);
         // all but the SC youngest memory operations (this tile's row stores) are complete: tile i+1 is in LDS, and the
         // compiler knows the epilogue's loads are done.  vmcnt = SC, expcnt / lgkmcnt untouched (gfx9 encoding)
         __builtin_amdgcn_s_waitcnt(SC | (7 << 4) | (15 << 8));
-        if (i + 2 < T) issue(i + 2, stage);
+        if (i + 2 < T && !(TSKIP(a) & 1)) issue(i + 2, stage);      // (tuning: bit 1 = no DMA inside the loop, timing only)
     }
 #endif
 }
@@ -1339,29 +1348,31 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         int stream_on = 1, wpc = 1;
         if (const char* e = TUNE_ENV("RGDA_STREAM")) stream_on = atoi(e);                   // tuning experiments only
         if (const char* e = TUNE_ENV("RGDA_STREAM_WPC")) wpc = atoi(e);                     // tuning experiments only
-        if (stream_on && kh == 1 && kw == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W && (Cin == 64 || Cin == 128) &&
-            !(Cout & 127) && !(M & 127)) {
+        if (stream_on && kh == 1 && kw == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W &&
+            (Cin == 64 || Cin == 128) && !(Cout & 127)) {
+            const int bp = 128;
             const int tiles_c = Cout / 128;
-            const long long tiles_p = M / 128;
+            const long long tiles_p = M / bp;
             int chunks = (256 * wpc) / tiles_c;
-            while (chunks > 1 && ((tiles_p % chunks) || (a.rows_per_group % (int)(tiles_p / chunks * 128)))) chunks >>= 1;
+            while (chunks > 1 && ((tiles_p % chunks) || (a.rows_per_group % (int)(tiles_p / chunks * bp)))) chunks >>= 1;
             const long long T = chunks >= 1 ? tiles_p / chunks : 0;
-            if (chunks >= 1 && T >= 4 && T <= 4096 && !(tiles_p % chunks) && !(a.rows_per_group % (int)(T * 128))) {
+            if (!(M % bp) && chunks >= 1 && T >= 4 && T <= 4096 && !(tiles_p % chunks) && !(a.rows_per_group % (int)(T * bp))) {
                 a.tiles_c = tiles_c; a.tiles_p = (int)tiles_p; a.tpw = (int)T;
                 const int grid = tiles_c * chunks;
                 // one instantiation per fused epilogue (the choice conv_epilogue makes from the arguments)
                 const int kind = a.ev_rm ? EPI_EV : a.bn_x ? (a.bn_relu == 2 ? EPI_BNX2 : EPI_BNX)
                                : a.res ? (a.stats ? EPI_RES_STATS : EPI_RES) : (a.stats ? EPI_STATS : EPI_PLAIN);
-#define RGDA_STREAM(KC, KIND)                                                                                  \
-    case KIND: RGDA_LAUNCH("conv1x1_stream_kernel<" #KC ", " #KIND ">",                                         \
-                           conv1x1_stream_kernel<KC, KIND><<<grid, 512, 0, st>>>(a)); break
-#define RGDA_STREAM_ALL(KC)                                                                                    \
+#define RGDA_STREAM(KC, BP, WC, WP, KIND)                                                                      \
+    case KIND: RGDA_LAUNCH("conv1x1_stream_kernel<" #KC ", " #BP ", " #WC ", " #WP ", " #KIND ">",              \
+                           conv1x1_stream_kernel<KC, BP, WC, WP, KIND><<<grid, 512, 0, st>>>(a)); break
+#define RGDA_STREAM_ALL(KC, BP, WC, WP)                                                                        \
     switch (kind) {                                                                                            \
-        RGDA_STREAM(KC, 0); RGDA_STREAM(KC, 1); RGDA_STREAM(KC, 2); RGDA_STREAM(KC, 3);                         \
-        RGDA_STREAM(KC, 4); RGDA_STREAM(KC, 5); RGDA_STREAM(KC, 6);                                             \
+        RGDA_STREAM(KC, BP, WC, WP, 0); RGDA_STREAM(KC, BP, WC, WP, 1); RGDA_STREAM(KC, BP, WC, WP, 2);         \
+        RGDA_STREAM(KC, BP, WC, WP, 3); RGDA_STREAM(KC, BP, WC, WP, 4); RGDA_STREAM(KC, BP, WC, WP, 5);         \
+        RGDA_STREAM(KC, BP, WC, WP, 6);                                                                         \
     }
-                if (Cin == 64) { RGDA_STREAM_ALL(1) }
-                else { RGDA_STREAM_ALL(2) }
+                if (Cin == 64) { RGDA_STREAM_ALL(1, 128, 2, 4) }
+                else { RGDA_STREAM_ALL(2, 128, 2, 4) }
 #undef RGDA_STREAM_ALL
 #undef RGDA_STREAM
                 RGDA_CHECK_LAUNCH();

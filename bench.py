@@ -572,6 +572,13 @@ def main():
                            'conv3x3': {'achieved': c3['tflops'], 'frac': c3['tflops'] / MFMA_PEAK_TFLOPS,
                                        'frac_of_sustained': c3['tflops'] / MFMA_SUSTAINED_TFLOPS,
                                        'unit': 'TFLOP/s', 'gflop_per_step': c3['gflop'], 'ms_per_step': c3['ms']},
+                           # the short-K 1x1 convolutions of layers 1 / 2 (conv1x1_stream_kernel, every fused epilogue): HBM-bound
+                           'conv1x1_stream': (lambda ks: None if not ks else {
+                               'achieved': sum(v['algorithmic_mb'] for v in ks) / max(sum(v['ms'] for v in ks), 1e-9),
+                               'frac': sum(v['algorithmic_mb'] for v in ks) / max(sum(v['ms'] for v in ks), 1e-9) / HBM_PEAK_GBPS,
+                               'unit': 'GB/s', 'launches_per_step': sum(v['launches'] for v in ks),
+                               'ms_per_step': sum(v['ms'] for v in ks)})(
+                               [v for k, v in kern.items() if k.startswith('conv1x1_stream_kernel')]),
                            'mfma_sustained_peak': {'value': MFMA_SUSTAINED_TFLOPS, 'unit': 'TFLOP/s',
                                                    'what': 'back-to-back v_mfma_f32_32x32x16_bf16 on N(0,1) operands, no '
                                                            'memory traffic (2440 on zeros); profiles/r02_mfma_ceiling.txt'},

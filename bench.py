@@ -79,7 +79,7 @@ def conv_flops_probe(step_fn, park_ms=150.0):
     rec = []
     import ctypes
     o_conv, o_wgrad, o_bne, o_bnb = ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd
-    o_wgrad_g, o_bnin = ops.conv2d_wgrad_grouped, ops.conv2d_bnin
+    o_wgrad_g, o_bnin, o_conv_g = ops.conv2d_wgrad_grouped, ops.conv2d_bnin, ops.conv2d_grouped
 
     kname = L.raw('rgda_conv2d_kernel')
     wname = L.raw('rgda_conv2d_wgrad_kernel')
@@ -104,6 +104,26 @@ def conv_flops_probe(step_fn, park_ms=150.0):
         extra = (2.0 * M * co if res is not None else 0.0) + (M * co / 8.0 if k.get('res_mask') is not None else 0.0)
         timed('dgrad' if mode else 'fwd', 0, w, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, stats is not None, stat_groups,
               lambda: o_conv(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode, res, stats, stat_groups, **k), extra)
+
+    def conv_grouped(items):
+        # one bracket for the whole list: the library packs the small-tile problems into one launch per eight
+        if not items:
+            return
+        fl = by = 0.0
+        for it in items:
+            x, w, y, N, H, W, Ho, Wo, kh, kw = it[:10]
+            co, taps, ci = w.shape
+            fl += 2.0 * N * Ho * Wo * co * taps * ci
+            by += 2.0 * N * H * W * ci + 2.0 * co * taps * ci + 2.0 * N * Ho * Wo * co + \
+                (2.0 * N * Ho * Wo * co if (len(it) > 14 and it[14] is not None) else 0.0)
+        nl = ops.conv2d_grouped_launches(items)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o_conv_g(items)
+        e1.record()
+        x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil = items[0][:13]
+        rec.append(('conv_igemm_grouped_kernel<128, 64, 3, 2, 2, true>', fl, e0, e1,
+                    ('grouped x%d' % len(items), N * Ho * Wo, w.shape[0], w.shape[2], kh * kw, stride, dil), nl, by, 0.0))
 
     def conv_bnin(bnop, x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, res=None, stats=None, stat_groups=1):
         M, co = N * Ho * Wo, w.shape[0]
@@ -159,7 +179,7 @@ def conv_flops_probe(step_fn, park_ms=150.0):
     def wgrad(*item):
         wgrad_grouped([item])
     ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd = conv, wgrad, conv_bne, conv_bnb
-    ops.conv2d_wgrad_grouped, ops.conv2d_bnin = wgrad_grouped, conv_bnin
+    ops.conv2d_wgrad_grouped, ops.conv2d_bnin, ops.conv2d_grouped = wgrad_grouped, conv_bnin, conv_grouped
     # The wrappers make the host slower than the GPU for the short kernels, and an event pair then also brackets the
     # host's enqueue time between `e0.record()` and the launch.  Park the stream behind a spin kernel long enough for
     # the host to enqueue the whole step first: every bracket then measures queue-to-queue GPU time only.
@@ -182,7 +202,7 @@ def conv_flops_probe(step_fn, park_ms=150.0):
         torch.cuda.synchronize()
     finally:
         ops.conv2d, ops.conv2d_wgrad, ops.conv2d_bneval, ops.conv2d_bnbwd = o_conv, o_wgrad, o_bne, o_bnb
-        ops.conv2d_wgrad_grouped, ops.conv2d_bnin = o_wgrad_g, o_bnin
+        ops.conv2d_wgrad_grouped, ops.conv2d_bnin, ops.conv2d_grouped = o_wgrad_g, o_bnin, o_conv_g
     kern, shapes = {}, {}
     c3 = [0.0, 0.0]                                # FLOPs / ms of the 3x3 convolutions (forward, data and weight gradient)
     for r in rec:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 7
+#define RGDA_ABI_VERSION 8
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore rgda_stat_t[RGDA_STAT_REPLICAS][2][C], zeroed by the caller.
@@ -196,6 +196,20 @@ int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const
                 int ldres, const uint8_t* res_relu_mask, rgda_stat_t* stats, int stat_groups, int N, int H, int W,
                 int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int mode,
                 rgda_stream_t stream);
+
+/* Several INDEPENDENT rgda_conv2d calls as (at most) one launch per eight: a descriptor holds exactly rgda_conv2d's
+ * arguments.  Same results as calling rgda_conv2d on each in turn (no output of one may be an input of another).  Problems
+ * served by the small-tile kernel (conv_igemm_kernel<128, 64, 3, 2, 2, true, false>: what the tiny maps of the PPM branches
+ * get, regda/models/Encoder.py:30-51 -- four scales x two statistics groups, 4 - 36 workgroups each) share launches; any
+ * other is launched on its own.  Every descriptor is validated before anything is launched.
+ * rgda_conv2d_grouped_launches: the number of kernel launches the list makes (negative: the status it would fail with). */
+typedef struct rgda_conv2d_desc {
+    const void* x; const void* wgt; void* y; const void* res; const uint8_t* res_relu_mask; rgda_stat_t* stats;
+    int ldx, ldy, ldres, stat_groups;
+    int N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, mode;
+} rgda_conv2d_desc;
+int rgda_conv2d_grouped(const rgda_conv2d_desc* descs, int n, rgda_stream_t stream);
+int rgda_conv2d_grouped_launches(const rgda_conv2d_desc* descs, int n);
 
 /* Forward conv with an INFERENCE-mode BatchNorm (+ residual + ReLU) folded into the epilogue -- the EMA teacher's
  * conv + BN + ReLU units (regda/models/Encoder.py:152-155 runs the model in eval()):

@@ -17,6 +17,7 @@
 // optional residual add and the per-channel sum / sum-of-squares of BatchNorm folded in.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include <type_traits>
@@ -401,8 +402,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
 // (ConvArgs::xf, common.h: BnOperand): the rows travel global -> registers -> fma / max / bf16 -> ds_write_b128 instead of by
 // LDS-DMA (padding rows are written as zeros: the activation of a padding pixel is 0, not relu(shift)); the weight tiles
 // keep the DMA ring.  Written for the 2-stage ring (two workgroups per CU hide each other's load latency).
-template <int BC, int BP, int STAGES = 3, int WC = 2, int WP = 2, bool PIPE = false, bool XF = false>
-__global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
+// (the body: `bid` = the workgroup's index inside ITS problem -- blockIdx.x for a single launch, blockIdx.x minus the problem's
+// first workgroup for conv_igemm_grouped_kernel)
+template <int BC, int BP, int STAGES, int WC, int WP, bool PIPE, bool XF>
+static __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist in the device pass only
     constexpr int NW = WC * WP;                         // waves per workgroup
     constexpr int FI = BC / WC / 32, FJ = BP / WP / 32;  // 32x32 accumulators per wave
@@ -419,7 +422,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wc = wave % WC, wp = wave / WC;
-    const int logical = xcd_remap(blockIdx.x, a.tiles_c * a.tiles_p);
+    const int logical = xcd_remap(bid, a.tiles_c * a.tiles_p);
     const int c0 = (logical % a.tiles_c) * BC;
     const int m0 = (logical / a.tiles_c) * BP;
     const int taps = a.KH * a.KW;
@@ -718,6 +721,31 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
         TDBG(a)[(gridDim.x + blockIdx.x) * 4 + 0] = twait; TDBG(a)[(gridDim.x + blockIdx.x) * 4 + 1] = tbar;
     }
 #endif
+}
+
+template <int BC, int BP, int STAGES = 3, int WC = 2, int WP = 2, bool PIPE = false, bool XF = false>
+__global__ void __launch_bounds__(64 * WC * WP) conv_igemm_kernel(ConvArgs a) {
+    conv_igemm_body<BC, BP, STAGES, WC, WP, PIPE, XF>(a, blockIdx.x);
+}
+
+// Several INDEPENDENT small convolutions in one launch (rgda_conv2d_grouped): the four scales of a PPM head's branch
+// convolutions are 4 - 36 workgroups each and run 32 - 72 K tiles -- alone on the chip each is a 17 - 35 us latency chain,
+// eight of them in a row 140 us of a head's forward.  The problems' argument blocks travel by value (kernarg, <= 8 x 352 B);
+// a workgroup finds its problem from the prefix of workgroup counts.
+constexpr int CONV_GROUP_MAX = 8;
+struct ConvGroup {
+    ConvArgs a[CONV_GROUP_MAX];
+    int start[CONV_GROUP_MAX + 1];
+    int n;
+};
+static_assert(sizeof(ConvGroup) <= 4096, "kernel arguments");
+template <int BC, int BP, int STAGES, int WC, int WP, bool PIPE>
+__global__ void __launch_bounds__(64 * WC * WP) conv_igemm_grouped_kernel(ConvGroup g) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < CONV_GROUP_MAX; ++i)
+        if (i < g.n && (int)blockIdx.x >= g.start[i]) p = i;
+    conv_igemm_body<BC, BP, STAGES, WC, WP, PIPE, false>(g.a[p], (int)blockIdx.x - g.start[p]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1231,13 +1259,14 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
                          const unsigned char* res_mask, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int kh, int kw, int stride, int pad, int dil, int mode, const BnBwdFuse* bnb,
                          rgda_stream_t stream, const BnEvalFuse* bne = nullptr, const rgda_bn_operand* bnin = nullptr,
-                         const char** sel = nullptr) {
+                         const char** sel = nullptr, ConvArgs* out_args = nullptr) {
     // sel != nullptr: dry run -- *sel = the kernel instantiation that would serve the call (the name rocprofv3 reports),
-    // nothing is launched (rgda_conv2d_kernel; bench.py labels its per-launch timings with it)
-#define RGDA_LAUNCH(NAME, ...)                       \
-    do {                                             \
-        if (sel) { *sel = NAME; return RGDA_OK; }    \
-        __VA_ARGS__;                                 \
+    // nothing is launched (rgda_conv2d_kernel; bench.py labels its per-launch timings with it); out_args: the argument
+    // block that launch would carry (rgda_conv2d_grouped packs several into one launch)
+#define RGDA_LAUNCH(NAME, ...)                                                     \
+    do {                                                                           \
+        if (sel) { *sel = NAME; if (out_args) *out_args = a; return RGDA_OK; }     \
+        __VA_ARGS__;                                                               \
     } while (0)
 #define RGDA_IGEMM(BC, BP, ST, WC, WP, PIPE, XF)                                                                  \
     RGDA_LAUNCH("conv_igemm_kernel<" #BC ", " #BP ", " #ST ", " #WC ", " #WP ", " #PIPE ", " #XF ">",              \
@@ -1431,6 +1460,70 @@ extern "C" const char* rgda_conv2d_kernel(int variant, int N, int H, int W, int 
                                  Wo, Cout, kh, kw, stride, pad, dil, variant == 3 ? 0 : mode, variant == 2 ? &b : nullptr, nullptr,
                                  variant == 1 ? &e : nullptr, variant == 3 ? &o : nullptr, &name);
     return rc == RGDA_OK ? name : nullptr;
+}
+
+static const char* const GROUPED_KERNEL = "conv_igemm_kernel<128, 64, 3, 2, 2, true, false>";
+
+extern "C" int rgda_conv2d_grouped(const rgda_conv2d_desc* descs, int n, rgda_stream_t stream) {
+    if (!descs || n < 0) return RGDA_ERR_ARG;
+    hipStream_t st = to_stream(stream);
+    ConvGroup g;
+    g.n = 0; g.start[0] = 0;
+    auto flush = [&]() -> int {
+        if (g.n == 1) {          // alone: the ordinary launch (same kernel, same argument block)
+            conv_igemm_kernel<128, 64, 3, 2, 2, true, false><<<g.start[1], 256, 0, st>>>(g.a[0]);
+        } else if (g.n > 1) {
+            for (int i = g.n + 1; i <= CONV_GROUP_MAX; ++i) g.start[i] = g.start[g.n];
+            conv_igemm_grouped_kernel<128, 64, 3, 2, 2, true><<<g.start[g.n], 256, 0, st>>>(g);
+        }
+        g.n = 0;
+        RGDA_CHECK_LAUNCH();
+        return RGDA_OK;
+    };
+    // validate everything first: nothing is launched when one descriptor is wrong
+    for (int i = 0; i < n; ++i) {
+        const rgda_conv2d_desc& d = descs[i];
+        const char* name = nullptr;
+        const int rc = conv2d_launch(d.x, d.ldx, d.wgt, d.y, d.ldy, d.res, d.ldres, d.res_relu_mask, (rgda_stat_t*)d.stats,
+                                     d.stat_groups, d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.kh, d.kw, d.stride, d.pad, d.dil,
+                                     d.mode, nullptr, stream, nullptr, nullptr, &name);
+        if (rc != RGDA_OK) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        const rgda_conv2d_desc& d = descs[i];
+        const char* name = nullptr;
+        ConvArgs a;
+        conv2d_launch(d.x, d.ldx, d.wgt, d.y, d.ldy, d.res, d.ldres, d.res_relu_mask, (rgda_stat_t*)d.stats, d.stat_groups, d.N, d.H,
+                      d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.kh, d.kw, d.stride, d.pad, d.dil, d.mode, nullptr, stream, nullptr, nullptr,
+                      &name, &a);
+        if (name && !strcmp(name, GROUPED_KERNEL)) {
+            g.a[g.n] = a;
+            g.start[g.n + 1] = g.start[g.n] + a.tiles_c * a.tiles_p;
+            if (++g.n == CONV_GROUP_MAX) { if (int rc = flush()) return rc; }
+        } else {                 // another kernel serves it: its own launch
+            const int rc = conv2d_launch(d.x, d.ldx, d.wgt, d.y, d.ldy, d.res, d.ldres, d.res_relu_mask, (rgda_stat_t*)d.stats,
+                                         d.stat_groups, d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.kh, d.kw, d.stride, d.pad, d.dil,
+                                         d.mode, nullptr, stream);
+            if (rc != RGDA_OK) return rc;
+        }
+    }
+    return flush();
+}
+
+// how many kernel launches rgda_conv2d_grouped makes of a list, and (name != NULL) whether they all share the grouped kernel
+extern "C" int rgda_conv2d_grouped_launches(const rgda_conv2d_desc* descs, int n) {
+    if (!descs || n < 0) return RGDA_ERR_ARG;
+    int grouped = 0, single = 0;
+    for (int i = 0; i < n; ++i) {
+        const rgda_conv2d_desc& d = descs[i];
+        const char* name = nullptr;
+        const int rc = conv2d_launch(d.x, d.ldx, d.wgt, d.y, d.ldy, d.res, d.ldres, d.res_relu_mask, (rgda_stat_t*)d.stats,
+                                     d.stat_groups, d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.kh, d.kw, d.stride, d.pad, d.dil,
+                                     d.mode, nullptr, nullptr, nullptr, nullptr, &name);
+        if (rc != RGDA_OK) return rc;
+        if (!strcmp(name, GROUPED_KERNEL)) ++grouped; else ++single;
+    }
+    return single + (grouped + CONV_GROUP_MAX - 1) / CONV_GROUP_MAX;
 }
 
 extern "C" int rgda_conv2d(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,

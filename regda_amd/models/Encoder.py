@@ -303,6 +303,7 @@ class Deeplabv2(nn.Module):
         # one-pass sparse maps (rgda_spatial_mix / rgda_spatial_mix_multi), kept as the cross-check
         self.factored_ppm = True
         self.parallel_heads = True       # training forward: the second head on its own stream
+        self.group_small_convs = True    # the PPM branches' small convolutions: the four scales in one launch (rgda_conv2d_grouped)
         self.early_last_flush = True     # layer1's weight gradients start before the stem's backward
         self.fused_stem = True           # conv1 straight from the image where the map width allows it (rgda_stem_conv)
         self.fused_stem_wgrad = True     # ... and its weight gradient too (rgda_stem_wgrad): no patch matrix at all
@@ -669,22 +670,34 @@ class Deeplabv2(nn.Module):
             }
         return self._mat_cache[key]
 
-    def _conv_stats(self, x, w, c, stats, G, N, H, W, Ho, Wo, k, stride, pad, dil, res=None):
+    def _conv_stats(self, x, w, c, stats, G, N, H, W, Ho, Wo, k, stride, pad, dil, res=None, queue=None):
         """Forward conv (+ `res` added in the epilogue, before the statistics) with BatchNorm statistics per row
         group; falls back to one launch per group when the groups are not a multiple of the pixel tile (tiny PPM
-        maps)."""
+        maps).  queue (a list): the launch(es) are appended as ops.conv2d_grouped items instead of being made."""
         if G == 1 or stats is None:
-            ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, res, stats, 1)
+            if queue is not None:
+                queue.append((x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, res, stats, 1))
+            else:
+                ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, res, stats, 1)
             return
+        whole = (x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, res, stats, G)
         try:
-            ops.conv2d(x, w, c, N, H, W, Ho, Wo, k, k, stride, pad, dil, 0, res, stats, G)
+            if queue is not None:
+                ops.conv2d_grouped_launches([whole])        # (validation only: raises where the groups do not tile)
+                queue.append(whole)
+            else:
+                ops.conv2d(*whole)
         except ValueError:
             Ng, C = N // G, c.shape[1]
             st = stats.view(G, -1)
             for g in range(G):
                 ro = slice(g * Ng * Ho * Wo, (g + 1) * Ng * Ho * Wo)
-                ops.conv2d(x[g * Ng * H * W:(g + 1) * Ng * H * W], w, c[ro], Ng, H,
-                           W, Ho, Wo, k, k, stride, pad, dil, 0, None if res is None else res[ro], st[g], 1)
+                part = (x[g * Ng * H * W:(g + 1) * Ng * H * W], w, c[ro], Ng, H, W, Ho, Wo, k, k, stride, pad, dil, 0,
+                        None if res is None else res[ro], st[g], 1)
+                if queue is not None:
+                    queue.append(part)
+                else:
+                    ops.conv2d(*part)
 
     def _materialise(self, T, lz):
         """The ordinary apply pass for a deferred unit whose consumer has no operand-transform kernel."""
@@ -708,7 +721,8 @@ class Deeplabv2(nn.Module):
         T['keep'].append(bnop)
         return bnop
 
-    def _cbr_fwd(self, T, key, conv, bn, x, N, H, W, relu, res=None, nscale=None, wb=None, geom=None, defer=False):
+    def _cbr_fwd(self, T, key, conv, bn, x, N, H, W, relu, res=None, nscale=None, wb=None, geom=None, defer=False,
+                 preconv=None):
         """conv + BatchNorm (+ residual + ReLU) unit.  `x` may be a deferred unit (_Lazy): its BatchNorm + ReLU then runs on
         this convolution's operand path.  defer=True (training only): return this unit deferred in turn."""
         Ho, Wo = conv.out_hw(H, W) if geom is None else geom
@@ -725,8 +739,11 @@ class Deeplabv2(nn.Module):
             return y, Ho, Wo
         if M // G < 2:
             raise ValueError('Expected more than 1 value per channel when training')
-        c = torch.empty(M, conv.co, dtype=BF, device=self.device)
-        stats = T['stats_pool'].take(G * NREP * 2 * conv.co) if train else None
+        if preconv is not None:        # the convolution (with its statistics) was launched by the caller, grouped with others
+            c, stats = preconv
+        else:
+            c = torch.empty(M, conv.co, dtype=BF, device=self.device)
+            stats = T['stats_pool'].take(G * NREP * 2 * conv.co) if train else None
         if isinstance(x, _Lazy):
             if geom is None and ops.conv2d_bnin_supported(M, conv.co, conv.ci, conv.k, conv.k, conv.stride, conv.pad,
                                                           conv.dil, H, W, Ho, Wo, G) >= self.bn_operand_level:
@@ -734,7 +751,7 @@ class Deeplabv2(nn.Module):
                                 conv.k, conv.stride, conv.pad, conv.dil, None, stats, G)
             else:
                 x = self._materialise(T, x)
-        if not isinstance(x, _Lazy):
+        if not isinstance(x, _Lazy) and preconv is None:
             if geom is None:
                 self._conv_stats(x, conv.wb if wb is None else wb, c, stats, G, N, H, W, Ho, Wo, conv.k, conv.stride,
                                  conv.pad, conv.dil)
@@ -766,11 +783,16 @@ class Deeplabv2(nn.Module):
         dev = self.device
         HW, M = h * w, N * h * w
         mats = self._mats(h, w)
-        zs = []
+        zs, queue = [], []
         for i, s in enumerate(POOL_SCALES):
             z = torch.empty(N * s * s, 9 * 512, dtype=BF, device=dev)
-            ops.conv2d(qs[i], hw['wz'][i], z, N, s, s, s, s, 1, 1, 1, 0, 1)
+            queue.append((qs[i], hw['wz'][i], z, N, s, s, s, s, 1, 1, 1, 0, 1))
             zs.append(z.view(N * s * s * 9, 512))
+        if self.group_small_convs:
+            ops.conv2d_grouped(queue)           # the four scales' Z = q W^T in one launch
+        else:
+            for it in queue:
+                ops.conv2d(*it)
         ppm = torch.empty(M, 512, dtype=BF, device=dev)
         if self.factored_ppm:       # V @ Z as the y map (gather from the four Z_s) then the x map (LDS-staged rows)
             fm = self._ppm_maps(h, w)
@@ -826,6 +848,7 @@ class Deeplabv2(nn.Module):
             ops.group_mix(dc, fm['Wx'], rows, N * h, fm['R'], w, 512)
             dzs = [torch.empty(N * s * s * 9, 512, dtype=BF, device=dev) for s in POOL_SCALES]
             ops.sparse_mix([rows], fm['bwd'], dzs, N, 512)
+        queue = []
         for i, s in enumerate(POOL_SCALES):
             if self.factored_ppm:
                 dz = dzs[i]
@@ -834,11 +857,18 @@ class Deeplabv2(nn.Module):
                 ops.spatial_mix(dc, mats[s][5], dz, N, 9 * s * s, HW, 512)
             dzr = dz.view(N * s * s, 9 * 512)
             dq = torch.empty(N * s * s, 512, dtype=BF, device=dev)
-            ops.conv2d(dzr, hw['wzt'][i], dq, N, s, s, s, s, 1, 1, 1, 0, 1)
+            # dq_i = dZ_i W_i: K = 4608 on 1 - 9 pixel tiles (72 K tiles on 4 - 36 workgroups, 35 us each alone): the four
+            # scales share one launch
+            if self.group_small_convs:
+                queue.append((dzr, hw['wzt'][i], dq, N, s, s, s, s, 1, 1, 1, 0, 1))
+            else:
+                ops.conv2d(dzr, hw['wzt'][i], dq, N, s, s, s, s, 1, 1, 1, 0, 1)
             # nine stacked 1x1 filters (rows tap * 512 + co) written channel-major into [co][tap][2048 + 512 i ...]
             T['wgrad_pending'].append((qs[i], dzr, gview[:, :, 2048 + 512 * i: 2048 + 512 * (i + 1)], N, s, s, s, s, 1, 1, 1, 0, 1))
             T['keep'].append((dz, dq))
             dqs.append(dq)
+        if queue:
+            ops.conv2d_grouped(queue)
         T['keep'].append((dc, dfeat))
         if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
             self._flush_wgrads(T)
@@ -915,7 +945,7 @@ class Deeplabv2(nn.Module):
             T['on_progress'](offset)
 
     def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False,
-                 consumer=None, dx_res_mask=None):
+                 consumer=None, dx_res_mask=None, conv_queue=None):
         """Backward of one conv+BN(+ReLU) unit.  `consumer` = (tape key, relu) of the unit that will consume this
         unit's data gradient: its BN-backward reduction is then folded into our data-gradient conv's epilogue.
         `dx_res` (+ optional ReLU sign mask gating it) is added to the data gradient in the same epilogue."""
@@ -986,8 +1016,12 @@ class Deeplabv2(nn.Module):
                 except ValueError:          # row groups do not tile (tiny maps): plain conv, standalone reduction
                     T['presums:' + ckey] = csums
             if not fused:
-                ops.conv2d(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil, 1,
-                           dx_res, None, res_mask=dx_res_mask)
+                if conv_queue is not None:      # launched by the caller, grouped with its siblings (ops.conv2d_grouped)
+                    conv_queue.append((dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil, 1,
+                                       dx_res, None, 1, dx_res_mask))
+                else:
+                    ops.conv2d(dc, conv.wtb, dx, N, Ho, Wo, H, W, conv.k, conv.k, conv.stride, conv.pad, conv.dil, 1,
+                               dx_res, None, res_mask=dx_res_mask)
         return dx, gm
 
     def _stem_fwd(self, T, xs, Ng, H, W, H1, W1, main_stream):
@@ -1167,9 +1201,22 @@ class Deeplabv2(nn.Module):
         for hi, head in enumerate(('layer5', 'layer6')):
             with (ops.use_stream(hs) if (hs is not None and hi == 1) else contextlib.nullcontext()):
                 qs = []
+                pre = [None] * len(POOL_SCALES)
+                if T is not None and self.group_small_convs:
+                    # the four branch convolutions (2048 -> 512 on s x s maps, one problem per scale and statistics group:
+                    # 4 - 20 workgroups each, 32 K tiles) in ONE launch instead of eight in a row
+                    queue = []
+                    for i, s in enumerate(POOL_SCALES):
+                        cv = C[f'{head}.ppm.{i}.1']
+                        cc = torch.empty(N * s * s, cv.co, dtype=BF, device=dev)
+                        st = T['stats_pool'].take(T['groups'] * NREP * 2 * cv.co)
+                        self._conv_stats(pooled_all[i], cv.wb, cc, st, T['groups'], N, s, s, s, s, cv.k, cv.stride, cv.pad,
+                                         cv.dil, queue=queue)
+                        pre[i] = (cc, st)
+                    ops.conv2d_grouped(queue)
                 for i, s in enumerate(POOL_SCALES):
                     q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
-                                            pooled_all[i], N, s, s, True)
+                                            pooled_all[i], N, s, s, True, preconv=pre[i])
                     qs.append(q)
                     if dbg is not None:
                         dbg[f'{head}.q{i}'] = q.float().reshape(N, s, s, -1).permute(0, 3, 1, 2)
@@ -1226,10 +1273,13 @@ class Deeplabv2(nn.Module):
             dfeat, dqs = self._head_last_bwd(T, head, dh, dfeat)
             if dbg is not None:
                 dbg[head + '.hidden'] = nchw(dh, h, w)
+            queue = [] if self.group_small_convs else None
             for i, s in enumerate(POOL_SCALES):
                 # ... and so are the gradients of the shared pooled maps
                 dpools[i], _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
-                                             dqs[i], True, dx_res=dpools[i])
+                                             dqs[i], True, dx_res=dpools[i], conv_queue=queue)
+            if queue:
+                ops.conv2d_grouped(queue)       # the four scales' 512 -> 2048 data gradients in one launch
         if self.head_kind == 'ppm':
             gpool = torch.empty(M, 2048, dtype=BF, device=dev)
             if self.factored_ppm:

@@ -344,6 +344,48 @@ def conv2d(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, mode=0, res=None,
                pad, dil, mode, _stream())
 
 
+class _ConvDesc(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ('x', 'wgt', 'y', 'res', 'res_relu_mask', 'stats')] + \
+               [(k, ctypes.c_int) for k in ('ldx', 'ldy', 'ldres', 'stat_groups', 'N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'kh',
+                                            'kw', 'stride', 'pad', 'dil', 'mode')]
+
+
+def _conv_descs(items):
+    arr = (_ConvDesc * len(items))()
+    for d, it in zip(arr, items):
+        x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil = it[:13]
+        mode = it[13] if len(it) > 13 else 0
+        res = it[14] if len(it) > 14 else None
+        stats = it[15] if len(it) > 15 else None
+        stat_groups = it[16] if len(it) > 16 else 1
+        res_mask = it[17] if len(it) > 17 else None
+        Cout, taps, Cin = w.shape
+        assert taps == kh * kw and x.shape[1] == Cin and y.shape[1] == Cout
+        d.x, d.wgt, d.y, d.res, d.res_relu_mask, d.stats = x.data_ptr(), w.data_ptr(), y.data_ptr(), _p(res), _p(res_mask), _stat(stats)
+        d.ldx, d.ldy, d.ldres, d.stat_groups = _ld(x), _ld(y), (_ld(res) if res is not None else 0), stat_groups
+        d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = N, H, W, Cin, Ho, Wo, Cout
+        d.kh, d.kw, d.stride, d.pad, d.dil, d.mode = kh, kw, stride, pad, dil, mode
+    return arr
+
+
+def conv2d_grouped(items):
+    """items: list of tuples holding conv2d's arguments (x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil[, mode[, res[, stats
+    [, stat_groups[, res_mask]]]]]) -- INDEPENDENT convolutions; the small-tile ones share launches (rgda_conv2d_grouped)."""
+    if not items:
+        return
+    arr = _conv_descs(items)
+    lib().call('rgda_conv2d_grouped', ctypes.cast(arr, ctypes.c_void_p), len(items), _stream())
+
+
+def conv2d_grouped_launches(items):
+    """Kernel launches conv2d_grouped(items) makes; raises where it would fail."""
+    arr = _conv_descs(items)
+    n = lib().size('rgda_conv2d_grouped_launches', ctypes.cast(arr, ctypes.c_void_p), len(items))
+    if n < 0:
+        raise ValueError('rgda_conv2d_grouped: status %d' % n)
+    return n
+
+
 def conv2d_bneval(x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, rm, rv, gamma, beta, relu, res=None, eps=1e-5):
     """conv + inference-mode BN (+ residual + ReLU) in one kernel (the EMA teacher's units)."""
     Cout, taps, Cin = w.shape

@@ -1148,3 +1148,69 @@ def test_maxpool_with_batchnorm_relu_on_the_operand_path(ops):
     y2, idx2 = torch.zeros_like(y), torch.zeros_like(idx)
     ops.maxpool_fwd(act, y2, idx2, N, H, W, C, Ho, Wo)
     assert torch.equal(y2, y) and torch.equal(idx2, idx)
+
+
+def test_grouped_small_convolutions_equal_the_single_launches(ops):
+    """rgda_conv2d_grouped: the PPM branches' problems -- 2048 -> 512 on s x s maps per statistics group, 512 -> 4608,
+    4608 -> 512 and the 512 -> 2048 data gradients with a residual -- in shared launches: bit-identical outputs AND
+    accumulators to one rgda_conv2d each (same kernel, same tiles); a problem that another kernel serves rides along as its
+    own launch; sixteen small problems make two launches."""
+    g = torch.Generator().manual_seed(91)
+    N = 16
+
+    def mk(M, C):
+        return (torch.randn(M, C, generator=g) * 0.5).to(BF).cuda()
+
+    def wt(Co, Ci):
+        return (torch.randn(Co, 1, Ci, generator=g) * 0.05).to(BF).cuda()
+    items, refs = [], []
+    for s_ in (1, 2, 3, 6):                                # branch convolutions: one problem per scale and statistics group
+        for grp in range(2):
+            Ng = N // 2
+            x, w = mk(Ng * s_ * s_, 2048), wt(512, 2048)
+            items.append([x, w, None, Ng, s_, s_, s_, s_, 1, 1, 1, 0, 1, 0, None, 'stats', 1])
+    for s_ in (1, 2, 3, 6):                                # Z = q W^T
+        items.append([mk(N * s_ * s_, 512), wt(4608, 512), None, N, s_, s_, s_, s_, 1, 1, 1, 0, 1])
+    for s_ in (1, 6):                                      # dq = dZ W (K = 4608) and a data gradient with a residual
+        items.append([mk(N * s_ * s_, 4608), wt(512, 4608), None, N, s_, s_, s_, s_, 1, 1, 1, 0, 1])
+        items.append([mk(N * s_ * s_, 512), wt(2048, 512), None, N, s_, s_, s_, s_, 1, 1, 1, 0, 1, 1, mk(N * s_ * s_, 2048)])
+    items.append([mk(4 * 32 * 32, 256), wt(1024, 256), None, 4, 32, 32, 32, 32, 1, 1, 1, 0, 1])      # a large one: own launch
+    outs_a, outs_b, st_a, st_b = [], [], [], []
+    a_items, b_items = [], []
+    for it in items:
+        M, Co = it[3] * it[6] * it[7], it[1].shape[0]
+        ya, yb = torch.zeros(M, Co, dtype=BF, device='cuda'), torch.zeros(M, Co, dtype=BF, device='cuda')
+        ia, ib = list(it), list(it)
+        ia[2], ib[2] = ya, yb
+        if len(it) > 15 and it[15] == 'stats':
+            sa, sb = ops.new_stats(1, 8, 2, Co), ops.new_stats(1, 8, 2, Co)
+            ia[15], ib[15] = sa, sb
+            st_a.append(sa); st_b.append(sb)
+        outs_a.append(ya); outs_b.append(yb)
+        a_items.append(tuple(ia)); b_items.append(tuple(ib))
+    assert ops.conv2d_grouped_launches(a_items) == 1 + 2      # 16 small problems in two launches + the large one on its own
+    ops.conv2d_grouped(a_items)
+    for it in b_items:
+        kw = {}
+        ops.conv2d(*it[:13], *(it[13:17] if len(it) > 13 else ()))
+    torch.cuda.synchronize()
+    for i, (ya, yb) in enumerate(zip(outs_a, outs_b)):
+        assert torch.equal(ya, yb), i
+        assert float(ya.float().abs().sum()) > 0
+    for sa, sb in zip(st_a, st_b):       # (a workgroup's replica is its XCD: the partials land in other replicas, the totals agree)
+        assert torch.equal(sa.sum(1), sb.sum(1)) and int(sa.sum(1).abs().sum()) > 0
+    # against fp32 on the same operands (first and last small problem)
+    for it, y in ((a_items[0], outs_a[0]), (a_items[15], outs_a[15])):
+        ref = it[0].float() @ it[1].float().view(it[1].shape[0], -1).t()
+        if len(it) > 14 and it[14] is not None:
+            ref = ref + it[14].float()
+        assert relerr(y.float().cpu(), ref.cpu()) < 6e-3
+    # a wrong descriptor: nothing is launched
+    bad = list(a_items[0]); bad[3] = 0
+    y0 = outs_a[1].clone()
+    outs_a[1].zero_()
+    with pytest.raises(ValueError):
+        ops.conv2d_grouped([a_items[1], tuple(bad)])
+    torch.cuda.synchronize()
+    assert float(outs_a[1].float().abs().sum()) == 0.0 and float(y0.float().abs().sum()) > 0
+    ops.conv2d_grouped([])

@@ -167,11 +167,13 @@ def test_layerwise_backward_consistency():
     m.load_state_dict(omodel.init_state_dict(rt, 6, seed=2), strict=True)
     m.train()
     m.wgrad_group_gflop = 0.0       # one weight-gradient launch per layer, so the spy sees each layer's dW at once
+    m.group_small_convs = False     # ... and every data gradient when its unit returns (not queued for a grouped launch)
     rec = []
     orig = E.Deeplabv2._cbr_bwd
 
     def spy(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False, consumer=None,
-            dx_res_mask=None):
+            dx_res_mask=None, conv_queue=None):
+        assert conv_queue is None
         x, c, y, mi, dims, nscale, rmask = T[key]
         g0 = conv.g.clone()
         dg0, db0 = bn.dgamma.clone(), bn.dbeta.clone()
@@ -289,6 +291,36 @@ def test_relu_sign_mask_mode_gives_identical_gradients():
     ga, gb = out[0][2], out[1][2]
     cos = (ga @ gb / (ga.norm() * gb.norm())).item()
     assert cos > 0.99 and abs(gb.norm().item() / ga.norm().item() - 1) < 0.03
+
+
+def test_grouped_small_convolutions_give_identical_bits():
+    """group_small_convs: the PPM branches' convolutions in shared launches (rgda_conv2d_grouped) run the same kernel over the
+    same tiles as one launch each -- logits, features and every gradient are BIT-identical (the fixed-point BatchNorm
+    statistics land in other replicas, their totals are the same integers), at one and at two statistics groups."""
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=4)
+    gen = torch.Generator().manual_seed(21)
+    x = [torch.randn(2, 3, 64, 64, generator=gen).cuda(), torch.randn(2, 3, 64, 64, generator=gen).cuda()]
+    g1, g2 = torch.randn(4, 6, 4, 4, generator=gen).cuda(), torch.randn(4, 6, 4, 4, generator=gen).cuda()
+    ones = torch.ones(2, 512)
+    for groups in (2, 1):
+        out = []
+        for flag in (True, False):
+            m = build(rt)
+            m.group_small_convs = flag
+            m.load_state_dict(sd, strict=True)
+            m.train()
+            m.set_drop_masks(ones, ones)
+            m.flat_g.zero_()
+            T = m.new_tape(groups=groups)
+            with torch.no_grad():
+                c1, c2, f = m._forward_plan(x if groups == 2 else torch.cat(x), T)
+                m._backward_plan(T, g1, g2)
+            torch.cuda.synchronize()
+            out.append((c1.clone(), c2.clone(), f.clone(), m.flat_g.clone()))
+        for a, b in zip(*out):
+            assert torch.equal(a, b)
+        assert float(out[0][3].abs().sum()) > 0
 
 
 def test_factored_ppm_maps_match_the_one_pass_maps():

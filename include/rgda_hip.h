@@ -383,6 +383,28 @@ int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy, const uint
                       int ldgm, float* dgamma, float* dbeta, int64_t M, int C, int relu, const float* beta,
                       void* act_out, int ldact, int groups, rgda_stream_t stream);
 
+/* BatchNorm of SMALL maps, several layers per launch (the PPM branches' conv -> BatchNorm -> ReLU on s x s maps,
+ * regda/models/Encoder.py:30-51; nn.BatchNorm2d in train mode per statistics group, as rgda_bn_train_apply /
+ * rgda_bn_bwd_reduce + rgda_bn_bwd_apply).  One workgroup owns 128 channels of one layer and all of its rows: it forms the
+ * statistics itself -- sums of the stored bf16 values in a fixed order -- and applies them; up to eight descriptors share a
+ * launch.  M = all rows (groups * rows per group), rows per group in [2, 320] forward, <= 320 backward (a workgroup keeps
+ * its rows in registers); larger maps take the general entry points.
+ * Forward: y = [relu]((x - mean) * invstd * gamma + beta), mi[groups][2][C] = (mean, invstd), running statistics updated
+ * group after group, num_batches_tracked += groups, relu_mask (optional) = sign bits of y.
+ * Backward: dx, dgamma += , dbeta += (atomic adds, as rgda_bn_bwd_apply); the ReLU gate from relu_mask or y. */
+typedef struct rgda_bn_small_fwd_desc {
+    const void* x; void* y; uint8_t* relu_mask; const float* gamma; const float* beta; float* mi;
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    int64_t M; int ldx, ldy, C, groups, relu; float eps, momentum;
+} rgda_bn_small_fwd_desc;
+typedef struct rgda_bn_small_bwd_desc {
+    const void* g; const void* y; const uint8_t* relu_mask; const void* x; void* dx; const float* mi; const float* gamma;
+    float* dgamma; float* dbeta;
+    int64_t M; int ldg, ldy, ldx, lddx, C, groups, relu;
+} rgda_bn_small_bwd_desc;
+int rgda_bn_train_small(const rgda_bn_small_fwd_desc* descs, int n, rgda_stream_t stream);
+int rgda_bn_bwd_small(const rgda_bn_small_bwd_desc* descs, int n, rgda_stream_t stream);
+
 /* MaxPool2d(3,2,1) on PxC bf16 (regda/_resnets.py:153); idx = argmax tap (uint8). */
 int rgda_maxpool_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho,
                      int Wo, rgda_stream_t stream);

@@ -637,6 +637,360 @@ extern "C" int rgda_bn_bwd_apply(const void* g, int ldg, const void* y, int ldy,
     return RGDA_OK;
 }
 
+// ------------------------------------------------------------------ BatchNorm of SMALL maps, several layers per launch
+// The PPM branches (regda/models/Encoder.py:30-51): conv -> BatchNorm -> ReLU on s x s maps, s = 1, 2, 3, 6 -- 8 to 288 rows
+// per statistics group and 512 channels.  As the general kernels these are 4 forward launches and 8 backward launches per
+// head of 6 - 8 us each, every one a statistics hand-off through memory for a tensor of a few hundred rows.  Here ONE
+// workgroup owns 64 channels of one layer and ALL of its rows: it forms the statistics itself (fixed summation order: run
+// to run identical), applies them, and up to eight layers share a launch.  Same formulas as the general kernels
+// (var = E[x^2] - mean^2 in double, invstd in fp32, y = (x - mean) * (invstd * gamma) + beta; dx = gamma * invstd *
+// (g' - mean(g') - xhat * mean(g' xhat))); the statistics are sums of the STORED bf16 values, as the convolution epilogue's are.
+constexpr int BN_SMALL_MAX = 8;
+struct BnSmallFwd {
+    const bf16_t* x; bf16_t* y; uint8_t* mask_out;
+    const float* gamma; const float* beta; float* mi; float* rm; float* rv; long long* nbt;
+    int ldx, ldy, M /* rows of one group */, C, groups, relu;
+    float eps, mom;
+};
+struct BnSmallBwd {
+    const bf16_t* g; const bf16_t* y; const uint8_t* rmask; const bf16_t* x; bf16_t* dx;
+    const float* mi; const float* gamma; float* dgamma; float* dbeta;
+    int ldg, ldy, ldx, lddx, M /* rows of one group */, C, groups, relu;
+};
+template <class A> struct BnSmallGroup { A a[BN_SMALL_MAX]; int start[BN_SMALL_MAX + 1]; int n; };
+
+// A workgroup is 512 threads = 8 channel vectors (64 channels) x 64 row lanes and keeps ITS rows in registers (packed bf16,
+// BN_SMALL_RPT rows per thread and group, TWO groups at a time, every load in flight at once): memory is read once, the
+// statistics and the apply both run from registers, and the per-channel parameters are fetched next to the rows -- one
+// memory round trip in front of the reduction, none behind it.  (First form: 256 threads walking the rows 16 at a time,
+// twice, group after group: 45 / 59 us per launch, a chain of ~100 dependent load round trips for the 6 x 6 maps; rows in
+// registers but group after group with the parameters loaded behind the reduction: 28 us.)
+constexpr int BN_SMALL_RPT = 5;                         // rows per thread: 64 x 5 = 320 rows of one group
+constexpr int BN_SMALL_LANES = 64;                      // row lanes
+constexpr int BN_SMALL_CV = 8;                          // channel vectors (of 8 channels) per workgroup
+constexpr int BN_SMALL_NT = BN_SMALL_CV * BN_SMALL_LANES, BN_SMALL_WAVES = BN_SMALL_NT / 64;
+constexpr int BN_SMALL_ROWS = BN_SMALL_LANES * BN_SMALL_RPT;
+constexpr int BN_SMALL_GP = 2;                          // groups resident at a time
+
+// totals of this thread's eight channels over the row lanes: the eight row lanes of a wave by three fixed shuffles, then
+// the waves through LDS, every thread summing in wave order.  NP planes at once (one barrier pair for all of them).
+template <int NP>
+static __device__ __forceinline__ void small_totals(float (*red)[BN_SMALL_WAVES][BN_SMALL_CV * 8], float (&v)[NP][8], int cvl,
+                                                    int wave, int lane) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[p][e];
+            x += __shfl_xor(x, 8, 64);
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            v[p][e] = x;
+        }
+    __syncthreads();                    // the previous pass's readers are done
+    if (lane < BN_SMALL_CV) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[p][wave][cvl * 8 + e] = v[p][e];
+    }
+    __syncthreads();
+}
+// (the totals stay in LDS and are summed where they are used: 2 x groups x 8 doubles per thread held in registers next to
+// the resident rows made both kernels spill)
+static __device__ __forceinline__ double small_total(float (*red)[BN_SMALL_WAVES][BN_SMALL_CV * 8], int plane, int c) {
+    double x = 0.0;
+#pragma unroll
+    for (int l = 0; l < BN_SMALL_WAVES; ++l) x += (double)red[plane][l][c];
+    return x;
+}
+
+__global__ void __launch_bounds__(BN_SMALL_NT) bn_small_fwd_kernel(BnSmallGroup<BnSmallFwd> G) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < BN_SMALL_MAX; ++i)
+        if (i < G.n && (int)blockIdx.x >= G.start[i]) p = i;
+    const BnSmallFwd& a = G.a[p];
+    const int cb = (int)blockIdx.x - G.start[p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cvl = threadIdx.x & (BN_SMALL_CV - 1), rl = threadIdx.x / BN_SMALL_CV;
+    const int cg = (cb * BN_SMALL_CV + cvl) * 8;
+    const bool cok = cg < a.C;
+    __shared__ float red[2 * BN_SMALL_GP][BN_SMALL_WAVES][BN_SMALL_CV * 8];
+    const int C = a.C, M = a.M;
+    float run_m[8], run_v[8], gam[8], bet[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        run_m[e] = (cok && a.rm) ? a.rm[cg + e] : 0.f; run_v[e] = (cok && a.rm) ? a.rv[cg + e] : 0.f;
+        gam[e] = cok ? a.gamma[cg + e] : 0.f; bet[e] = cok ? a.beta[cg + e] : 0.f;
+    }
+    const float unb = (M > 1) ? (float)M / (float)(M - 1) : 1.f;
+    const double invMd = 1.0 / (double)M;       // (as the general kernels: sums times 1 / M)
+    for (int g0 = 0; g0 < a.groups; g0 += BN_SMALL_GP) {
+        u16x8 xv[BN_SMALL_GP][BN_SMALL_RPT];
+#pragma unroll
+        for (int gi = 0; gi < BN_SMALL_GP; ++gi)
+#pragma unroll
+            for (int u = 0; u < BN_SMALL_RPT; ++u) {
+                const int r = rl + BN_SMALL_LANES * u;
+                if (cok && g0 + gi < a.groups && r < M) xv[gi][u] = *(const u16x8*)(a.x + (unsigned)(((g0 + gi) * M + r) * a.ldx + cg));
+            }
+        float sq[2 * BN_SMALL_GP][8];
+#pragma unroll
+        for (int gi = 0; gi < BN_SMALL_GP; ++gi) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sq[2 * gi][e] = 0.f; sq[2 * gi + 1][e] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < BN_SMALL_RPT; ++u) {
+                if (cok && g0 + gi < a.groups && rl + BN_SMALL_LANES * u < M) {
+                    float f[8];
+                    cvt8(xv[gi][u], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sq[2 * gi][e] += f[e]; sq[2 * gi + 1][e] += f[e] * f[e]; }
+                }
+            }
+        }
+        small_totals<2 * BN_SMALL_GP>(red, sq, cvl, wave, lane);
+        if (!cok) continue;
+#pragma unroll
+        for (int gi = 0; gi < BN_SMALL_GP; ++gi)
+#pragma unroll
+            for (int u = 0; u < BN_SMALL_RPT; ++u) asm volatile("" : "+v"(xv[gi][u]));      // (re-converted below, not kept as floats)
+#pragma unroll
+        for (int gi = 0; gi < BN_SMALL_GP; ++gi) {
+            const int grp = g0 + gi;
+            if (grp >= a.groups) break;
+            float mean[8], sc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double m = small_total(red, 2 * gi, cvl * 8 + e) * invMd;
+                double v = small_total(red, 2 * gi + 1, cvl * 8 + e) * invMd - m * m;
+                if (v < 0.0) v = 0.0;
+                const float is = 1.f / sqrtf((float)v + a.eps);
+                mean[e] = (float)m;
+                sc[e] = is * gam[e];
+                run_m[e] = (1.f - a.mom) * run_m[e] + a.mom * (float)m;
+                run_v[e] = (1.f - a.mom) * run_v[e] + a.mom * (float)v * unb;
+                if (rl == 0) { a.mi[(size_t)grp * 2 * C + cg + e] = (float)m; a.mi[(size_t)grp * 2 * C + C + cg + e] = is; }
+            }
+#pragma unroll
+            for (int u = 0; u < BN_SMALL_RPT; ++u) {
+                const int r = rl + BN_SMALL_LANES * u;
+                if (r >= M) break;
+                float f[8];
+                cvt8(xv[gi][u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[e] = (f[e] - mean[e]) * sc[e] + bet[e];
+                    if (a.relu) f[e] = fmaxf(f[e], 0.f);
+                }
+                uint4 pk;
+                pk.x = pack2bf(f[0], f[1]); pk.y = pack2bf(f[2], f[3]); pk.z = pack2bf(f[4], f[5]); pk.w = pack2bf(f[6], f[7]);
+                const int rr = grp * M + r;
+                *(uint4*)(a.y + (unsigned)(rr * a.ldy + cg)) = pk;
+                if (a.mask_out) a.mask_out[(unsigned)(rr * (C >> 3) + (cg >> 3))] = relu_bits(pk);
+            }
+        }
+    }
+    if (cok && rl == 0 && a.rm) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a.rm[cg + e] = run_m[e]; a.rv[cg + e] = run_v[e]; }
+    }
+    if (cb == 0 && threadIdx.x == 0 && a.nbt) *a.nbt += a.groups;
+}
+
+// USE_Y: the ReLU gate is read from y (one more resident row set) instead of from the sign mask
+template <bool USE_Y>
+__global__ void __launch_bounds__(BN_SMALL_NT) bn_small_bwd_kernel(BnSmallGroup<BnSmallBwd> G) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < BN_SMALL_MAX; ++i)
+        if (i < G.n && (int)blockIdx.x >= G.start[i]) p = i;
+    const BnSmallBwd& a = G.a[p];
+    const int cb = (int)blockIdx.x - G.start[p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cvl = threadIdx.x & (BN_SMALL_CV - 1), rl = threadIdx.x / BN_SMALL_CV;
+    const int cg = (cb * BN_SMALL_CV + cvl) * 8;
+    const bool cok = cg < a.C;
+    __shared__ float red[2 * BN_SMALL_GP][BN_SMALL_WAVES][BN_SMALL_CV * 8];
+    const int C = a.C, M = a.M;
+    float dg[8] = {0}, db[8] = {0}, gam[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gam[e] = cok ? a.gamma[cg + e] : 0.f;
+    for (int g0 = 0; g0 < a.groups; g0 += BN_SMALL_GP) {
+        float mean[BN_SMALL_GP][8], istd[BN_SMALL_GP][8];
+        u16x8 gv[BN_SMALL_GP][BN_SMALL_RPT], xv[BN_SMALL_GP][BN_SMALL_RPT], yv[USE_Y ? BN_SMALL_GP : 1][USE_Y ? BN_SMALL_RPT : 1];
+        unsigned mb[BN_SMALL_GP][BN_SMALL_RPT];
+#pragma unroll
+        for (int gi = 0; gi < BN_SMALL_GP; ++gi) {
+            const bool gok = cok && g0 + gi < a.groups;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mean[gi][e] = gok ? a.mi[(size_t)(g0 + gi) * 2 * C + cg + e] : 0.f;
+                istd[gi][e] = gok ? a.mi[(size_t)(g0 + gi) * 2 * C + C + cg + e] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < BN_SMALL_RPT; ++u) {
+                const int r = (g0 + gi) * M + rl + BN_SMALL_LANES * u;      // (32-bit offsets: a small map)
+                mb[gi][u] = 0xffu;
+                if (gok && rl + BN_SMALL_LANES * u < M) {
+                    gv[gi][u] = *(const u16x8*)(a.g + (unsigned)(r * a.ldg + cg));
+                    xv[gi][u] = *(const u16x8*)(a.x + (unsigned)(r * a.ldx + cg));
+                    if (a.relu) {
+                        if constexpr (USE_Y) yv[gi][u] = *(const u16x8*)(a.y + (unsigned)(r * a.ldy + cg));
+                        else mb[gi][u] = a.rmask[(unsigned)(r * (C >> 3) + (cg >> 3))];
+                    }
+                }
+            }
+        }
+        auto row = [&](int gi, int u, float (&gf)[8], float (&xh)[8]) {       // g' and xhat of a register row
+            float xf[8];
+            cvt8(gv[gi][u], gf);
+            cvt8(xv[gi][u], xf);
+            if constexpr (USE_Y) {
+                if (a.relu) {
+                    float yf[8];
+                    cvt8(yv[gi][u], yf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gf[e] = (yf[e] > 0.f) ? gf[e] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gf[e] = ((mb[gi][u] >> e) & 1u) ? gf[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xh[e] = (xf[e] - mean[gi][e]) * istd[gi][e];
+        };
+        float sq[2 * BN_SMALL_GP][8];
+#pragma unroll
+        for (int gi = 0; gi < BN_SMALL_GP; ++gi) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sq[2 * gi][e] = 0.f; sq[2 * gi + 1][e] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < BN_SMALL_RPT; ++u) {
+                if (cok && g0 + gi < a.groups && rl + BN_SMALL_LANES * u < M) {
+                    float gf[8], xh[8];
+                    row(gi, u, gf, xh);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sq[2 * gi][e] += gf[e]; sq[2 * gi + 1][e] += gf[e] * xh[e]; }
+                }
+            }
+        }
+        small_totals<2 * BN_SMALL_GP>(red, sq, cvl, wave, lane);
+        if (!cok) continue;
+        // the apply RE-converts the packed rows: left to common-subexpression elimination, the 2 x 5 x 16 floats of the
+        // first pass stay live across the reduction and the kernel spills
+#pragma unroll
+        for (int gi = 0; gi < BN_SMALL_GP; ++gi)
+#pragma unroll
+            for (int u = 0; u < BN_SMALL_RPT; ++u) asm volatile("" : "+v"(gv[gi][u]), "+v"(xv[gi][u]));
+        const float invM = 1.f / (float)M;
+#pragma unroll
+        for (int gi = 0; gi < BN_SMALL_GP; ++gi) {
+            if (g0 + gi >= a.groups) break;
+            float k0[8], k1[8], k2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t1 = (float)small_total(red, 2 * gi, cvl * 8 + e), t2 = (float)small_total(red, 2 * gi + 1, cvl * 8 + e);
+                k0[e] = gam[e] * istd[gi][e];
+                k1[e] = t1 * invM;
+                k2[e] = t2 * invM;
+                db[e] += t1;
+                dg[e] += t2;
+            }
+#pragma unroll
+            for (int u = 0; u < BN_SMALL_RPT; ++u) {
+                if (rl + BN_SMALL_LANES * u >= M) break;
+                float gf[8], xh[8], o[8];
+                row(gi, u, gf, xh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = k0[e] * (gf[e] - k1[e] - xh[e] * k2[e]);
+                store8(a.dx + (unsigned)(((g0 + gi) * M + rl + BN_SMALL_LANES * u) * a.lddx + cg), o);
+            }
+        }
+    }
+    if (cok && rl == 0 && a.dgamma) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(a.dgamma + cg + e, dg[e]); atomicAdd(a.dbeta + cg + e, db[e]); }
+    }
+}
+
+// rows of one group the small kernels accept (BN_SMALL_LANES row lanes x BN_SMALL_RPT rows in registers)
+#define RGDA_BN_SMALL_MAX_ROWS BN_SMALL_ROWS
+
+extern "C" int rgda_bn_train_small(const rgda_bn_small_fwd_desc* descs, int n, rgda_stream_t stream) {
+    if (!descs || n < 0) return RGDA_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        const rgda_bn_small_fwd_desc& d = descs[i];
+        if (!d.x || !d.y || !d.gamma || !d.beta || !d.mi || d.M <= 0 || d.C <= 0 || (d.C & 7) || (d.ldx & 7) || (d.ldy & 7) ||
+            d.ldx < d.C || d.ldy < d.C || d.groups < 1 || d.groups > 8 || (d.M % d.groups) || d.M / d.groups < 2 ||
+            d.M / d.groups > RGDA_BN_SMALL_MAX_ROWS || (d.relu_mask && !d.relu) || d.M * (int64_t)(d.ldx > d.ldy ? d.ldx : d.ldy) >= (1ll << 31) ||
+            ((d.running_mean == nullptr) != (d.running_var == nullptr)))
+            return RGDA_ERR_ARG;
+    }
+    for (int i0 = 0; i0 < n; i0 += BN_SMALL_MAX) {
+        BnSmallGroup<BnSmallFwd> G;
+        G.n = (n - i0 < BN_SMALL_MAX) ? n - i0 : BN_SMALL_MAX;
+        G.start[0] = 0;
+        for (int i = 0; i < BN_SMALL_MAX; ++i) {
+            if (i < G.n) {
+                const rgda_bn_small_fwd_desc& d = descs[i0 + i];
+                BnSmallFwd& a = G.a[i];
+                a.x = (const bf16_t*)d.x; a.y = (bf16_t*)d.y; a.mask_out = d.relu_mask; a.gamma = d.gamma; a.beta = d.beta;
+                a.mi = d.mi; a.rm = d.running_mean; a.rv = d.running_var; a.nbt = (long long*)d.num_batches_tracked;
+                a.ldx = d.ldx; a.ldy = d.ldy; a.M = (int)(d.M / d.groups); a.C = d.C; a.groups = d.groups; a.relu = d.relu;
+                a.eps = d.eps; a.mom = d.momentum;
+                G.start[i + 1] = G.start[i] + cdiv(d.C, BN_SMALL_CV * 8);
+            } else {
+                G.start[i + 1] = G.start[i];
+            }
+        }
+        bn_small_fwd_kernel<<<G.start[G.n], BN_SMALL_NT, 0, to_stream(stream)>>>(G);
+        RGDA_CHECK_LAUNCH();
+    }
+    return RGDA_OK;
+}
+
+extern "C" int rgda_bn_bwd_small(const rgda_bn_small_bwd_desc* descs, int n, rgda_stream_t stream) {
+    if (!descs || n < 0) return RGDA_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        const rgda_bn_small_bwd_desc& d = descs[i];
+        if (!d.g || !d.x || !d.dx || !d.mi || !d.gamma || (d.relu && !d.y && !d.relu_mask) || d.relu < 0 || d.relu > 1 || d.M <= 0 ||
+            d.C <= 0 || (d.C & 7) || (d.ldg & 7) || (d.ldx & 7) || (d.lddx & 7) || (d.y && (d.ldy & 7)) || d.groups < 1 ||
+            d.groups > 8 || (d.M % d.groups) || d.M / d.groups > RGDA_BN_SMALL_MAX_ROWS ||
+            d.M * (int64_t)(d.ldg > d.ldx ? (d.ldg > d.lddx ? d.ldg : d.lddx) : (d.ldx > d.lddx ? d.ldx : d.lddx)) >= (1ll << 31) ||
+            ((d.dgamma == nullptr) != (d.dbeta == nullptr)))
+            return RGDA_ERR_ARG;
+    }
+    // the gate's source is a compile-time variant: descriptors that read y and descriptors that read the mask go to separate launches
+    for (int use_y = 0; use_y < 2; ++use_y) {
+        BnSmallGroup<BnSmallBwd> G;
+        G.n = 0; G.start[0] = 0;
+        auto flush = [&]() -> int {
+            if (!G.n) return RGDA_OK;
+            for (int i = G.n; i < BN_SMALL_MAX; ++i) G.start[i + 1] = G.start[G.n];
+            if (use_y) bn_small_bwd_kernel<true><<<G.start[G.n], BN_SMALL_NT, 0, to_stream(stream)>>>(G);
+            else bn_small_bwd_kernel<false><<<G.start[G.n], BN_SMALL_NT, 0, to_stream(stream)>>>(G);
+            G.n = 0;
+            RGDA_CHECK_LAUNCH();
+            return RGDA_OK;
+        };
+        for (int i = 0; i < n; ++i) {
+            const rgda_bn_small_bwd_desc& d = descs[i];
+            if ((d.relu && !d.relu_mask) != (use_y != 0)) continue;
+            BnSmallBwd& a = G.a[G.n];
+            a.g = (const bf16_t*)d.g; a.y = (const bf16_t*)d.y; a.rmask = d.relu_mask; a.x = (const bf16_t*)d.x;
+            a.dx = (bf16_t*)d.dx; a.mi = d.mi; a.gamma = d.gamma; a.dgamma = d.dgamma; a.dbeta = d.dbeta;
+            a.ldg = d.ldg; a.ldy = d.ldy; a.ldx = d.ldx; a.lddx = d.lddx; a.M = (int)(d.M / d.groups); a.C = d.C;
+            a.groups = d.groups; a.relu = d.relu;
+            G.start[G.n + 1] = G.start[G.n] + cdiv(d.C, BN_SMALL_CV * 8);
+            if (++G.n == BN_SMALL_MAX) { if (int rc = flush()) return rc; }
+        }
+        if (int rc = flush()) return rc;
+    }
+    return RGDA_OK;
+}
+
 // ------------------------------------------------------------------ MaxPool 3x3 / 2 / pad 1
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho,

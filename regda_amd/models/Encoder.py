@@ -304,6 +304,7 @@ class Deeplabv2(nn.Module):
         self.factored_ppm = True
         self.parallel_heads = True       # training forward: the second head on its own stream
         self.group_small_convs = True    # the PPM branches' small convolutions: the four scales in one launch (rgda_conv2d_grouped)
+        self.small_bn = True             # ... and their BatchNorms: statistics + apply / reduce + apply of the four scales in one launch
         self.early_last_flush = True     # layer1's weight gradients start before the stem's backward
         self.fused_stem = True           # conv1 straight from the image where the map width allows it (rgda_stem_conv)
         self.fused_stem_wgrad = True     # ... and its weight gradient too (rgda_stem_wgrad): no patch matrix at all
@@ -945,7 +946,7 @@ class Deeplabv2(nn.Module):
             T['on_progress'](offset)
 
     def _cbr_bwd(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False,
-                 consumer=None, dx_res_mask=None, conv_queue=None):
+                 consumer=None, dx_res_mask=None, conv_queue=None, bn_queue=None):
         """Backward of one conv+BN(+ReLU) unit.  `consumer` = (tape key, relu) of the unit that will consume this
         unit's data gradient: its BN-backward reduction is then folded into our data-gradient conv's epilogue.
         `dx_res` (+ optional ReLU sign mask gating it) is added to the data gradient in the same epilogue."""
@@ -958,18 +959,25 @@ class Deeplabv2(nn.Module):
         if from_x:
             rmask = None
         sums = T.pop('sums:' + key, None)
-        if sums is None:
-            sums = T.pop('presums:' + key, None)        # arena slice reserved by a producer that could not fuse
-            if sums is None:
-                sums = T['sums_pool'].take(G * NREP * 2 * C)
-            ops.bn_bwd_reduce(g, y if (rl == 1 and rmask is None) else None, c, mi, sums, M, C, rl, nscale, Ho * Wo,
-                              groups=G, relu_mask=rmask, gamma=bn.gamma, beta=bn.beta)
+        deferred = T.pop('wgrad_deferred:' + key, None)
         dc = torch.empty(M, C, dtype=BF, device=self.device)
         gm = torch.empty(M, C, dtype=BF, device=self.device) if want_gmask else None
-        deferred = T.pop('wgrad_deferred:' + key, None)
         act = torch.empty(M, C, dtype=BF, device=self.device) if deferred is not None else None
-        ops.bn_bwd_apply(g, y if (rl == 1 and rmask is None) else None, c, mi, bn.gamma, sums, dc, M, C, rl, gm,
-                         bn.dgamma, bn.dbeta, nscale, Ho * Wo, groups=G, relu_mask=rmask, beta=bn.beta, act_out=act)
+        if (bn_queue is not None and conv_queue is not None and sums is None and rl != 2 and nscale is None and not want_gmask
+                and deferred is None and M // G <= ops.BN_SMALL_MAX_ROWS and ('presums:' + key) not in T):
+            # a small map: reduce + apply in one workgroup per 128 channels, launched by the caller together with its
+            # siblings (ops.bn_bwd_small) -- and before the data gradients it queues in conv_queue
+            bn_queue.append((g, y if (rl == 1 and rmask is None) else None, c, mi, bn.gamma, dc, bn.dgamma, bn.dbeta, M, C,
+                             rl, G, rmask))
+        else:
+            if sums is None:
+                sums = T.pop('presums:' + key, None)        # arena slice reserved by a producer that could not fuse
+                if sums is None:
+                    sums = T['sums_pool'].take(G * NREP * 2 * C)
+                ops.bn_bwd_reduce(g, y if (rl == 1 and rmask is None) else None, c, mi, sums, M, C, rl, nscale, Ho * Wo,
+                                  groups=G, relu_mask=rmask, gamma=bn.gamma, beta=bn.beta)
+            ops.bn_bwd_apply(g, y if (rl == 1 and rmask is None) else None, c, mi, bn.gamma, sums, dc, M, C, rl, gm,
+                             bn.dgamma, bn.dbeta, nscale, Ho * Wo, groups=G, relu_mask=rmask, beta=bn.beta, act_out=act)
         if deferred is not None:        # the consumer's weight gradient: its operand exists from here on
             ddc, dg, geom, flop = deferred
             T['wgrad_pending'].append((act, ddc, dg) + geom)
@@ -1202,7 +1210,29 @@ class Deeplabv2(nn.Module):
             with (ops.use_stream(hs) if (hs is not None and hi == 1) else contextlib.nullcontext()):
                 qs = []
                 pre = [None] * len(POOL_SCALES)
-                if T is not None and self.group_small_convs:
+                G = T['groups'] if T is not None else 1
+                small = (T is not None and self.group_small_convs and self.small_bn and
+                         all(2 <= N * s * s // G <= ops.BN_SMALL_MAX_ROWS for s in POOL_SCALES))
+                if small:
+                    # conv -> BatchNorm -> ReLU of the four branches (s x s maps): ONE launch for the four 2048 -> 512
+                    # convolutions and one for the four BatchNorms, which sum the stored values themselves (no per-group
+                    # convolution problems, no accumulators)
+                    queue, bnq = [], []
+                    for i, s in enumerate(POOL_SCALES):
+                        cv, bn = C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2']
+                        Ms = N * s * s
+                        cc = torch.empty(Ms, cv.co, dtype=BF, device=dev)
+                        y = torch.empty(Ms, cv.co, dtype=BF, device=dev)
+                        mi = torch.empty(G, 2, cv.co, device=dev)
+                        rmask = (torch.empty(Ms, cv.co // 8, dtype=torch.uint8, device=dev)
+                                 if (self.relu_sign_mask and cv.co >= self.relu_sign_mask) else None)
+                        queue.append((pooled_all[i], cv.wb, cc, N, s, s, s, s, cv.k, cv.k, cv.stride, cv.pad, cv.dil))
+                        bnq.append((cc, y, mi, bn.rm, bn.rv, bn.nbt, bn.gamma, bn.beta, Ms, cv.co, True, G, rmask))
+                        T[f'{head}.ppm{i}'] = (pooled_all[i], cc, y, mi, (N, s, s, s, s), None, rmask)
+                        qs.append(y)
+                    ops.conv2d_grouped(queue)
+                    ops.bn_train_small(bnq)
+                elif T is not None and self.group_small_convs:
                     # the four branch convolutions (2048 -> 512 on s x s maps, one problem per scale and statistics group:
                     # 4 - 20 workgroups each, 32 K tiles) in ONE launch instead of eight in a row
                     queue = []
@@ -1215,9 +1245,12 @@ class Deeplabv2(nn.Module):
                         pre[i] = (cc, st)
                     ops.conv2d_grouped(queue)
                 for i, s in enumerate(POOL_SCALES):
-                    q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
-                                            pooled_all[i], N, s, s, True, preconv=pre[i])
-                    qs.append(q)
+                    if small:
+                        q = qs[i]
+                    else:
+                        q, _, _ = self._cbr_fwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
+                                                pooled_all[i], N, s, s, True, preconv=pre[i])
+                        qs.append(q)
                     if dbg is not None:
                         dbg[f'{head}.q{i}'] = q.float().reshape(N, s, s, -1).permute(0, 3, 1, 2)
                 hid = self._head_last_fwd(T, head, xn, qs, N, h, w, masks[hi])
@@ -1274,10 +1307,13 @@ class Deeplabv2(nn.Module):
             if dbg is not None:
                 dbg[head + '.hidden'] = nchw(dh, h, w)
             queue = [] if self.group_small_convs else None
+            bnq = [] if (self.group_small_convs and self.small_bn) else None
             for i, s in enumerate(POOL_SCALES):
                 # ... and so are the gradients of the shared pooled maps
                 dpools[i], _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
-                                             dqs[i], True, dx_res=dpools[i], conv_queue=queue)
+                                             dqs[i], True, dx_res=dpools[i], conv_queue=queue, bn_queue=bnq)
+            if bnq:
+                ops.bn_bwd_small(bnq)           # the four scales' BatchNorm backward (reduce + apply) in one launch
             if queue:
                 ops.conv2d_grouped(queue)       # the four scales' 512 -> 2048 data gradients in one launch
         if self.head_kind == 'ppm':

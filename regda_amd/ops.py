@@ -573,6 +573,48 @@ def bn_bwd_apply(g, y, x, mi, gamma, sums, dx, M, C, relu, gmask=None, dgamma=No
                _p(act_out), _ld(act_out) if act_out is not None else 0, groups, _stream())
 
 
+class _BnSmallFwd(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ('x', 'y', 'relu_mask', 'gamma', 'beta', 'mi', 'running_mean', 'running_var',
+                                               'num_batches_tracked')] + [('M', ctypes.c_int64)] + \
+               [(k, ctypes.c_int) for k in ('ldx', 'ldy', 'C', 'groups', 'relu')] + [('eps', ctypes.c_float), ('momentum', ctypes.c_float)]
+
+
+class _BnSmallBwd(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ('g', 'y', 'relu_mask', 'x', 'dx', 'mi', 'gamma', 'dgamma', 'dbeta')] + \
+               [('M', ctypes.c_int64)] + [(k, ctypes.c_int) for k in ('ldg', 'ldy', 'ldx', 'lddx', 'C', 'groups', 'relu')]
+
+
+BN_SMALL_MAX_ROWS = 320         # rows of one statistics group the small-map BatchNorm kernels take (include/rgda_hip.h)
+
+
+def bn_train_small(items, eps=1e-5, momentum=0.1):
+    """Train-mode BatchNorm (+ ReLU) of several SMALL maps in one launch (rgda_bn_train_small).  items: (x, y, mi, rm, rv, nbt,
+    gamma, beta, M, C, relu, groups, relu_mask) -- the tensors of bn_train_apply, without the convolution's accumulators (the
+    kernel sums the stored values itself)."""
+    if not items:
+        return
+    arr = (_BnSmallFwd * len(items))()
+    for d, (x, y, mi, rm, rv, nbt, gamma, beta, M, C, relu, groups, rmask) in zip(arr, items):
+        d.x, d.y, d.relu_mask, d.gamma, d.beta, d.mi = x.data_ptr(), y.data_ptr(), _p(rmask), gamma.data_ptr(), beta.data_ptr(), mi.data_ptr()
+        d.running_mean, d.running_var, d.num_batches_tracked = _p(rm), _p(rv), _p(nbt)
+        d.M, d.ldx, d.ldy, d.C, d.groups, d.relu, d.eps, d.momentum = M, _ld(x), _ld(y), C, groups, int(bool(relu)), eps, momentum
+    lib().call('rgda_bn_train_small', ctypes.cast(arr, ctypes.c_void_p), len(items), _stream())
+
+
+def bn_bwd_small(items):
+    """BatchNorm backward (reduce + apply) of several SMALL maps in one launch (rgda_bn_bwd_small).  items: (g, y, x, mi, gamma,
+    dx, dgamma, dbeta, M, C, relu, groups, relu_mask)."""
+    if not items:
+        return
+    arr = (_BnSmallBwd * len(items))()
+    for d, (g, y, x, mi, gamma, dx, dgamma, dbeta, M, C, relu, groups, rmask) in zip(arr, items):
+        d.g, d.y, d.relu_mask, d.x, d.dx, d.mi, d.gamma = g.data_ptr(), _p(y), _p(rmask), x.data_ptr(), dx.data_ptr(), mi.data_ptr(), gamma.data_ptr()
+        d.dgamma, d.dbeta = _p(dgamma), _p(dbeta)
+        d.M, d.ldg, d.ldy, d.ldx, d.lddx = M, _ld(g), (_ld(y) if y is not None else 0), _ld(x), _ld(dx)
+        d.C, d.groups, d.relu = C, groups, int(bool(relu))
+    lib().call('rgda_bn_bwd_small', ctypes.cast(arr, ctypes.c_void_p), len(items), _stream())
+
+
 def maxpool_fwd(x, y, idx, N, H, W, C, Ho, Wo):
     lib().call('rgda_maxpool_fwd', x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, H, W, C, Ho, Wo, _stream())
 

@@ -1214,3 +1214,83 @@ def test_grouped_small_convolutions_equal_the_single_launches(ops):
     torch.cuda.synchronize()
     assert float(outs_a[1].float().abs().sum()) == 0.0 and float(y0.float().abs().sum()) > 0
     ops.conv2d_grouped([])
+
+
+def test_small_map_batchnorm_several_layers_per_launch(ops):
+    """rgda_bn_train_small / rgda_bn_bwd_small: the PPM branches' BatchNorm + ReLU on s x s maps (8 - 288 rows per
+    statistics group), four scales per launch -- against torch autograd per group in fp32 on the same bf16 inputs, and
+    against the general kernels (statistics from the accumulators, reduce + apply); C = 72 leaves a partial channel block,
+    ten layers make two launches, strided views on both sides."""
+    g = torch.Generator().manual_seed(44)
+    N, G = 16, 2
+    cases = [(s_, 512) for s_ in (1, 2, 3, 6)] + [(2, 72), (3, 1024)] + [(1, 512)] * 4
+    fwd, bwd, keep = [], [], []
+    for li, (s_, C) in enumerate(cases):
+        M = N * s_ * s_
+        xw = (torch.randn(M, C + 8, generator=g) * 1.5 + 0.3).to(BF).cuda()
+        x = xw[:, :C] if li % 2 else xw[:, :C].contiguous()
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+        rm, rv, nbt = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+        y = torch.zeros(M, C, dtype=BF, device='cuda')
+        mi = torch.zeros(G, 2, C, device='cuda')
+        use_mask = li % 3 != 0
+        mask = torch.zeros(M, C // 8, dtype=torch.uint8, device='cuda') if use_mask else None
+        go = (torch.randn(M, C, generator=g)).to(BF).cuda()
+        dx = torch.zeros(M, C, dtype=BF, device='cuda')
+        dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+        fwd.append((x, y, mi, rm, rv, nbt, gamma, beta, M, C, True, G, mask))
+        bwd.append((go, None if use_mask else y, x, mi, gamma, dx, dgam, dbet, M, C, True, G, mask))
+        keep.append((xw, x, gamma, beta, rm, rv, nbt, y, mi, mask, go, dx, dgam, dbet, M, C))
+    ops.bn_train_small(fwd)
+    ops.bn_bwd_small(bwd)
+    torch.cuda.synchronize()
+    for li, (xw, x, gamma, beta, rm, rv, nbt, y, mi, mask, go, dx, dgam, dbet, M, C) in enumerate(keep):
+        Mg = M // G
+        xr = x.float().cpu().view(G, Mg, C).clone().requires_grad_(True)
+        gr, br = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+        rm2, rv2 = torch.zeros(C), torch.ones(C)
+        outs = [F.relu(F.batch_norm(xr[gi].t().reshape(1, C, Mg), rm2, rv2, gr, br, True, 0.1, 1e-5)) for gi in range(G)]
+        yref = torch.cat([o.reshape(C, Mg).t() for o in outs], 0)
+        yref.backward(go.float().cpu())
+        assert relerr(y.float().cpu(), yref.detach()) < 1e-2, li
+        torch.testing.assert_close(rm.cpu(), rm2, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(rv.cpu(), rv2, rtol=2e-4, atol=2e-5)
+        assert int(nbt) == G
+        torch.testing.assert_close(mi[:, 0].cpu(), xr.detach().mean(1), rtol=1e-4, atol=1e-5)
+        if mask is not None:
+            assert torch.equal(unpack_mask(mask, C), (y > 0).cpu())
+        # the gradient: tolerance of the general kernels' test (bf16 output, fp32 sums in another order)
+        assert relerr(dx.float().cpu(), xr.grad.reshape(M, C)) < 2e-2, li
+        assert relerr(dgam.cpu(), gr.grad) < 1e-2 and relerr(dbet.cpu(), br.grad) < 1e-2
+        # ... and against the general kernels on the same tensors
+        st = ops.new_stats(G, 8, 2, C)
+        xc = x.contiguous()
+        ops.bn_stats(xc[:Mg], st[0], Mg, C)
+        ops.bn_stats(xc[Mg:], st[1], Mg, C)
+        mi2 = torch.empty(G, 2, C, device='cuda')
+        y2 = torch.empty(M, C, dtype=BF, device='cuda')
+        rm3, rv3, nbt3 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda')
+        ops.bn_train_apply(xc, st, mi2, rm3, rv3, nbt3, gamma, beta, y2, M, C, True, None, None, 1, groups=G)
+        torch.testing.assert_close(mi, mi2, rtol=1e-5, atol=1e-6)
+        assert (y.float() - y2.float()).abs().max().item() <= 2 * 2.0 ** -8 * max(1.0, y2.float().abs().max().item())
+        torch.testing.assert_close(rm, rm3, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv, rv3, rtol=1e-5, atol=1e-6)
+    # two runs: identical bits (fixed summation order, no atomics but the parameter-gradient adds of ONE workgroup each)
+    y_first = [k[7].clone() for k in keep]
+    dx_first = [k[11].clone() for k in keep]
+    for k in keep:
+        k[4].zero_(); k[5].fill_(1.0); k[6].zero_(); k[12].zero_(); k[13].zero_()
+    ops.bn_train_small(fwd)
+    ops.bn_bwd_small(bwd)
+    torch.cuda.synchronize()
+    for k, y0, d0 in zip(keep, y_first, dx_first):
+        assert torch.equal(k[7], y0) and torch.equal(k[11], d0)
+    # argument checks: one row per group, too many rows
+    x1 = torch.zeros(2, 64, dtype=BF, device='cuda')
+    with pytest.raises(ValueError):
+        ops.bn_train_small([(x1, x1.clone(), torch.zeros(2, 2, 64, device='cuda'), None, None, None, torch.ones(64, device='cuda'),
+                             torch.zeros(64, device='cuda'), 2, 64, True, 2, None)])
+    big = torch.zeros(2 * 328, 64, dtype=BF, device='cuda')
+    with pytest.raises(ValueError):
+        ops.bn_train_small([(big, big.clone(), torch.zeros(2, 2, 64, device='cuda'), None, None, None, torch.ones(64, device='cuda'),
+                             torch.zeros(64, device='cuda'), 2 * 328, 64, True, 2, None)])

@@ -172,8 +172,8 @@ def test_layerwise_backward_consistency():
     orig = E.Deeplabv2._cbr_bwd
 
     def spy(self, T, key, conv, bn, g, relu, need_dx=True, want_gmask=False, dx_res=None, stem=False, consumer=None,
-            dx_res_mask=None, conv_queue=None):
-        assert conv_queue is None
+            dx_res_mask=None, conv_queue=None, bn_queue=None):
+        assert conv_queue is None and bn_queue is None
         x, c, y, mi, dims, nscale, rmask = T[key]
         g0 = conv.g.clone()
         dg0, db0 = bn.dgamma.clone(), bn.dbeta.clone()
@@ -308,6 +308,7 @@ def test_grouped_small_convolutions_give_identical_bits():
         for flag in (True, False):
             m = build(rt)
             m.group_small_convs = flag
+            m.small_bn = False              # (the small-map BatchNorm kernels sum in another order: next test)
             m.load_state_dict(sd, strict=True)
             m.train()
             m.set_drop_masks(ones, ones)
@@ -321,6 +322,40 @@ def test_grouped_small_convolutions_give_identical_bits():
         for a, b in zip(*out):
             assert torch.equal(a, b)
         assert float(out[0][3].abs().sum()) > 0
+
+
+def test_small_map_batchnorm_path_matches_the_general_kernels():
+    """small_bn: the PPM branches' BatchNorms through rgda_bn_train_small / rgda_bn_bwd_small (statistics summed by the
+    kernel itself from the stored values) against the general path (accumulators of the convolution epilogue, reduce +
+    apply): same logits and gradients up to the rounding of another summation order, running statistics included."""
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=4)
+    gen = torch.Generator().manual_seed(22)
+    x = [torch.randn(2, 3, 64, 64, generator=gen).cuda(), torch.randn(2, 3, 64, 64, generator=gen).cuda()]
+    g1, g2 = torch.randn(4, 6, 4, 4, generator=gen).cuda(), torch.randn(4, 6, 4, 4, generator=gen).cuda()
+    ones = torch.ones(2, 512)
+    out = []
+    for flag in (True, False):
+        m = build(rt)
+        m.small_bn = flag
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        m.set_drop_masks(ones, ones)
+        m.flat_g.zero_()
+        T = m.new_tape(groups=2)
+        with torch.no_grad():
+            c1, c2, f = m._forward_plan(x, T)
+            m._backward_plan(T, g1, g2)
+        torch.cuda.synchronize()
+        bnb = {k: v.clone() for k, v in m.state_dict().items() if 'ppm' in k and ('running' in k or 'num_batches' in k)}
+        out.append((c1.clone(), c2.clone(), m.flat_g.clone(), bnb))
+    (a1, a2, ga, ba), (b1, b2, gb, bb) = out
+    assert l2(a1, b1) < 5e-3 and l2(a2, b2) < 5e-3
+    cos = (ga @ gb / (ga.norm() * gb.norm())).item()
+    assert cos > 0.999 and ga.norm().item() == pytest.approx(gb.norm().item(), rel=5e-3)
+    assert len(ba) >= 8 * 3
+    for k in ba:
+        torch.testing.assert_close(ba[k].float(), bb[k].float(), rtol=1e-4, atol=1e-6, msg=k)
 
 
 def test_factored_ppm_maps_match_the_one_pass_maps():

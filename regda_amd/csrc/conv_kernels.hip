@@ -1378,7 +1378,8 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         if (const char* e = TUNE_ENV("RGDA_STREAM")) stream_on = atoi(e);                   // tuning experiments only
         if (const char* e = TUNE_ENV("RGDA_STREAM_WPC")) wpc = atoi(e);                     // tuning experiments only
         if (stream_on && kh == 1 && kw == 1 && stride == 1 && pad == 0 && Ho == H && Wo == W &&
-            (Cin == 64 || Cin == 128) && !(Cout & 127) && M >= 4 * 128 && !(M & 127)) {
+            (Cin == 64 || Cin == 128) && !(Cout & 127) && M >= 4 * 128 && !(M & 127) &&
+            (long long)M * ldx * 2 < (1ll << 31)) {            // (32-bit byte offsets into the pixel operand)
             const int bp = 128;
             const int tiles_c = Cout / 128;
             const long long tiles_p = M / bp;

@@ -305,6 +305,7 @@ class Deeplabv2(nn.Module):
         self.parallel_heads = True       # training forward: the second head on its own stream
         self.group_small_convs = True    # the PPM branches' small convolutions: the four scales in one launch (rgda_conv2d_grouped)
         self.small_bn = True             # ... and their BatchNorms: statistics + apply / reduce + apply of the four scales in one launch
+        self.parallel_tails = True       # backward: the PPM half of a head on the head stream, under the other head's convolution
         self.early_last_flush = True     # layer1's weight gradients start before the stem's backward
         self.fused_stem = True           # conv1 straight from the image where the map width allows it (rgda_stem_conv)
         self.fused_stem_wgrad = True     # ... and its weight gradient too (rgda_stem_wgrad): no patch matrix at all
@@ -819,10 +820,11 @@ class Deeplabv2(nn.Module):
             ops.bn_apply(c, mi, bn.gamma, bn.beta, y, M, 512, True, None, nscale, HW, groups=G)
         return y
 
-    def _head_last_bwd(self, T, head, g, dfeat_prev):
+    def _head_last_bwd(self, T, head, g, dfeat_prev, tail=True):
         """Backward of _head_last_fwd: BN backward, then dW / dX of the feature half as an ordinary 3x3 conv over 2048
         channels and, per PPM branch, dZ_i = V_i^T @ dc (a pooling with the tap-shifted bilinear weights),
-        dq_i = dZ_i W_i and dW_i = dZ_i^T q_i at s x s resolution.  Returns (dfeat [M,2048], [dq_i])."""
+        dq_i = dZ_i W_i and dW_i = dZ_i^T q_i at s x s resolution.  Returns (dfeat [M,2048], [dq_i]); tail=False: the
+        feature half only -> (dfeat, dc), the caller runs _head_last_bwd_tail."""
         C, B = self.convs, self.bns
         conv, bn = C[f'{head}.conv_last.0'], B[f'{head}.conv_last.1']
         hw = self.head_w[head]
@@ -842,6 +844,23 @@ class Deeplabv2(nn.Module):
         T['wgrad_pending_flop'] += 2.0 * M * 512 * 2048 * 9
         dfeat = torch.empty(M, 2048, dtype=BF, device=dev)
         ops.conv2d(dc, conv.wtb[:2048], dfeat, N, h, w, h, w, 3, 3, 1, 1, 1, 1, dfeat_prev, None)
+        T['keep'].append((dc, dfeat))
+        if tail:
+            return dfeat, self._head_last_bwd_tail(T, head, dc)
+        return dfeat, dc
+
+    def _head_last_bwd_tail(self, T, head, dc):
+        """The PPM half of _head_last_bwd: dZ_i = V_i^T dc, dq_i = dZ_i W_i, dW_i queued -> [dq_i].  A dozen launches of at
+        most 113 workgroups: with `parallel_tails` they run on the head stream under the other head's convolution."""
+        C = self.convs
+        conv = C[f'{head}.conv_last.0']
+        hw = self.head_w[head]
+        dev = self.device
+        xn, c, y, mi, (N, h, w, _, _), nscale, _ = T[f'{head}.last']
+        qs = T[f'{head}.last.q']
+        HW = h * w
+        mats = self._mats(h, w)
+        gview = conv.g.view(512, 9, 4096)
         dqs = []
         if self.factored_ppm:       # V^T @ dc: the x map once for all scales, then one y map per scale
             fm = self._ppm_maps(h, w)
@@ -870,10 +889,7 @@ class Deeplabv2(nn.Module):
             dqs.append(dq)
         if queue:
             ops.conv2d_grouped(queue)
-        T['keep'].append((dc, dfeat))
-        if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
-            self._flush_wgrads(T)
-        return dfeat, dqs
+        return dqs
 
     def _aspp_fwd(self, T, xn, N, h, w):
         """Both Classifier_Module heads (Encoder.py:80-84): one 1x1 convolution for all 2 x 4 x 9 taps, then the
@@ -1290,6 +1306,11 @@ class Deeplabv2(nn.Module):
         dfeat = None
         dpools = [None] * len(POOL_SCALES)
         dbg = getattr(self, '_debug_grads', None)
+        tail_stream, tail_wgrads = None, []
+        if self.head_kind == 'ppm' and self.parallel_heads and self.parallel_tails and T.get('wgrad_stream') is not None:
+            if self._head_stream is None:
+                self._head_stream = torch.cuda.Stream(device=dev)
+            tail_stream = self._head_stream
 
         def nchw(t, hh, ww):
             return t.float().reshape(N, hh, ww, -1).permute(0, 3, 1, 2)
@@ -1303,19 +1324,47 @@ class Deeplabv2(nn.Module):
             ops.classifier_bwd(hid, cl.w.view(cl.co, cl.ci), gl, dh, cl.g.view(cl.co, cl.ci),
                                cl.gbias, N, HW, 512, self.num_classes)
             # the second head's feature gradient is added onto the first head's in the conv epilogue
-            dfeat, dqs = self._head_last_bwd(T, head, dh, dfeat)
+            dfeat, dc_head = self._head_last_bwd(T, head, dh, dfeat, tail=False)
             if dbg is not None:
                 dbg[head + '.hidden'] = nchw(dh, h, w)
-            queue = [] if self.group_small_convs else None
-            bnq = [] if (self.group_small_convs and self.small_bn) else None
-            for i, s in enumerate(POOL_SCALES):
-                # ... and so are the gradients of the shared pooled maps
-                dpools[i], _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
-                                             dqs[i], True, dx_res=dpools[i], conv_queue=queue, bn_queue=bnq)
-            if bnq:
-                ops.bn_bwd_small(bnq)           # the four scales' BatchNorm backward (reduce + apply) in one launch
-            if queue:
-                ops.conv2d_grouped(queue)       # the four scales' 512 -> 2048 data gradients in one launch
+
+            def ppm_tail(head=head, dc_head=dc_head):
+                dqs = self._head_last_bwd_tail(T, head, dc_head)
+                queue = [] if self.group_small_convs else None
+                bnq = [] if (self.group_small_convs and self.small_bn) else None
+                for i, s in enumerate(POOL_SCALES):
+                    # ... and so are the gradients of the shared pooled maps
+                    dpools[i], _ = self._cbr_bwd(T, f'{head}.ppm{i}', C[f'{head}.ppm.{i}.1'], B[f'{head}.ppm.{i}.2'],
+                                                 dqs[i], True, dx_res=dpools[i], conv_queue=queue, bn_queue=bnq)
+                if bnq:
+                    ops.bn_bwd_small(bnq)           # the four scales' BatchNorm backward (reduce + apply) in one launch
+                if queue:
+                    ops.conv2d_grouped(queue)       # the four scales' 512 -> 2048 data gradients in one launch
+            if tail_stream is None:
+                ppm_tail()
+                if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
+                    self._flush_wgrads(T)
+            else:
+                # the PPM half of the head's backward (mixes, dq, the branches' BatchNorm and data gradients: ~90 us of launches
+                # of <= 113 workgroups) on the head stream, under the OTHER head's 230 us convolution.  Its weight-gradient
+                # operands are queued apart and join the pending list behind the stream join: a flush orders the weight-gradient
+                # stream behind the MAIN stream only
+                plan.wait_event(tail_stream, plan.record_event(bwd_stream))
+                pend, flop = T['wgrad_pending'], T['wgrad_pending_flop']
+                T['wgrad_pending'], T['wgrad_pending_flop'] = tail_wgrads, float('-inf')
+                try:
+                    with ops.use_stream(tail_stream):
+                        ppm_tail()
+                finally:
+                    T['wgrad_pending'], T['wgrad_pending_flop'] = pend, flop
+                if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
+                    self._flush_wgrads(T)
+        if tail_stream is not None:
+            plan.wait_event(bwd_stream, plan.record_event(tail_stream))
+            T['wgrad_pending'].extend(tail_wgrads)
+            T['wgrad_pending_flop'] += sum(2.0 * it[3] * it[6] * it[7] * it[2].numel() for it in tail_wgrads)
+            if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
+                self._flush_wgrads(T)
         if self.head_kind == 'ppm':
             gpool = torch.empty(M, 2048, dtype=BF, device=dev)
             if self.factored_ppm:

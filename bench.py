@@ -372,6 +372,9 @@ def main():
         # The lazy form (communicator created by the first collective on the current device) costs nothing.
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 init_method=None if 'MASTER_ADDR' in os.environ else 'tcp://127.0.0.1:29533')
+        if dist.get_world_size() != args.gpus or dist.get_backend() != 'nccl':
+            sys.exit(f'bench.py: --gpus {args.gpus} but the RCCL process group has {dist.get_world_size()} ranks '
+                     f'(backend {dist.get_backend()}): refusing to report a {args.gpus}-GPU number')
     from regda_amd.models.Encoder import Deeplabv2
     from regda_amd.ssl import SSLStep
     from regda_amd.synthetic import make_batch
@@ -503,6 +506,33 @@ def main():
         comm = {'rank0_ms': mine, 'max_over_ranks_ms': worst, 'payload': args.grad_payload,
                 'mb_per_step_per_rank': step.reducer.flat_g.numel() * (4 if args.grad_payload == 'fp32' else 2) / 1e6,
                 'what': 'main-stream stall at the join with the bucketed gradient exchange (HIP events around reducer.finish), last timed step'}
+        # when each bucket left (its gradients final), relative to the start of backward and to the join -- what overlaps
+        if step.bwd_start_event is not None and step.reducer.issue_events:
+            per = [{'bucket': i, 'mb': (step.reducer.buckets[i][1] - step.reducer.buckets[i][0]) * 4 / 1e6,
+                    'issued_ms_after_backward_start': step.bwd_start_event.elapsed_time(ev),
+                    'issued_ms_before_join': ev.elapsed_time(step.comm_events[0])} for i, ev in step.reducer.issue_events]
+            comm['buckets'] = per
+            print('rank %d buckets: %s' % (rank, ', '.join('#%d %.0f MB @%.2f ms (join -%.2f)' % (
+                b['bucket'], b['mb'], b['issued_ms_after_backward_start'], b['issued_ms_before_join']) for b in per)),
+                file=sys.stderr, flush=True)
+    # ---- every rank must hold the SAME weights after the timed loop (identical initial weights, summed gradients,
+    # identical optimizer): a bitwise checksum of the master weights, the EMA shadow and the prototypes is compared over the
+    # ranks and the run FAILS if they diverged -- a scaling number from ranks that train different models means nothing
+    replicas = None
+    if dist.is_initialized():
+        torch.cuda.synchronize()
+        def bits(t):
+            return t.contiguous().view(torch.int32).to(torch.int64).sum()
+        parts = [bits(model.flat_p), bits(step.prototypes)] + ([bits(step.teacher.flat_p)] if step.teacher is not None else [])
+        lo = torch.stack(parts)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas = {'identical': bool(torch.equal(lo, hi)), 'checksums': [int(v) for v in lo.tolist()],
+                    'what': 'int64 sums of the fp32 bit patterns of weights / prototypes / EMA shadow, min == max over ranks'}
+        if not replicas['identical']:
+            sys.exit(f'bench.py: rank {rank}: the ranks hold DIFFERENT weights after the timed loop '
+                     f'(checksums min {lo.tolist()} max {hi.tolist()}): the data-parallel step is broken')
     # host cost of enqueueing ONE step, measured from an idle queue (in the timed loop above the GPU is the bottleneck and
     # the launch queue pushes back on the host, so that loop's host time mostly shows the back-pressure)
     t_iso = []
@@ -543,6 +573,7 @@ def main():
             'mb_per_step': pf[0].bytes_per_batch / 1e6},
         'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
         'comm_exposed_ms': comm,
+        'replicas': replicas,
         # whole-step MFMA fraction on the REFERENCE's convolution FLOPs (1268 GFLOP/pair with the teacher forward): an
         # "effective" figure -- the step executes fewer (the head conv is re-associated); the executed-FLOP
         # fraction is roofline.step_executed_mfma_frac

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 8
+#define RGDA_ABI_VERSION 9
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore rgda_stat_t[RGDA_STAT_REPLICAS][2][C], zeroed by the caller.
@@ -152,6 +152,16 @@ int rgda_proto_update(const float* feat, const int64_t* label, float* protos, in
                       int b, int k, int c, int h, int w, int scale, int ignore_label,
                       float min_ratio, float decay, void* ws, size_t ws_bytes,
                       rgda_stream_t stream);
+/* The two halves of rgda_proto_update, for data-parallel ranks (ABI 9).  rgda_proto_stats leaves the
+ * sufficient statistics of _compute_local_prototypes (alignment.py:300-327) in `stats` (rgda_proto_update_workspace
+ * bytes): f32 sums[c][k] = sum of feat over the pixels whose downscaled label is class c, f32 cnt[c] = their number,
+ * then a flag word.  Both add over batches: the ranks all-reduce (sum) the first c * k + c floats and each calls
+ * rgda_proto_apply -- local = sums / (cnt + 1e-7), the old prototype where cnt < 1 (:318-321), EMA (:435-438) -- which
+ * gives the prototypes of the concatenated global batch on every rank.  rgda_proto_update == stats + apply. */
+int rgda_proto_stats(const float* feat, const int64_t* label, int64_t* label_ds, int b, int k, int c,
+                     int h, int w, int scale, int ignore_label, float min_ratio, void* stats,
+                     size_t stats_bytes, rgda_stream_t stream);
+int rgda_proto_apply(float* protos, const void* stats, int c, int k, float decay, rgda_stream_t stream);
 
 /* loss_calc([p1,p2], label, CrossEntropy, multi=True) forward + d(loss)/d(logits)
  *   regda/utils/tools.py:240-254; regda/gast/balance.py:88-101.

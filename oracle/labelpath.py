@@ -108,6 +108,24 @@ def update_prototype(feat_s, label_s, prototypes, decay=0.996, class_num=6, igno
     return (1.0 - decay) * local + decay * prototypes, ds               # :435-438
 
 
+def prototype_statistics(feat, label_ds, class_num=6, ignore_label=-1):
+    """The sufficient statistics of `local_prototypes` (alignment.py:300-317): (sums (c,k), counts (c,)).  They add over
+    batches -- what data-parallel ranks exchange."""
+    b, k, h, w = feat.shape
+    feats = feat.permute(0, 2, 3, 1).reshape(-1, k)
+    lab = label_ds.reshape(-1).clone()
+    lab[lab == ignore_label] = class_num
+    onehot = F.one_hot(lab, class_num + 1)[:, :-1].to(feats.dtype)
+    return onehot.t() @ feats, onehot.sum(0)
+
+
+def apply_prototype_statistics(prototypes, sums, counts, decay=0.996):
+    """alignment.py:318-321 + :435-438 from (global) statistics: local = sums / (n + eps), old prototype where n < 1, EMA."""
+    n_inst = counts.unsqueeze(1).expand_as(sums)
+    local = torch.where(n_inst < 1, prototypes, sums / (n_inst + EPS))
+    return (1.0 - decay) * local + decay * prototypes
+
+
 def class_balance_local_freq(label, class_num=6, ignore_label=-1):
     """balance.py:45-53."""
     lab = label.reshape(-1)

@@ -13,6 +13,7 @@ instance-norm backward)."""
 import torch
 
 from . import ops
+from .ddp import all_reduce_prototype_statistics
 from .ssl import SSLStep
 
 BF = torch.bfloat16
@@ -52,10 +53,14 @@ class AlignStep(SSLStep):
         s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
         feat_s, feat_t = feat[:nb], feat[nb:]
         # ema-updating prototypes comes first here (train_align_reg.py:157): the target branch sees the new ones
-        label_s_down = ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
         if self.world > 1:
-            torch.distributed.all_reduce(self.prototypes, group=self.group)
-            self.prototypes.div_(self.world)
+            # data-parallel ranks: all-reduce the sufficient statistics (per-class feature sums, pixel counts) and apply the
+            # totals -- the prototypes of the concatenated global batch, identical on every rank (SSLStep does the same)
+            self.proto_stats, label_s_down = ops.proto_stats(feat_s, label_s, 16, self.ig, 0.75, self.C, stats=self.proto_stats)
+            all_reduce_prototype_statistics(self.proto_stats, self.C, self.prototypes.shape[1], self.group)
+            ops.proto_apply(self.prototypes, self.proto_stats, self.pdecay)
+        else:
+            label_s_down = ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
         soft_t = ops.teacher_probs(t1, t2, tuple(images_t.shape[-2:]))             # :164-166
         if self.refine_label:
             soft, cm = ops.label_refine(feat_t, self.prototypes, t1, t2, soft_t, self.temp, return_ws=True)

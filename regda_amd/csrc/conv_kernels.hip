@@ -762,7 +762,12 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_grouped_kernel(ConvGr
 // relu(BatchNorm(x)) in place -- slab s + 1's piece i two tap steps after it was issued (the counted wait at the top of a
 // step leaves only the previous step's pieces in flight, and a wave needs no barrier to see its own DMA data); halo rows
 // outside the image stay the zeros the DMA deposited.  One 16-byte vector per thread and tap step.
-template <int D, int TR, bool XF = false>
+// NS = 4 (a fourth weight stage): the K loop is software-pipelined ACROSS its barriers.  The wait at the top of step q then
+// covers the weight tile of step q + 1 (issued three steps ahead instead of two), so behind barrier q every wave may read
+// stage q + 1 as well: the fragments of step q + 1's first two k-slices are read under the last MFMAs of step q, and no
+// wave opens a step with an LDS round trip in front of its first MFMA (with one barrier per step all eight waves of the
+// workgroup did -- both waves of every SIMD at the same time, matrix pipes idle).
+template <int D, int TR, bool XF = false, int NS = 3>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TC = 32;                                  // pixel tile: TR image rows x the 32 columns of the map
@@ -771,7 +776,11 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     constexpr int PXW = (NH + 63) / 64;                     // halo pieces (8 rows of 128 B) per wave and slab
     constexpr int XS = PXW * 64 * 128, WS = BC * 128;       // bytes of a halo buffer / a weight stage
     constexpr int CSTR = BC * 2 + 16, EPI = BP * CSTR + NW * BC * 2 * 4;
-    constexpr int SMEM = 2 * XS + 3 * WS;
+    constexpr int SMEM = 2 * XS + NS * WS;
+    constexpr bool PF = NS == 4;
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    static_assert(!PF || PXW <= 7, "the next slab's halo is complete behind the barrier of tap 8");
+    static_assert(!(PF && XF) || PXW + 3 <= 9, "... and transformed");
     constexpr int XFTAB = XF ? RGDA_BNIN_MAX_C * 2 * 4 : 0;
     static_assert(EPI <= SMEM && SMEM + XFTAB <= 160 * 1024, "LDS budget");
     static_assert(!XF || PXW + 2 <= 9, "every piece of the next slab is transformed before the slab ends");
@@ -807,21 +816,35 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
         hvo[i] = ok ? (((n * a.H + y) * TC + x) * a.ldx * 2 + (lslot ^ ((h >> 1) & 7)) * 16) : OOB;
     }
     const i32x4 rs_wa = dma_rsrc(a.w, (unsigned)((size_t)a.Cout * 9 * a.Cin * 2));
-    auto issue_w = [&](int q, int stage) {
+    // live = false: the same instructions with out-of-range offsets (no traffic, zeros into a stage nobody reads): the
+    // pipelined loop issues a constant number of DMA instructions per step, so its vmcnt waits are compile-time constants
+    auto issue_w2 = [&](int tap, int sl, int stage, bool live) {
+        const int so = (tap * a.Cin + sl * 64) * 2;
+        unsigned char* wb = swb + stage * WS + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int vo = live ? wvo[i] : OOB;
+            if constexpr (XF) dma16_to_lds(rs_wa, wb + i * NW * 1024, vo, so);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * NW * 1024), 16, vo, so, 0, 0);
+        }
+    };
+    auto issue_w = [&](int q, int stage, bool live = true) {
         const int tap = q % 9, sl = q / 9;
         const int so = (tap * a.Cin + sl * 64) * 2;
         unsigned char* wb = swb + stage * WS + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if constexpr (XF) dma16_to_lds(rs_wa, wb + i * NW * 1024, wvo[i], so);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * NW * 1024), 16, wvo[i], so, 0, 0);
+            const int vo = live ? wvo[i] : OOB;
+            if constexpr (XF) dma16_to_lds(rs_wa, wb + i * NW * 1024, vo, so);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(wb + i * NW * 1024), 16, vo, so, 0, 0);
         }
     };
     const i32x4 rs_xa = dma_rsrc(a.x, (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2));
-    auto issue_h = [&](int sl, int i) {
+    auto issue_h = [&](int sl, int i, bool live = true) {
         unsigned char* xb = sxb + (sl & 1) * XS + wave * 1024 + i * NW * 1024;
-        if constexpr (XF) dma16_to_lds(rs_xa, xb, hvo[i], sl * 128);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(xb), 16, hvo[i], sl * 128, 0, 0);
+        const int vo = live ? hvo[i] : OOB;
+        if constexpr (XF) dma16_to_lds(rs_xa, xb, vo, sl * 128);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(xb), 16, vo, sl * 128, 0, 0);
     };
 
     f32x16 acc[FI][FJ];
@@ -871,6 +894,7 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     for (int i = 0; i < PXW; ++i) issue_h(0, i);
     issue_w(0, 0);
     issue_w(1, 1);
+    if constexpr (PF) issue_w(2, 2);
     // ---- XF: this thread's vector of halo piece k is row k * 64 + (t >> 3), LOGICAL slot lslot (the channels, hence the
     // scale / shift registers, are the same for every row); those are bytes of the wave's own DMA instructions
     float xsc[8], xsh[8];
@@ -899,6 +923,52 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     }
     int pend = 2, wstage = 0;
     bf16x8 fa0[2][FI], fb0[2][FJ], fa1[2][FI], fb1[2][FJ];
+    if constexpr (PF) {
+        // the first step's first fragments: halo slab 0 and weight tile 0 have landed (tiles 1 and 2 stay in flight)
+        WAIT_VMCNT(4);
+        if constexpr (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_half(swb, sxb, 0, 0, fa0, fb0);
+    }
+    if constexpr (PF) {
+      for (int sl = 0; sl < S; ++sl) {
+        const bool more = sl + 1 < S;
+        const unsigned char* xb = sxb + (sl & 1) * XS;
+        const unsigned char* xbn = sxb + ((sl + 1) & 1) * XS;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int q = sl * 9 + tp;
+            // everything but the previous step's DMA instructions has landed: weight tile q + 1 (and, with the barrier, every
+            // wave's part of it); in flight: tile q + 2 and the halo piece of step tp - 1
+            if (tp >= 1 && tp - 1 < PXW) WAIT_VMCNT(3); else WAIT_VMCNT(2);
+            if constexpr (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the previous step's in-place transform
+            __builtin_amdgcn_s_barrier();
+            issue_w2((tp + 3) % 9, sl + (tp + 3) / 9, wstage >= 1 ? wstage - 1 : 3, q + 3 < KT);
+            if (tp < PXW) issue_h(sl + 1, tp, more);
+            if constexpr (XF) {
+                if (more) {
+                    if (tp == 1) xf_load(sl + 1);
+                    if (tp >= 2 && tp - 2 < PXW) xf_piece(sl + 1, tp - 2);
+                }
+            }
+            // k-slices 2, 3 of this step are read while 0, 1 (read under the previous step) multiply; then the next step's
+            // k-slices 0, 1 -- the stage after this one, the other halo buffer behind tap 8 -- under 2, 3.  (Behind the last
+            // step the prefetch reads a stage that holds nothing new: unconditional, so that the step stays ONE basic block.)
+            read_half(swb + wstage * WS, xb, tp, 1, fa1, fb1);
+            mfma_half(fa0, fb0);
+            read_half(swb + (wstage == NS - 1 ? 0 : wstage + 1) * WS, tp == 8 ? xbn : xb, tp == 8 ? 0 : tp + 1, 0, fa0, fb0);
+            mfma_half(fa1, fb1);
+            // one fragment read behind every MFMA (the compiler's own order -- all of a half's reads in one burst, then a
+            // wait that also covers part of the NEXT burst -- stalls the first MFMA of each half on LDS latency)
+#pragma unroll
+            for (int i = 0; i < 4 * FI * FJ; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, (FI + FJ + FI * FJ - 1) / (FI * FJ), 0);   // its share of the LDS reads
+            }
+            wstage = (wstage == NS - 1) ? 0 : wstage + 1;
+        }
+      }
+    } else {
     for (int sl = 0; sl < S; ++sl) {
         const bool more = sl + 1 < S;
         const unsigned char* xb = sxb + (sl & 1) * XS;
@@ -931,8 +1001,9 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
             }
             mfma_half(fa0, fb0);
             mfma_half(fa1, fb1);
-            wstage = (wstage == 2) ? 0 : wstage + 1;
+            wstage = (wstage == NS - 1) ? 0 : wstage + 1;
         }
+    }
     }
     __syncthreads();
     float s[8], q8[8];
@@ -1337,8 +1408,11 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
             const int tr = kind == 1 ? 4 : 8;
             a.tiles_c = cdiv(Cout, 128); a.tiles_p = (int)(M / (tr * 32));
             const int grid = a.tiles_c * a.tiles_p;
-            if (kind == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true>", conv3x3_halo_kernel<1, 4, true><<<grid, 512, 0, st>>>(a));
-            else RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true>", conv3x3_halo_kernel<1, 8, true><<<grid, 512, 0, st>>>(a));
+            int ns = 4;
+            if (const char* e = TUNE_ENV("RGDA_HALO_NS")) ns = atoi(e);                     // tuning experiments only
+            if (kind == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 4>", conv3x3_halo_kernel<1, 4, true, 4><<<grid, 512, 0, st>>>(a));
+            else if (kind == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 3>", conv3x3_halo_kernel<1, 4, true><<<grid, 512, 0, st>>>(a));
+            else RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true, 3>", conv3x3_halo_kernel<1, 8, true><<<grid, 512, 0, st>>>(a));
         }
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
@@ -1366,9 +1440,13 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         a.tiles_c = cdiv(Cout, 128);
         a.tiles_p = (int)(M / (tr * 32));
         const int grid = a.tiles_c * a.tiles_p;
-        if (tr == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false>", conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a));
-        else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false>", conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a));
-        else RGDA_LAUNCH("conv3x3_halo_kernel<2, 8, false>", conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a));
+        int ns = 4;                                                                        // (dilation 2: 3 stages, 160 KB)
+        if (const char* e = TUNE_ENV("RGDA_HALO_NS")) ns = atoi(e);                         // tuning experiments only
+        if (tr == 4 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 4>", conv3x3_halo_kernel<1, 4, false, 4><<<grid, 512, 0, st>>>(a));
+        else if (tr == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 3>", conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a));
+        else if (dil == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false, 4>", conv3x3_halo_kernel<1, 8, false, 4><<<grid, 512, 0, st>>>(a));
+        else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false, 3>", conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a));
+        else RGDA_LAUNCH("conv3x3_halo_kernel<2, 8, false, 3>", conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a));
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
     }

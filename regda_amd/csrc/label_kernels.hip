@@ -378,9 +378,14 @@ __global__ void __launch_bounds__(256) pick_hist_kernel(const float* __restrict_
     // ---- the last workgroup of this image decides the image's table
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's atomics have been performed
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&counters[b], 1) == (int)gridDim.x - 1);
+    if (threadIdx.x == 0) {
+        __threadfence();                                    // agent-scope release: the workgroup's histogram adds (ordered before this
+                                                            // thread by the barrier) are visible before the arrival count moves
+        s_last = (atomicAdd(&counters[b], 1) == (int)gridDim.x - 1);
+    }
     __syncthreads();
     if (!s_last) return;
+    __threadfence();                                        // agent-scope acquire in front of the table's reads (one workgroup per image)
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gh, 0, R * C * 4, 0x00020000);
     // eight regions per thread and pass, all 48 loads in flight together (region after region this tail was 16 dependent
@@ -1070,18 +1075,22 @@ __global__ void __launch_bounds__(256) proto_finalize_kernel(float* protos, cons
 
 extern "C" size_t rgda_proto_update_workspace(int c, int k) { return ((size_t)c * k + c) * 4 + 16; }
 
-extern "C" int rgda_proto_update(const float* feat, const int64_t* label, float* protos, int64_t* label_ds, int b,
-                                 int k, int c, int h, int w, int scale, int ignore_label, float min_ratio,
-                                 float decay, void* ws, size_t ws_bytes, rgda_stream_t stream) {
-    if (!feat || !label || !protos || !label_ds || !ws) return RGDA_ERR_ARG;
+// The sufficient statistics of _compute_local_prototypes (alignment.py:300-327): f32 sums[c][k] = sum of the features of
+// the pixels whose downscaled label is class c, f32 cnt[c] = their number, then one flag word.  They ADD over batches, so
+// data-parallel ranks all-reduce (sum) the first c * k + c floats and every rank applies the same totals: the prototypes
+// of the concatenated global batch, not an average of per-rank prototypes.
+extern "C" int rgda_proto_stats(const float* feat, const int64_t* label, int64_t* label_ds, int b, int k, int c, int h, int w,
+                                int scale, int ignore_label, float min_ratio, void* stats, size_t stats_bytes,
+                                rgda_stream_t stream) {
+    if (!feat || !label || !label_ds || !stats) return RGDA_ERR_ARG;
     if (c != 6) return RGDA_ERR_UNSUPPORTED;
-    if (b <= 0 || k <= 0 || h <= 0 || w <= 0 || scale <= 1 || !(decay > 0.f && decay < 1.f)) return RGDA_ERR_ARG;
-    if (ws_bytes < rgda_proto_update_workspace(c, k)) return RGDA_ERR_WORKSPACE;
+    if (b <= 0 || k <= 0 || h <= 0 || w <= 0 || scale <= 1) return RGDA_ERR_ARG;
+    if (stats_bytes < rgda_proto_update_workspace(c, k)) return RGDA_ERR_WORKSPACE;
     hipStream_t st = to_stream(stream);
-    float* sums = (float*)ws;
+    float* sums = (float*)stats;
     float* cnt = sums + (size_t)c * k;
     int* flag = (int*)(cnt + c);
-    if (zero_bytes(ws, rgda_proto_update_workspace(c, k), stream) != RGDA_OK) return RGDA_ERR_LAUNCH;
+    if (zero_bytes(stats, rgda_proto_update_workspace(c, k), stream) != RGDA_OK) return RGDA_ERR_LAUNCH;
     if (scale == 16 && c <= 6 && !(w & 1))
         downscale_label16_kernel<<<dim3(cdiv(w * 8, 256), b * h), 256, 0, st>>>(label, label_ds, cnt, flag, h, w, c, ignore_label, min_ratio);
     else
@@ -1089,10 +1098,28 @@ extern "C" int rgda_proto_update(const float* feat, const int64_t* label, float*
     RGDA_CHECK_LAUNCH();
     proto_accum_kernel<6><<<k, 256, 0, st>>>(feat, label_ds, sums, k, h * w, b);
     RGDA_CHECK_LAUNCH();
+    return RGDA_OK;
+}
+
+// local = sums / (cnt + 1e-7), the old prototype where cnt < 1 (alignment.py:318-321), then the EMA (:435-438)
+extern "C" int rgda_proto_apply(float* protos, const void* stats, int c, int k, float decay, rgda_stream_t stream) {
+    if (!protos || !stats) return RGDA_ERR_ARG;
+    if (c <= 0 || k <= 0 || !(decay > 0.f && decay < 1.f)) return RGDA_ERR_ARG;
+    const float* sums = (const float*)stats;
+    const float* cnt = sums + (size_t)c * k;
     float omd = (float)(1.0 - (double)decay);
-    proto_finalize_kernel<<<cdiv((long long)c * k, 256), 256, 0, st>>>(protos, sums, cnt, k, c * k, omd, decay);
+    proto_finalize_kernel<<<cdiv((long long)c * k, 256), 256, 0, to_stream(stream)>>>(protos, sums, cnt, k, c * k, omd, decay);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
+}
+
+extern "C" int rgda_proto_update(const float* feat, const int64_t* label, float* protos, int64_t* label_ds, int b,
+                                 int k, int c, int h, int w, int scale, int ignore_label, float min_ratio,
+                                 float decay, void* ws, size_t ws_bytes, rgda_stream_t stream) {
+    if (!protos || !(decay > 0.f && decay < 1.f)) return RGDA_ERR_ARG;
+    const int rc = rgda_proto_stats(feat, label, label_ds, b, k, c, h, w, scale, ignore_label, min_ratio, ws, ws_bytes, stream);
+    if (rc != RGDA_OK) return rc;
+    return rgda_proto_apply(protos, ws, c, k, decay, stream);
 }
 
 // --------------------------------------------------------------------------------------

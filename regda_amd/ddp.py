@@ -47,6 +47,21 @@ def make_buckets(boundaries, total, bucket_elems, tail_elems=None):
     return buckets
 
 
+def all_reduce_prototype_statistics(stats, class_num, feat_channels, group=None):
+    """Cross-rank state of `Aligner.update_prototype` (regda/gast/alignment.py:300-327).  `stats` is the flat
+    float32 buffer rgda_proto_stats leaves: sums[c][k] (sum of the source features over the pixels of downscaled class c)
+    followed by cnt[c].  Both ADD over batches, so one all-reduce (sum) of these class_num * (feat_channels + 1) floats
+    gives every rank the statistics of the concatenated global batch; rgda_proto_apply then forms
+    sums / (cnt + 1e-7), keeps the old prototype where the GLOBAL count is < 1, and does the EMA -- what the reference
+    computes on the whole batch.  (Averaging per-rank prototypes is a different number whenever class counts differ
+    across ranks, and lets a rank without a class vote for the old prototype.)"""
+    n = class_num * feat_channels + class_num
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= n
+    if dist.is_initialized():
+        dist.all_reduce(stats[:n], op=dist.ReduceOp.SUM, group=group)
+    return stats
+
+
 class FlatGradReducer:
     def __init__(self, flat_g, boundaries, bucket_elems=12 << 20, group=None, payload='fp32'):
         assert payload in ('fp32', 'bf16')
@@ -59,12 +74,22 @@ class FlatGradReducer:
         self.buckets = make_buckets(boundaries, flat_g.numel(), bucket_elems)
         self._next = 0
         self._works = []
+        self.measure = False        # bench: a timing event on the issuing stream per bucket (`issue_events`, cleared by reset())
+        self.issue_events = []
         self._stage = {}            # bf16 payload: per-bucket staging buffers, allocated once
         self._comm_stream = None    # bf16 payload on a GPU: the two collectives and the kernels between them run here
+        if payload == 'bf16' and (self.world > 1 or self.force):
+            # every staging buffer and the stream exist before the first exchange: nothing is allocated inside a recorded
+            # plan's private pool or on the communication stream
+            for a, b in self.buckets:
+                self._staging(a, b)
+            if flat_g.is_cuda:
+                self._comm_stream = torch.cuda.Stream(device=flat_g.device)
 
     def reset(self):
         self._next = 0
         self._works = []
+        self.issue_events = []
 
     @property
     def active(self):
@@ -109,6 +134,10 @@ class FlatGradReducer:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= offset:
             a, b = self.buckets[self._next]
+            if self.measure and self.flat_g.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()             # on the stream the bucket is issued from: when its gradients were final
+                self.issue_events.append((self._next, ev))
             if self.payload == 'fp32':
                 self._works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
                                                    async_op=True))

@@ -52,7 +52,9 @@ class Aligner:
         """alignment.py:194-265: every `mode`, one or two prediction tensors, with or without the superpixel view
         (label_t_sup (b,1,H,W) int64 given and mode 'all' / 's', :238-258; the SSL path passes None,
         tools/train_ssl_reg.py:214).  `max_superpixels` (attribute, default 65536) bounds the ids: the table of
-        per-superpixel maxima is sized by it instead of by a read-back of label_t_sup.max()."""
+        per-superpixel maxima is sized by it instead of by a read-back of label_t_sup.max() (the reference has no bound:
+        torch_scatter sizes its output by the largest id); ids beyond it raise ValueError -- that check reads a flag back
+        (one host sync per call); `check_superpixel_range = False` (attribute) skips it and keeps the call enqueue-only."""
         assert mode in ['all', 's', 'p', 'n', 'l']
         if not refine:
             return label_t_soft
@@ -71,7 +73,8 @@ class Aligner:
         feat = feat_t.detach() if views & 1 else None
         if sup:
             out, cm = ops.label_refine_sup(feat, self.prototypes, p1, p2, label_t_soft, label_t_sup.long(), temp, views,
-                                           max_regions=getattr(self, 'max_superpixels', 65536), return_ws=True)
+                                           max_regions=getattr(self, 'max_superpixels', 65536), return_ws=True,
+                                           check=getattr(self, 'check_superpixel_range', True))
         else:
             out, cm = ops.label_refine(feat, self.prototypes, p1, p2, label_t_soft, temp, return_ws=True, views=views)
         self._classmax_ws = cm       # per-image per-class maxima of the result (reused by the fused trainer)

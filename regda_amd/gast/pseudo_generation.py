@@ -39,10 +39,10 @@ def gener_target_pseudo(_cfg, model, pseudo_loader, save_pseudo_label_path, slid
                 out = ops.resize_bilinear_ac(cls, size) if tuple(cls.shape[-2:]) != tuple(size) else cls
                 torch.save(out.squeeze(dim=0).cpu(), os.path.join(save_pseudo_label_path, ret_gt['fname'][0] + '.pt'))
             else:
-                if getattr(_cfg, 'PSEUDO_SELECT', True):
+                if _cfg.PSEUDO_SELECT:                # required attribute, as in the reference (:144)
                     lab = pseudo_selection(cls, ignore_label=ignore_label)      # the reference's call: default cut-offs, ndarray (:145)
                 else:
                     lab = ops.argmax_nchw(cls).cpu().numpy()
                 from PIL import Image
                 arr = (np.asarray(lab) + 1).reshape(*size).astype(np.uint8)      # -1 .. C-1  ->  0 .. C  (:149-150)
-                Image.fromarray(arr, mode='L').save(os.path.join(save_pseudo_label_path, ret_gt['fname'][0]))
+                Image.fromarray(arr)               # uint8, 2-D: mode 'L'.save(os.path.join(save_pseudo_label_path, ret_gt['fname'][0]))

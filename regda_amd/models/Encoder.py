@@ -27,8 +27,9 @@ from .. import ops
 from .. import plan
 
 BF = torch.bfloat16
-LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3),
-          'resnet17t': (2, 1, 1, 2)}   # resnet17t: test-only shallow topology (same code paths, 6 blocks)
+# blocks per stage of the topologies the reference builds (regda/_resnets.py:232-262); tests register a shallow one of
+# their own (tests/conftest.py) -- the table is read when a model is constructed
+LAYERS = {'resnet101': (3, 4, 23, 3), 'resnet50': (3, 4, 6, 3)}
 POOL_SCALES = (1, 2, 3, 6)
 NREP = 8                # RGDA_STAT_REPLICAS (include/rgda_hip.h)
 LAYOUT_TILE = 64        # RGDA_LAYOUT_TILE
@@ -256,6 +257,79 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
+def _param_entries(resnet_type, head_kind, num_classes):
+    """(name, kind, shape) of every state_dict entry in the reference's order (688 for ResNet-101 + two PPM heads), the
+    block specifications and the name of a head's first convolution.  Pure: no device, no tensors."""
+    entries = []            # (name, kind, shape) in the reference's state_dict order
+
+    def conv(name, co, ci, k, bias=False):
+        entries.append((name + '.weight', 'convw', (co, ci, k, k)))
+        if bias:
+            entries.append((name + '.bias', 'vec', (co,)))
+
+    def bn(name, c):
+        entries.append((name + '.weight', 'vec', (c,)))
+        entries.append((name + '.bias', 'vec', (c,)))
+        entries.append((name + '.running_mean', 'buf', (c,)))
+        entries.append((name + '.running_var', 'buf', (c,)))
+        entries.append((name + '.num_batches_tracked', 'nbt', ()))
+
+    conv('encoder.resnet.conv1', 64, 3, 7); bn('encoder.resnet.bn1', 64)
+    blocks = _block_specs(resnet_type)
+    for p, inpl, planes, stride, dil, ds in blocks:
+        conv(p + '.conv1', planes, inpl, 1); bn(p + '.bn1', planes)
+        conv(p + '.conv2', planes, planes, 3); bn(p + '.bn2', planes)
+        conv(p + '.conv3', planes * 4, planes, 1); bn(p + '.bn3', planes * 4)
+        if ds:
+            conv(p + '.downsample.0', planes * 4, inpl, 1); bn(p + '.downsample.1', planes * 4)
+    for head in ('layer5', 'layer6'):
+        if head_kind == 'aspp':
+            for i in range(len(ASPP_DILATIONS)):
+                conv(f'{head}.conv2d_list.{i}', num_classes, 2048, 3, bias=True)
+            continue
+        for i in range(4):
+            conv(f'{head}.ppm.{i}.1', 512, 2048, 1); bn(f'{head}.ppm.{i}.2', 512)
+        conv(f'{head}.conv_last.0', 512, 2048 + 4 * 512, 3); bn(f'{head}.conv_last.1', 512)
+        conv(f'{head}.conv_last.4', num_classes, 512, 1, bias=True)
+    head_first = 'ppm.0.1' if head_kind == 'ppm' else 'conv2d_list.0'
+
+    return entries, blocks, head_first
+
+
+def flat_layout(resnet_type='resnet101', head_kind='ppm', num_classes=6):
+    """Element offset and size of every parameter in the flat fp32 buffers (flat_p / flat_g / momentum / EMA shadow):
+    {name: (offset, numel)}, tensors padded to multiples of 64 elements, in `named_parameters()` order.  Pure host
+    arithmetic (the CPU tests of the gradient exchange use it; `Deeplabv2._build_params` lays the buffers out the same way)."""
+    entries, _, _ = _param_entries(resnet_type, head_kind, num_classes)
+    out, op = {}, 0
+    for name, kind, shape in entries:
+        if kind in ('convw', 'vec'):
+            n = math.prod(shape)
+            out[name] = (op, n)
+            op += _pad64(n)
+    out['__total__'] = (op, 0)
+    return out
+
+
+def backward_progress_offsets(resnet_type='resnet101', head_kind='ppm', num_classes=6):
+    """The offsets `Deeplabv2._backward_plan` reports through `on_progress`, in order: "every gradient at a flat offset >=
+    this one is final" -- after both heads (the first head's first convolution), then after each residual block from the
+    last to the first (its conv1).  The stem's gradients are final when backward returns (`FlatGradReducer.finish`)."""
+    lay = flat_layout(resnet_type, head_kind, num_classes)
+    _, blocks, head_first = _param_entries(resnet_type, head_kind, num_classes)
+    offs = [lay[f'layer5.{head_first}.weight'][0]]
+    offs += [lay[p + '.conv1.weight'][0] for p, *_ in reversed(blocks)]
+    return offs
+
+
+def bucket_boundaries(resnet_type='resnet101', head_kind='ppm', num_classes=6):
+    """`Deeplabv2.param_boundaries()` without a model: the legal bucket cuts (block and head starts)."""
+    lay = flat_layout(resnet_type, head_kind, num_classes)
+    _, blocks, head_first = _param_entries(resnet_type, head_kind, num_classes)
+    return sorted([lay[p + '.conv1.weight'][0] for p, *_ in blocks] +
+                  [lay[f'{h}.{head_first}.weight'][0] for h in ('layer5', 'layer6')])
+
+
 class Deeplabv2(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -324,38 +398,7 @@ class Deeplabv2(nn.Module):
     # ------------------------------------------------------------------ parameters
     def _build_params(self):
         dev = self.device
-        entries = []            # (name, kind, shape) in the reference's state_dict order
-
-        def conv(name, co, ci, k, bias=False):
-            entries.append((name + '.weight', 'convw', (co, ci, k, k)))
-            if bias:
-                entries.append((name + '.bias', 'vec', (co,)))
-
-        def bn(name, c):
-            entries.append((name + '.weight', 'vec', (c,)))
-            entries.append((name + '.bias', 'vec', (c,)))
-            entries.append((name + '.running_mean', 'buf', (c,)))
-            entries.append((name + '.running_var', 'buf', (c,)))
-            entries.append((name + '.num_batches_tracked', 'nbt', ()))
-
-        conv('encoder.resnet.conv1', 64, 3, 7); bn('encoder.resnet.bn1', 64)
-        self.blocks = _block_specs(self.resnet_type)
-        for p, inpl, planes, stride, dil, ds in self.blocks:
-            conv(p + '.conv1', planes, inpl, 1); bn(p + '.bn1', planes)
-            conv(p + '.conv2', planes, planes, 3); bn(p + '.bn2', planes)
-            conv(p + '.conv3', planes * 4, planes, 1); bn(p + '.bn3', planes * 4)
-            if ds:
-                conv(p + '.downsample.0', planes * 4, inpl, 1); bn(p + '.downsample.1', planes * 4)
-        for head in ('layer5', 'layer6'):
-            if self.head_kind == 'aspp':
-                for i in range(len(ASPP_DILATIONS)):
-                    conv(f'{head}.conv2d_list.{i}', self.num_classes, 2048, 3, bias=True)
-                continue
-            for i in range(4):
-                conv(f'{head}.ppm.{i}.1', 512, 2048, 1); bn(f'{head}.ppm.{i}.2', 512)
-            conv(f'{head}.conv_last.0', 512, 2048 + 4 * 512, 3); bn(f'{head}.conv_last.1', 512)
-            conv(f'{head}.conv_last.4', self.num_classes, 512, 1, bias=True)
-        self._head_first = 'ppm.0.1' if self.head_kind == 'ppm' else 'conv2d_list.0'
+        entries, self.blocks, self._head_first = _param_entries(self.resnet_type, self.head_kind, self.num_classes)
 
         n_param = sum(_pad64(math.prod(s)) for _, k, s in entries if k in ('convw', 'vec'))
         n_buf = sum(_pad64(math.prod(s)) for _, k, s in entries if k == 'buf')
@@ -1340,8 +1383,22 @@ class Deeplabv2(nn.Module):
                     ops.bn_bwd_small(bnq)           # the four scales' BatchNorm backward (reduce + apply) in one launch
                 if queue:
                     ops.conv2d_grouped(queue)       # the four scales' 512 -> 2048 data gradients in one launch
-            if tail_stream is None:
-                ppm_tail()
+            if tail_stream is None and not (self.group_small_convs and self.small_bn):
+                ppm_tail()                  # every unit's BatchNorm backward is launched inside its _cbr_bwd: flushes are safe there
+                if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
+                    self._flush_wgrads(T)
+            elif tail_stream is None:
+                # the branches' weight-gradient operands (dc) are written by ops.bn_bwd_small at the END of the tail: they
+                # are queued apart (no flush can fire inside the tail) and join the pending list once it has been launched
+                pend, flop = T['wgrad_pending'], T['wgrad_pending_flop']
+                mine = []
+                T['wgrad_pending'], T['wgrad_pending_flop'] = mine, float('-inf')
+                try:
+                    ppm_tail()
+                finally:
+                    T['wgrad_pending'], T['wgrad_pending_flop'] = pend, flop
+                T['wgrad_pending'].extend(mine)
+                T['wgrad_pending_flop'] += sum(2.0 * it[3] * it[6] * it[7] * it[2].numel() for it in mine)
                 if T['wgrad_pending_flop'] >= self.wgrad_group_gflop * 1e9:
                     self._flush_wgrads(T)
             else:

@@ -256,6 +256,38 @@ def proto_update(feat, label, protos, scale=16, ignore_label=-1, min_ratio=0.75,
     return ds
 
 
+def proto_stats(feat, label, scale=16, ignore_label=-1, min_ratio=0.75, class_num=6, stats=None):
+    """The sufficient statistics of update_prototype for data-parallel ranks (rgda_proto_stats): returns (stats, ds) --
+    `stats` a float32 buffer whose first class_num * k + class_num elements are sums[c][k] and cnt[c] (what the ranks
+    all-reduce), ds the downscaled label (b,1,h,w) int64."""
+    _need_cuda(feat, label)
+    feat = feat.contiguous().float()
+    label = label.contiguous()
+    if label.dim() == 4:
+        label = label.squeeze(1)
+    assert label.dtype == torch.int64
+    b, k, h, w = feat.shape
+    assert label.shape == (b, h * scale, w * scale), (label.shape, feat.shape)
+    ds = torch.empty((b, 1, h, w), dtype=torch.int64, device=feat.device)
+    L = lib()
+    nbytes = L.size('rgda_proto_update_workspace', class_num, k)
+    if stats is None:
+        stats = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=feat.device)
+    assert stats.is_contiguous() and stats.dtype == torch.float32 and stats.numel() * 4 >= nbytes
+    L.call('rgda_proto_stats', feat.data_ptr(), label.data_ptr(), ds.data_ptr(), b, k, class_num, h, w, scale, ignore_label,
+           float(min_ratio), stats.data_ptr(), stats.numel() * 4, _stream())
+    return stats, ds
+
+
+def proto_apply(protos, stats, decay=0.996):
+    """protos <- EMA(protos, sums / (cnt + 1e-7), kept where cnt < 1) from (all-reduced) statistics (rgda_proto_apply)."""
+    _need_cuda(protos, stats)
+    assert protos.is_contiguous() and protos.dtype == torch.float32 and stats.dtype == torch.float32
+    c, k = protos.shape
+    assert stats.numel() >= c * k + c
+    lib().call('rgda_proto_apply', protos.data_ptr(), stats.data_ptr(), c, k, float(decay), _stream())
+
+
 def fill_zero(t):
     """t.zero_() as a kernel of this library (contiguous tensor, 16-byte aligned storage)."""
     assert t.is_contiguous()

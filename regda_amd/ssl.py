@@ -13,7 +13,7 @@ import torch
 
 from . import ops
 from . import plan
-from .ddp import FlatGradReducer
+from .ddp import FlatGradReducer, all_reduce_prototype_statistics
 
 
 class SSLStep:
@@ -47,6 +47,7 @@ class SSLStep:
         self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group, payload=grad_payload)
         self.measure_comm = False   # bench: HIP events around the main stream's wait for the gradient exchange
         self.comm_events = None
+        self.bwd_start_event = None
         self.wgrad_stream = torch.cuda.Stream(device=dev) if overlap_wgrad else None
         self.source_side = overlap_wgrad    # source half of the label path on the second stream
         # --bcs / --bct of tools/train_ssl_reg.py:54-58,125-158: regda_amd.gast.balance.ClassBalance objects whose
@@ -55,6 +56,7 @@ class SSLStep:
         self._graph = None
         self._plan = None
         self._proto_ready = None
+        self.proto_stats = None     # data-parallel ranks: sums[c][k], cnt[c] of update_prototype (all-reduced per step)
         self.marks = None           # set to [] to collect (name, event) phase marks of the next step (bench --phases)
         self.overlap_comm = overlap_comm
         self.keep_debug = False     # tests: keep the step's target logits / features / refined soft labels (`self.debug`)
@@ -278,11 +280,12 @@ class SSLStep:
         else:
             soft = soft_t
             hard = ops.pseudo_select(soft_t, self.top, self.low, self.ig, check=False)
+        exchange_protos = self.reducer.active
         if side is not None:
             # update_prototype rewrites the prototypes label_refine has just read
             plan.wait_event(side, plan.record_event(main))
             with ops.use_stream(side):
-                ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
+                self._proto_local(feat_s, label_s, exchange_protos)
             source_done = plan.record_event(side)
         if self.keep_debug:
             self.debug = dict(t1=t1, t2=t2, s1=s1, s2=s2, feat_t=feat_t, feat_s=feat_s, soft_in=soft_t, soft=soft,
@@ -299,20 +302,22 @@ class SSLStep:
                 hard = ops.lrh(hard, regs.contiguous(), self.percent, self.C, self.ig, self.max_regions, check=False,
                                ws=self.lrh_ws)
         if side is None:
-            ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
-        if self.reducer.active:
-            # keep the prototypes identical on every rank: averaged over the ranks.  Nothing of THIS step
-            # reads them any more (label_refine is done), so the 48 KB all-reduce -- pure latency -- runs on the second
-            # stream next to backward and the next step's label path waits for it
+            self._proto_local(feat_s, label_s, exchange_protos)
+        if exchange_protos:
+            # data-parallel ranks: the per-class feature sums and pixel counts of the rank's source batch are
+            # all-reduced (sum) and every rank applies the same totals -- the prototypes of the concatenated GLOBAL batch
+            # (alignment.py:300-327: sum feat 1[c] / (n_c + eps), old prototype kept iff the global n_c < 1), identical bits on
+            # every rank, the reference exactly at world 1.  Nothing of THIS step reads the prototypes any more (label_refine
+            # is done), so the 48 KB all-reduce -- pure latency -- and the apply run on the second stream next to backward;
+            # the next step's label path waits for them
             pside = self.wgrad_stream if self.wgrad_stream is not None else main
             if pside is not main and side is None:
                 plan.wait_event(pside, plan.record_event(main))
-
-            def sync_prototypes():
-                torch.distributed.all_reduce(self.prototypes, group=self.group)
-                self.prototypes.div_(self.world)
+            def exchange_statistics():
+                all_reduce_prototype_statistics(self.proto_stats, self.C, self.prototypes.shape[1], self.group)
             with ops.use_stream(pside):
-                plan.host(sync_prototypes)
+                plan.host(exchange_statistics)
+                ops.proto_apply(self.prototypes, self.proto_stats, self.pdecay)
                 plan.host(lambda: setattr(self, '_proto_ready', pside.record_event() if pside is not main else None))
         # ---- losses + d(loss)/d(logits)
         if side is None:
@@ -330,11 +335,25 @@ class SSLStep:
         self.last_hard = hard
         return loss_s, loss_t, self.gn
 
+    def _proto_local(self, feat_s, label_s, exchange):
+        """update_prototype on this rank's source batch: the whole update (one rank), or its sufficient statistics only
+        (data-parallel ranks: `_step` all-reduces them and applies the totals)."""
+        if exchange:
+            self.proto_stats, _ = ops.proto_stats(feat_s, label_s, 16, self.ig, 0.75, self.C, stats=self.proto_stats)
+        else:
+            ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)
+
     def _backward_and_update(self, T, main, g1, g2, gfeat=None):
         """Backward (both domains in one pass; all-reduce buckets are released as it moves down the net), then clip +
         SGD (+ EMA) in one pass over the flat buffers."""
         m = self.model
         plan.host(self.reducer.reset)
+        if self.measure_comm and self.reducer.active:
+            def mark_backward_start():
+                self.reducer.measure = True
+                self.bwd_start_event = torch.cuda.Event(enable_timing=True)
+                self.bwd_start_event.record()
+            plan.host(mark_backward_start)
         T['wgrad_stream'] = self.wgrad_stream
         T['main_stream'] = main
         T['mark'] = self._mark if self.marks is not None else None

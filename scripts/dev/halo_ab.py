@@ -1,0 +1,36 @@
+"""dev: the halo kernel's ring depth A/B (tuning library: RGDA_HALO_NS = 3 | 4), isolated launches on rotating buffers.
+Prints us per launch and TFLOP/s per geometry, and checks that both depths give the same bits."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from regda_amd import ops
+BF = torch.bfloat16
+GEOMS = [(16, 32, 32, 2048, 512, 1, 'head 2048->512'), (16, 32, 32, 512, 512, 1, 'layer4 512->512'),
+         (16, 32, 32, 256, 256, 1, 'layer3 256->256'), (8, 32, 32, 2048, 512, 1, 'teacher head'), (8, 32, 32, 256, 256, 1, 'teacher layer3'),
+         (16, 32, 32, 512, 512, 2, 'layer4 dil2')]
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+for N, H, W, Ci, Co, d, name in GEOMS:
+    M = N * H * W
+    xs = [torch.randn(M, Ci, device='cuda').to(BF) for _ in range(4)]
+    w = (torch.randn(Co, 9, Ci, device='cuda') * 0.05).to(BF)
+    ys = [torch.empty(M, Co, dtype=BF, device='cuda') for _ in range(4)]
+    out = {}
+    for mode in (0, 1):
+        for ns in ('3', '4'):
+            os.environ['RGDA_HALO_NS'] = ns
+            for i in range(3):
+                ops.conv2d(xs[i % 4], w, ys[i % 4], N, H, W, H, W, 3, 3, 1, d, d, mode)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(reps):
+                ops.conv2d(xs[i % 4], w, ys[i % 4], N, H, W, H, W, 3, 3, 1, d, d, mode)
+            e1.record(); torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps
+            ops.conv2d(xs[0], w, ys[0], N, H, W, H, W, 3, 3, 1, d, d, mode)
+            torch.cuda.synchronize()
+            out[(mode, ns)] = (t, ys[0].clone())
+        same = torch.equal(out[(mode, '3')][1], out[(mode, '4')][1])
+        print('%-18s mode %d  NS3 %.1f us %.0f TF/s | NS4 %.1f us %.0f TF/s | same bits %s' % (
+            name, mode, out[(mode, '3')][0] * 1e3, 2.0 * M * Co * Ci * 9 / out[(mode, '3')][0] / 1e9,
+            out[(mode, '4')][0] * 1e3, 2.0 * M * Co * Ci * 9 / out[(mode, '4')][0] / 1e9, same), flush=True)

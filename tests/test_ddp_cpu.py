@@ -141,6 +141,141 @@ def test_flat_grad_reducer_gloo_world2():
     assert all(nb >= 3 for _, _, nb in res)
 
 
+def _guarded(target, rank, world, port, q):
+    try:
+        target(rank, world, port, q)
+    except BaseException as e:          # a worker that dies must not leave the parent waiting for the queue
+        import traceback
+        q.put((rank, False, 'worker failed: ' + traceback.format_exc()[-1500:]))
+        raise e
+
+
+def _spawn(target, world=2, timeout=300):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_guarded, args=(target, r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    return sorted(res)
+
+
+def _worker_prototypes(rank, world, port, q):
+    """ranks exchange the SUFFICIENT STATISTICS of update_prototype; the result is the reference's update on
+    the concatenated batch (regda/gast/alignment.py:300-327), also for a class only one rank sees."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import numpy as np
+    from oracle import labelpath as opath, labels as olab
+    from regda_amd.ddp import all_reduce_prototype_statistics
+    C, K, b, h, w = 6, 96, 2, 4, 4
+    g = torch.Generator().manual_seed(100)
+    protos = torch.randn(C, K, generator=g)
+
+    def batch(r):
+        gr = torch.Generator().manual_seed(200 + r)
+        feat = torch.randn(b, K, h, w, generator=gr)
+        cells = torch.randint(-1, C, (b, h, w), generator=gr)
+        # class 3 only on rank 1, class 4 on nobody, class 5 only on rank 0 (a single cell)
+        cells[cells == 4] = 0
+        cells[cells == (3 if r == 0 else 5)] = 1
+        if r == 0:
+            cells[0, 0, 0] = 5
+        label = cells.repeat_interleave(16, 1).repeat_interleave(16, 2).contiguous()      # (b, 16h, 16w): pure cells
+        return feat, label
+    feat, label = batch(rank)
+    ds = torch.from_numpy(olab.downscale_label(label.numpy(), 16, C, -1, 0.75))
+    sums, cnt = opath.prototype_statistics(feat, ds, C, -1)
+    stats = torch.cat([sums.reshape(-1), cnt, torch.zeros(4)]).contiguous()             # the layout rgda_proto_stats leaves
+    all_reduce_prototype_statistics(stats, C, K)
+    new = opath.apply_prototype_statistics(protos, stats[:C * K].view(C, K), stats[C * K:C * K + C], 0.996)
+    # the reference on the concatenated global batch
+    fs, ls = zip(*[batch(r) for r in range(world)])
+    want, _ = opath.update_prototype(torch.cat(fs), torch.cat(ls), protos, 0.996, C, -1)
+    ok = torch.allclose(new, want, rtol=1e-6, atol=1e-6)
+    ok = ok and torch.equal(new[4], 0.996 * protos[4] + (1.0 - 0.996) * protos[4])     # a class nobody has: the old prototype
+    # what the round-4 build did (average of per-rank updates) is a different number for the one-rank classes
+    mine, _ = opath.update_prototype(feat, label, protos, 0.996, C, -1)
+    avg = mine.clone()
+    dist.all_reduce(avg)
+    avg /= world
+    differs = not torch.allclose(avg[3], want[3], rtol=1e-4, atol=1e-6) and not torch.allclose(avg[5], want[5], rtol=1e-4, atol=1e-6)
+    # identical bits on every rank
+    others = [torch.zeros_like(new) for _ in range(world)]
+    dist.all_gather(others, new)
+    same = all(torch.equal(o, new) for o in others)
+    q.put((rank, bool(ok), bool(differs), bool(same)))
+    dist.destroy_process_group()
+
+
+def test_prototype_statistics_exchange_equals_the_global_batch_gloo_world2():
+    res = _spawn(_worker_prototypes)
+    assert all(len(r) == 4 and r[1] and r[2] and r[3] for r in res), res
+
+
+def _worker_overlap(rank, world, port, q):
+    """The overlap bookkeeping with real data: two ranks run the oracle's backward on two DIFFERENT batches; the flat
+    gradient is filled in the order backward finalises it and `ready_down_to` is called at exactly the offsets
+    `Deeplabv2._backward_plan` reports (Encoder.backward_progress_offsets), buckets cut at the model's boundaries.  A bucket
+    issued before its gradients are final would reduce the NaN poison."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(4)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import model as omodel
+    from oracle.step import CpuStep
+    from regda_amd.models import Encoder as E
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    E.LAYERS.setdefault(rt, omodel.LAYERS[rt])
+    lay = E.flat_layout(rt, 'ppm', 6)
+    total = lay.pop('__total__')[0]
+    sd = omodel.init_state_dict(rt, 6, seed=3)
+    b = make_batch(b=2, size=64, seed=40 + rank, device='cpu')                 # a different batch on every rank
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
+    masks = (torch.ones(2, 512), torch.ones(2, 512))
+    out = CpuStep(sd, protos, rt).step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], masks, masks)
+
+    def phys(name, g):                                           # conv weights lie [Cout][kh][kw][Cin] in the flat buffers
+        return (g.permute(0, 2, 3, 1) if g.dim() == 4 else g).reshape(-1)
+    single = torch.zeros(total)
+    for name, (off, n) in lay.items():
+        single[off:off + n] = phys(name, out['grads'][name])
+    flat = torch.zeros(total)
+    for name, (off, n) in lay.items():
+        flat[off:off + n] = float('nan')                         # not produced yet
+    red = FlatGradReducer(flat, E.bucket_boundaries(rt, 'ppm', 6), bucket_elems=total // 7)
+    red.reset()
+    pending = sorted(lay.items(), key=lambda kv: -kv[1][0])      # backward finalises the buffer from its END
+    issued_at = []
+    for off in E.backward_progress_offsets(rt, 'ppm', 6):
+        while pending and pending[0][1][0] >= off:
+            name, (o, n) = pending.pop(0)
+            flat[o:o + n] = single[o:o + n]
+        before = red._next
+        red.ready_down_to(off)
+        issued_at += [(off, red.buckets[i]) for i in range(before, red._next)]
+    for name, (o, n) in pending:                                 # the stem: final when backward returns
+        flat[o:o + n] = single[o:o + n]
+    red.finish()
+    singles = [torch.zeros(total) for _ in range(world)]
+    dist.all_gather(singles, single)
+    ok = torch.equal(flat, singles[0] + singles[1])              # fp32 all-reduce of two ranks: bit for bit
+    ok = ok and torch.equal(flat * red.gscale, (singles[0] + singles[1]) * 0.5)          # the mean the optimizer applies
+    ok = ok and not torch.equal(singles[0], singles[1]) and bool(torch.isfinite(flat).all())
+    ok = ok and all(a >= off for off, (a, _) in issued_at) and len(issued_at) >= 2        # something WAS issued during backward
+    q.put((rank, bool(ok), len(red.buckets), len(issued_at)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_reduce_at_the_real_backward_offsets_gloo_world2():
+    res = _spawn(_worker_overlap)
+    assert all(len(r) == 4 and r[1] for r in res), res
+    assert all(r[2] >= 4 for r in res), res
+
+
 def test_single_process_reducer_is_a_noop():
     flat = torch.arange(10.0)
     red = FlatGradReducer(flat, [5], bucket_elems=2)

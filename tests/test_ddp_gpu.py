@@ -81,7 +81,50 @@ def test_forced_rccl_step_equals_plain_step(nccl_world1):
         cos = (mm.flat_g @ m0.flat_g / (mm.flat_g.norm() * m0.flat_g.norm())).item()
         assert cos > 0.97 and abs(mm.flat_g.norm().item() / m0.flat_g.norm().item() - 1) < 0.05     # (0.989 .. 0.998 seen)
         assert ((mm.flat_p - m0.flat_p).norm() / m0.flat_p.norm()).item() < 1e-4
-    assert ((st1.prototypes - st0.prototypes).norm() / st0.prototypes.norm()).item() < 2e-3
+    # the prototype exchange (statistics -> all-reduce -> apply) at one rank IS update_prototype: same kernels, same bits
+    assert st1.proto_stats is not None and st0.proto_stats is None
+    assert torch.equal(st1.prototypes, st0.prototypes)
+
+
+def test_prototype_statistics_of_two_half_batches_give_the_global_batch_update():
+    """SURVEY.md 8e through the C ABI: rgda_proto_stats on two halves of a batch, summed (what the all-reduce does), then
+    rgda_proto_apply == rgda_proto_update on the whole batch == the oracle's update_prototype on it
+    (regda/gast/alignment.py:300-327) -- including a class that only one half contains and a class nobody has."""
+    from oracle import labelpath as opath
+    from regda_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, K, h, w, C = 4, 2048, 8, 8, 6
+    feat = torch.randn(b, K, h, w, generator=g).cuda()
+    cells = torch.randint(-1, C, (b, h, w), generator=g)
+    cells[cells == 4] = 0                       # class 4: nobody
+    cells[:2][cells[:2] == 3] = 1               # class 3: second half only
+    label = cells.repeat_interleave(16, 1).repeat_interleave(16, 2).contiguous().cuda()
+    protos0 = torch.randn(C, K, generator=g).cuda()
+    whole = protos0.clone()
+    ds = ops.proto_update(feat, label, whole, 16, -1, 0.75, 0.996)
+    # stats + apply on the whole batch: the same two kernels, the same bits
+    st, ds2 = ops.proto_stats(feat, label)
+    one = protos0.clone()
+    ops.proto_apply(one, st, 0.996)
+    assert torch.equal(one, whole) and torch.equal(ds, ds2)
+    # two ranks' halves
+    s0, _ = ops.proto_stats(feat[:2].contiguous(), label[:2].contiguous())
+    s1, _ = ops.proto_stats(feat[2:].contiguous(), label[2:].contiguous())
+    n = C * K + C
+    tot = s0.clone()
+    tot[:n] = s0[:n] + s1[:n]
+    assert float(s0[C * K + 3]) == 0 and float(s1[C * K + 3]) > 0 and float(tot[C * K + 4]) == 0
+    two = protos0.clone()
+    ops.proto_apply(two, tot, 0.996)
+    torch.testing.assert_close(two, whole, rtol=1e-6, atol=1e-6)
+    want, _ = opath.update_prototype(feat.cpu(), label.cpu(), protos0.cpu(), 0.996, C, -1)
+    torch.testing.assert_close(two.cpu(), want, rtol=1e-5, atol=1e-6)
+    assert torch.equal(two[4], whole[4])
+    # the average of per-rank updates (the round-4 exchange) is NOT that number for the one-rank class
+    r0, r1 = protos0.clone(), protos0.clone()
+    ops.proto_update(feat[:2].contiguous(), label[:2].contiguous(), r0, 16, -1, 0.75, 0.996)
+    ops.proto_update(feat[2:].contiguous(), label[2:].contiguous(), r1, 16, -1, 0.75, 0.996)
+    assert not torch.allclose(0.5 * (r0 + r1)[3], whole[3], rtol=1e-4, atol=1e-6)
 
 
 def test_class_balance_counts_go_through_the_process_group(nccl_world1):
@@ -97,7 +140,7 @@ def test_class_balance_counts_go_through_the_process_group(nccl_world1):
 
 def test_recorded_plan_replays_the_collectives(nccl_world1):
     """The multi-GPU step as a recorded launch plan (bench.py's default at every world size): the bucketed gradient
-    all-reduces, their stream waits and the prototype average are host actions of the plan and are re-issued by every
+    all-reduces, their stream waits and the prototype-statistics all-reduce are host actions of the plan and are re-issued by every
     replay -- counted here through the reducer, and the replayed steps track the eager ones."""
     import torch.distributed as dist_mod
     from regda_amd.models.Encoder import Deeplabv2
@@ -141,7 +184,7 @@ def test_recorded_plan_replays_the_collectives(nccl_world1):
         n_plan = len(calls)
     finally:
         dist_mod.all_reduce = real
-    per_step = len(st_e.reducer.buckets) + 1                    # gradient buckets + the prototype average
+    per_step = len(st_e.reducer.buckets) + 1                    # gradient buckets + the prototype statistics
     assert per_step >= 4 and n_eager == 4 * per_step
     assert st_p._plan is not None and n_plan == n_eager         # every replay issued every collective again
     for oe, op in zip(out_e, out_p):

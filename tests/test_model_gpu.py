@@ -476,3 +476,43 @@ def test_resnet101_layerwise_forward_bound():
 def unpack_bits(mask, C):
     bits = (mask.cpu().unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1
     return bits.reshape(mask.shape[0], C).bool()
+@pytest.mark.gpu
+def test_weight_gradient_flush_per_layer_waits_for_the_small_map_batchnorm_backward():
+    """A flush of the queued weight gradients must not fire between a PPM branch unit being QUEUED for the small-map
+    BatchNorm backward (which writes its `dc`, the weight gradient's operand) and that launch: with one flush per layer
+    (wgrad_group_gflop = 0), the default grouping and no weight-gradient stream, every gradient -- the branch convolutions'
+    in particular -- equals the run with 500-GFLOP groups and the run through the general BatchNorm kernels."""
+    rt = 'resnet17t'
+    sd = omodel.init_state_dict(rt, 6, seed=4)
+    gen = torch.Generator().manual_seed(23)
+    x = [torch.randn(2, 3, 64, 64, generator=gen).cuda(), torch.randn(2, 3, 64, 64, generator=gen).cuda()]
+    g1, g2 = torch.randn(4, 6, 4, 4, generator=gen).cuda(), torch.randn(4, 6, 4, 4, generator=gen).cuda()
+    ones = torch.ones(2, 512)
+    out = []
+    for gflop, small in ((0.0, True), (500.0, True), (0.0, False)):
+        m = build(rt)
+        m.wgrad_group_gflop = gflop
+        m.small_bn = small
+        assert m.group_small_convs
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        m.set_drop_masks(ones, ones)
+        m.flat_g.zero_()
+        T = m.new_tape(groups=2)
+        assert T.get('wgrad_stream') is None
+        with torch.no_grad():
+            m._forward_plan(x, T)
+            m._backward_plan(T, g1, g2)
+        torch.cuda.synchronize()
+        out.append({k: v.clone() for k, v in m._gviews.items()})
+    per_layer, grouped, general = out
+    names = [k for k in per_layer if '.ppm.' in k and k.endswith('.1.weight')]
+    assert len(names) == 8
+    for k in per_layer:
+        a, b = per_layer[k].float(), grouped[k].float()
+        assert l2(a, b) < 1e-5, k                        # same operands, another split of the pixel sum at most
+    for k in names:
+        assert float(per_layer[k].abs().sum()) > 0
+        assert l2(per_layer[k].float(), general[k].float()) < 2e-2, k      # another BatchNorm summation order (bf16 dc)
+
+

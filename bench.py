@@ -299,8 +299,12 @@ def cpu_baseline(args):
     batch = make_batch(b=b, size=args.size, seed=2333, device='cpu')
     sd = omodel.init_state_dict(args.model, 6, seed=0)
     protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
-    st = CpuStep(sd, protos, resnet_type=args.model)
-    run = lambda: st.step(batch['images_s'], batch['label_s'], batch['images_t'], batch['soft_t'], batch['regs_t'], lr=1e-4)
+    # the same work as the GPU leg: with the online EMA teacher (the default) the soft target labels come from the
+    # teacher's eval forward on the shadow weights inside the step, and the shadow is updated behind the optimizer
+    teacher = not args.no_teacher
+    st = CpuStep(sd, protos, resnet_type=args.model, ema_decay=0.999 if teacher else None)
+    soft_in = None if teacher else batch['soft_t']
+    run = lambda: st.step(batch['images_s'], batch['label_s'], batch['images_t'], soft_in, batch['regs_t'], lr=1e-4)
     t0 = time.time()
     run()
     warm = time.time() - t0
@@ -308,7 +312,7 @@ def cpu_baseline(args):
     phases = {}
     while n < 1 or (time.time() - t0 < 15.0 and n < 5):
         ph = {}
-        st.step(batch['images_s'], batch['label_s'], batch['images_t'], batch['soft_t'], batch['regs_t'], lr=1e-4, phases=ph)
+        st.step(batch['images_s'], batch['label_s'], batch['images_t'], soft_in, batch['regs_t'], lr=1e-4, phases=ph)
         for k, v in ph.items():
             phases[k] = phases.get(k, 0.0) + v
         n += 1
@@ -323,7 +327,7 @@ def cpu_baseline(args):
     return dict(value=b / dt, unit='pairs/s', cores=threads, threads=threads, kind='port', host=limits,
                 s_per_step=dt, phases_s={k: v / n for k, v in phases.items()},
                 s_per_step_8_threads=probe,
-                sample=f'oracle/step.py (stock PyTorch CPU fp32, offline soft labels), {args.model}, b={b}+{b} {args.size}x{args.size}, '
+                sample=f'oracle/step.py (stock PyTorch CPU fp32, ' + ('online EMA teacher: eval forward + shadow update inside the step' if teacher else 'offline soft labels') + f'), {args.model}, b={b}+{b} {args.size}x{args.size}, '
                        f'{n} timed step(s) after 1 warm-up ({warm:.1f}s), {dt:.2f} s/step on {threads} threads '
                        f'(= physical cores of one socket within affinity / cgroup quota)')
 

@@ -127,6 +127,58 @@ def aspp_head(x, weights, biases, dilations=ASPP_DILATIONS):
     return out
 
 
+def bottleneck(y, sd, spec, training=True, new_stats=None, rb=lambda t: t):
+    """One bottleneck block, regda/_resnets.py:92-112 (conv1 -> bn1 -> relu -> conv2 -> bn2 -> relu -> conv3 -> bn3,
+    + identity / downsample, relu).  spec: a row of layer_specs(); rb: the rounding applied where the HIP path stores bf16
+    (identity for the fp32 reference semantics).  `forward` is made of these; the per-unit GPU test calls them directly."""
+    p, inpl, planes, stride, dil, ds = spec
+    idt = y
+    o = rb(F.conv2d(y, sd[p + '.conv1.weight']))
+    o = rb(F.relu(_bn(o, sd, p + '.bn1', training, new_stats)))
+    o = rb(F.conv2d(o, sd[p + '.conv2.weight'], None, stride, dil, dil))
+    o = rb(F.relu(_bn(o, sd, p + '.bn2', training, new_stats)))
+    o = rb(F.conv2d(o, sd[p + '.conv3.weight']))
+    o = _bn(o, sd, p + '.bn3', training, new_stats)
+    if ds:
+        idt = rb(F.conv2d(y, sd[p + '.downsample.0.weight'], None, stride))
+        idt = rb(_bn(idt, sd, p + '.downsample.1', training, new_stats))
+    return rb(F.relu(o + idt))
+
+
+def heads(y, sd, training=True, drop_masks=None, new_stats=None, rb=lambda t: t, tap=lambda name, t: t):
+    """Instance norm + the two heads on the layer-4 output y (regda/models/Encoder.py:8-65,68-84,123,146-151):
+    returns ([logits of layer5, logits of layer6], feat)."""
+    aspp = 'layer5.conv2d_list.0.weight' in sd
+    feat = F.instance_norm(y, eps=1e-5)                       # Encoder.py:123,146-147
+    tap('feat', feat)
+    featq = rb(feat)
+    outs = []
+    for head in (('layer5', 'layer6') if aspp else ()):
+        # Classifier_Module.forward (Encoder.py:80-84): the four dilated 3x3 convs, summed
+        outs.append(aspp_head(featq, [sd[f'{head}.conv2d_list.{i}.weight'] for i in range(len(ASPP_DILATIONS))],
+                              [sd[f'{head}.conv2d_list.{i}.bias'] for i in range(len(ASPP_DILATIONS))]))
+    for hi, head in enumerate(() if aspp else ('layer5', 'layer6')):
+        size = feat.shape[-2:]
+        parts = [featq]
+        for i, s in enumerate(POOL_SCALES):
+            q = rb(F.adaptive_avg_pool2d(featq, s))
+            q = rb(F.conv2d(q, sd[f'{head}.ppm.{i}.1.weight']))
+            q = rb(F.relu(_bn(q, sd, f'{head}.ppm.{i}.2', training, new_stats)))
+            tap(f'{head}.q{i}', q)
+            parts.append(rb(F.interpolate(q, size, mode='bilinear', align_corners=False)))
+        cat = torch.cat(parts, 1)
+        tap(head + '.cat', cat)
+        o = rb(F.conv2d(cat, sd[f'{head}.conv_last.0.weight'], None, 1, 1))
+        o = F.relu(_bn(o, sd, f'{head}.conv_last.1', training, new_stats))
+        if training and drop_masks is not None:
+            o = o * (drop_masks[hi].to(o.dtype) / 0.9)[:, :, None, None]
+        o = rb(o)
+        tap(head + '.hidden', o)
+        o = F.conv2d(o, sd[f'{head}.conv_last.4.weight'], sd[f'{head}.conv_last.4.bias'])
+        outs.append(o)
+    return outs, feat
+
+
 def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_stats=None,
             taps=None, emulate_bf16=False):
     """Train: (x1, x2, feat).  Eval: per-pixel class probabilities at input size.
@@ -161,46 +213,10 @@ def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_
     tap('stem', y)
     y = F.max_pool2d(y, 3, 2, 1)
     tap('pool', y)
-    for p, inpl, planes, stride, dil, ds in layer_specs(resnet_type):
-        idt = y
-        o = rb(F.conv2d(y, sd[p + '.conv1.weight']))
-        o = rb(F.relu(_bn(o, sd, p + '.bn1', training, new_stats)))
-        o = rb(F.conv2d(o, sd[p + '.conv2.weight'], None, stride, dil, dil))
-        o = rb(F.relu(_bn(o, sd, p + '.bn2', training, new_stats)))
-        o = rb(F.conv2d(o, sd[p + '.conv3.weight']))
-        o = _bn(o, sd, p + '.bn3', training, new_stats)
-        if ds:
-            idt = rb(F.conv2d(y, sd[p + '.downsample.0.weight'], None, stride))
-            idt = rb(_bn(idt, sd, p + '.downsample.1', training, new_stats))
-        y = rb(F.relu(o + idt))
-        tap(p, y)
-    feat = F.instance_norm(y, eps=1e-5)                       # Encoder.py:123,146-147
-    tap('feat', feat)
-    featq = rb(feat)
-    outs = []
-    for head in (('layer5', 'layer6') if aspp else ()):
-        # Classifier_Module.forward (Encoder.py:80-84): the four dilated 3x3 convs, summed
-        outs.append(aspp_head(featq, [sd[f'{head}.conv2d_list.{i}.weight'] for i in range(len(ASPP_DILATIONS))],
-                              [sd[f'{head}.conv2d_list.{i}.bias'] for i in range(len(ASPP_DILATIONS))]))
-    for hi, head in enumerate(() if aspp else ('layer5', 'layer6')):
-        size = feat.shape[-2:]
-        parts = [featq]
-        for i, s in enumerate(POOL_SCALES):
-            q = rb(F.adaptive_avg_pool2d(featq, s))
-            q = rb(F.conv2d(q, sd[f'{head}.ppm.{i}.1.weight']))
-            q = rb(F.relu(_bn(q, sd, f'{head}.ppm.{i}.2', training, new_stats)))
-            tap(f'{head}.q{i}', q)
-            parts.append(rb(F.interpolate(q, size, mode='bilinear', align_corners=False)))
-        cat = torch.cat(parts, 1)
-        tap(head + '.cat', cat)
-        o = rb(F.conv2d(cat, sd[f'{head}.conv_last.0.weight'], None, 1, 1))
-        o = F.relu(_bn(o, sd, f'{head}.conv_last.1', training, new_stats))
-        if training and drop_masks is not None:
-            o = o * (drop_masks[hi].to(o.dtype) / 0.9)[:, :, None, None]
-        o = rb(o)
-        tap(head + '.hidden', o)
-        o = F.conv2d(o, sd[f'{head}.conv_last.4.weight'], sd[f'{head}.conv_last.4.bias'])
-        outs.append(o)
+    for spec in layer_specs(resnet_type):
+        y = bottleneck(y, sd, spec, training, new_stats, rb)
+        tap(spec[0], y)
+    outs, feat = heads(y, sd, training, drop_masks, new_stats, rb, tap)
     if training:
         return outs[0], outs[1], feat
     x1 = F.interpolate(outs[0], x.shape[-2:], mode='bilinear', align_corners=True)

@@ -14,7 +14,7 @@ class CpuStep:
     def __init__(self, sd, prototypes, resnet_type='resnet101', class_num=6, ignore_label=-1,
                  lr=1e-2, momentum=0.9, weight_decay=5e-4, max_norm=32.0,
                  cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996,
-                 refine_temp=2.0, sam_refine=True, balancer_s=None, balancer_t=None, emulate_bf16=False):
+                 refine_temp=2.0, sam_refine=True, balancer_s=None, balancer_t=None, emulate_bf16=False, ema_decay=None):
         # balancer_s / balancer_t: labelpath.ClassBalanceState (--bcs / --bct, train_ssl_reg.py:125-158) or None
         self.balancer_s, self.balancer_t = balancer_s, balancer_t
         # emulate_bf16: the network rounds to bf16 where the HIP path stores bf16 (oracle/model.py: forward); fp32
@@ -32,12 +32,26 @@ class CpuStep:
         self.lr, self.m, self.wd, self.max_norm = lr, momentum, weight_decay, max_norm
         self.top, self.low, self.percent = cutoff_top, cutoff_low, percent
         self.pdecay, self.temp, self.sam = proto_decay, refine_temp, sam_refine
+        # ema_decay: the ONLINE EMA teacher (BASELINE.json north_star; regda/utils/ema.py:34-51).  register(): the shadow
+        # starts as a copy of the parameters (:44-47); `step(soft_t=None)` takes the target soft labels from the teacher's
+        # eval forward (Encoder.py:152-155: (softmax(up x1) + softmax(up x2)) / 2) on the shadow weights with the
+        # student's BatchNorm buffers as they stand at the START of the step (ema.py averages parameters only), and
+        # update() (:49-54) follows the optimizer: shadow = (1 - d) * param + d * shadow
+        self.ema_decay = ema_decay
+        self.shadow = None if ema_decay is None else {k: self.sd[k].detach().clone() for k in self.names}
 
     def step(self, images_s, label_s, images_t, soft_t, regs_t, drop_masks_s=None, drop_masks_t=None,
              lr=None, phases=None):
         import time
         t0 = time.time()
         sd = self.sd
+        if soft_t is None:
+            assert self.shadow is not None, 'soft_t=None needs the online teacher (ema_decay=...)'
+            with torch.no_grad():
+                tsd = {k: (self.shadow[k] if k in self.shadow else v.detach()) for k, v in sd.items()}
+                soft_t = model.forward(tsd, images_t, False, None, self.rt, emulate_bf16=self.emulate_bf16)
+            self.last_soft_t = soft_t
+        t_teacher = time.time()
         ns = {}
         s1, s2, feat_s = model.forward(sd, images_s, True, drop_masks_s, self.rt, ns, emulate_bf16=self.emulate_bf16)
         for k, v in ns.items():
@@ -75,9 +89,11 @@ class CpuStep:
                 else:
                     self.mom[k].mul_(self.m).add_(d)
                 p.sub_(lr * self.mom[k])
+                if self.shadow is not None:                                     # ema.update(), ema.py:49-54
+                    self.shadow[k] = (1.0 - self.ema_decay) * p.detach() + self.ema_decay * self.shadow[k]
         t_opt = time.time()
         if phases is not None:
-            phases.update(fwd=t_fwd - t0, label=t_lab - t_fwd, bwd=t_bwd - t_lab, opt=t_opt - t_bwd)
+            phases.update(teacher=t_teacher - t0, fwd=t_fwd - t_teacher, label=t_lab - t_fwd, bwd=t_bwd - t_lab, opt=t_opt - t_bwd)
         return dict(loss=float(loss.detach()), loss_source=float(loss_s.detach()), loss_target=float(loss_t.detach()),
                     grad_norm=float(total), hard=hard, soft=soft, grads=dict(zip(self.names, grads)),
                     preds=(s1.detach(), s2.detach(), t1.detach(), t2.detach()),

@@ -631,6 +631,8 @@ static __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const 
                     for (int j = 0; j < FJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
         };
+        // (spreading each half's fragment reads between the other half's MFMAs with sched_group_barrier, what pays in
+        // conv3x3_halo_kernel<.., NS = 4>, measured no different here: round 5, scripts/dev/iso_set.py)
         read_half(0, 0);
         // (the last tile is peeled: a branch around the barrier block would merge two different LDS-counter states
         // and make the compiler wait for the NEXT tile's fragments before this tile's second half)
@@ -940,11 +942,14 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
             const int q = sl * 9 + tp;
             // everything but the previous step's DMA instructions has landed: weight tile q + 1 (and, with the barrier, every
             // wave's part of it); in flight: tile q + 2 and the halo piece of step tp - 1
-            if (tp >= 1 && tp - 1 < PXW) WAIT_VMCNT(3); else WAIT_VMCNT(2);
+            // (tuning builds, timing only: skip bit 1 = no DMA inside the loop, 2 = no vmcnt wait, 4 = no barrier)
+            if (!(TSKIP(a) & 2)) { if (tp >= 1 && tp - 1 < PXW) WAIT_VMCNT(3); else WAIT_VMCNT(2); }
             if constexpr (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the previous step's in-place transform
-            __builtin_amdgcn_s_barrier();
+            if (!(TSKIP(a) & 4)) __builtin_amdgcn_s_barrier();
+            if (!(TSKIP(a) & 1)) {
             issue_w2((tp + 3) % 9, sl + (tp + 3) / 9, wstage >= 1 ? wstage - 1 : 3, q + 3 < KT);
             if (tp < PXW) issue_h(sl + 1, tp, more);
+            }
             if constexpr (XF) {
                 if (more) {
                     if (tp == 1) xf_load(sl + 1);
@@ -2508,6 +2513,8 @@ static __device__ __forceinline__ void conv_wgrad3x3_body(const WgradGroup& g) {
                         acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[kh * 3 + kw], 0, 0, 0);
                     }
             }
+            // (the tile's 80 transposing reads spread between its 36 MFMAs by sched_group_barrier: measured no faster, and
+            // 12 - 20 % slower for the dilated layers -- round 5)
             stage = (stage == STAGES - 1) ? 0 : stage + 1;
         }
     }

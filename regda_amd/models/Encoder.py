@@ -1141,6 +1141,54 @@ class Deeplabv2(nn.Module):
         T['stem'] = (col, c, y, mi, (N, H, W, H1, W1), None, rmask)
         return y, col_ready
 
+    def _block_fwd(self, T, blk, y, N, h, w, main_stream, bs=None):
+        """One bottleneck block (regda/_resnets.py:92-112) on the pixel-major map y [N*h*w][inplanes]: returns (out, h', w').
+        bs: the stream a downsample branch runs on next to conv1 .. conv3 (None: the current one)."""
+        C, B = self.convs, self.bns
+        p, inpl, planes, stride, dil, ds = blk
+        idt = y
+        joined = None
+        if ds:
+            if bs is not None:
+                plan.wait_event(bs, plan.record_event(main_stream))
+            with (ops.use_stream(bs) if bs is not None else contextlib.nullcontext()):
+                idt, _, _ = self._cbr_fwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], y, N, h, w,
+                                          False)
+                if bs is not None:
+                    joined = plan.record_event(bs)
+        # bn1 / bn2 (+ ReLU) are deferred to the next convolution's operand path (training; see bn_on_operand)
+        a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True,
+                                 defer='bn1' in self.bn_operand_units)
+        a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True,
+                                   defer='bn2' in self.bn_operand_units)
+        if joined is not None:
+            plan.wait_event(main_stream, joined)
+        y, _, _ = self._cbr_fwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], a2, N, h2, w2, True, res=idt)
+        return y, h2, w2
+
+    def _block_bwd(self, T, blk, g, below):
+        """Backward of one bottleneck block: g = d loss / d (block output) [N*h'*w'][4 planes] -> d loss / d (block input).
+        below: (tape key, relu) of the unit that consumes the returned gradient (bn3 of the block before; None: the stem
+        side), whose BatchNorm-backward reduction is folded into conv1's data-gradient epilogue."""
+        C, B = self.convs, self.bns
+        p, inpl, planes, stride, dil, ds = blk
+        # identity blocks: the skip-path gradient g * [y3 > 0] is never written -- conv1's data-gradient epilogue
+        # adds g gated by bn3's ReLU sign mask (when the unit kept one)
+        g3, m3 = g, T[p + '.3'][6]
+        gate_in_epilogue = (not ds) and (m3 is not None)
+        da2, gm = self._cbr_bwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], g, True,
+                                want_gmask=not gate_in_epilogue, consumer=(p + '.2', True))
+        da1, _ = self._cbr_bwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], da2, True, consumer=(p + '.1', True))
+        if ds:
+            dxd, _ = self._cbr_bwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], gm, False)
+            g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=dxd, consumer=below)
+        elif gate_in_epilogue:
+            g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=g3,
+                                 dx_res_mask=m3, consumer=below)
+        else:
+            g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm, consumer=below)
+        return g
+
     # ------------------------------------------------------------------ forward plan
     def _forward_plan(self, x, T):
         """x: one NCHW image batch, or a list of equally shaped batches that run through the network together
@@ -1184,28 +1232,18 @@ class Deeplabv2(nn.Module):
             if self._head_stream is None:
                 self._head_stream = torch.cuda.Stream(device=dev)
             bs = self._head_stream
-        for p, inpl, planes, stride, dil, ds in self.blocks:
-            idt = y
-            joined = None
-            if ds:
-                if bs is not None:
-                    plan.wait_event(bs, plan.record_event(main_stream))
-                with (ops.use_stream(bs) if bs is not None else contextlib.nullcontext()):
-                    idt, _, _ = self._cbr_fwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], y, N, h, w,
-                                              False)
-                    if bs is not None:
-                        joined = plan.record_event(bs)
-            # bn1 / bn2 (+ ReLU) are deferred to the next convolution's operand path (training; see bn_on_operand)
-            a1, _, _ = self._cbr_fwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], y, N, h, w, True,
-                                     defer='bn1' in self.bn_operand_units)
-            a2, h2, w2 = self._cbr_fwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], a1, N, h, w, True,
-                                       defer='bn2' in self.bn_operand_units)
-            if joined is not None:
-                plan.wait_event(main_stream, joined)
-            y, _, _ = self._cbr_fwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], a2, N, h2, w2, True, res=idt)
-            h, w = h2, w2
+        for blk in self.blocks:
+            y, h, w = self._block_fwd(T, blk, y, N, h, w, main_stream, bs)
             if dbg is not None:
-                dbg[p] = y.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
+                dbg[blk[0]] = y.float().reshape(N, h, w, -1).permute(0, 3, 1, 2)
+        return self._heads_fwd(T, y, N, h, w, main_stream, col_ready)
+
+    def _heads_fwd(self, T, y, N, h, w, main_stream, col_ready=None):
+        """Instance norm + the two heads (regda/models/Encoder.py:123,146-155) on the pixel-major layer-4 output
+        y [N*h*w][2048]: returns (logits of layer5, logits of layer6, feat); T = None: eval (no tape, no dropout)."""
+        dev = self.device
+        C, B = self.convs, self.bns
+        dbg = getattr(self, '_debug_taps', None)
         HW, M = h * w, N * h * w
         xn = torch.empty(M, 2048, dtype=BF, device=dev)          # instance-normalised features, shared by both heads
         feat = torch.empty(N, 2048, h, w, device=dev) if T is not None else None   # eval returns probabilities only
@@ -1327,21 +1365,16 @@ class Deeplabv2(nn.Module):
             T['out_shape'] = tuple(logits[0].shape)
         return logits[0], logits[1], feat
 
-    # ------------------------------------------------------------------ backward plan
-    def _backward_plan(self, T, g1, g2, on_progress=None, gfeat=None):
-        """g1, g2: d(loss)/d(logits) of the two heads (N, classes, h, w) f32.  gfeat (optional): d(loss)/d(feat) of the
-        third forward output, bf16 pixel-major [N*h*w, 2048] -- the stage-2 prototype loss acts on the features."""
-        dev = self.device
-        bwd_stream = torch.cuda.current_stream()
-
-        def wait_transposed_weights():                         # transposed weights rebuilt on another stream
-            if getattr(self, '_wt_ready', None) is not None:
-                bwd_stream.wait_event(self._wt_ready)
-                self._wt_ready = None
-        plan.host(wait_transposed_weights)
+    def _begin_backward(self, T, on_progress=None):
+        """Per-step state of a backward pass on tape T (the queue of pending weight gradients, the statistic arena)."""
         T['on_progress'] = on_progress
         T['wgrad_pending'], T['wgrad_pending_flop'], T['wgrad_post'] = [], 0.0, []
         T['sums_pool'] = T['sums_pool_next']
+
+    def _heads_bwd(self, T, g1, g2, gfeat, bwd_stream):
+        """Backward of the two heads and the instance norm: d loss / d logits (N, classes, h, w) f32 of the two heads
+        (+ optional d loss / d feat, bf16 pixel-major) -> d loss / d (layer-4 output), pixel-major bf16 [N*h*w][2048]."""
+        dev = self.device
         C, B = self.convs, self.bns
         y4, imi, (N, h, w) = T['inorm']
         HW, M = h * w, N * h * w
@@ -1434,6 +1467,28 @@ class Deeplabv2(nn.Module):
             g = torch.empty(M, 2048, dtype=BF, device=dev)
             ops.instnorm_bwd(dfeat, gfeat, gpool, y4, imi, g, N, HW, 2048)
             del dfeat, gpool
+        return g
+
+    # ------------------------------------------------------------------ backward plan
+    def _backward_plan(self, T, g1, g2, on_progress=None, gfeat=None):
+        """g1, g2: d(loss)/d(logits) of the two heads (N, classes, h, w) f32.  gfeat (optional): d(loss)/d(feat) of the
+        third forward output, bf16 pixel-major [N*h*w, 2048] -- the stage-2 prototype loss acts on the features."""
+        dev = self.device
+        bwd_stream = torch.cuda.current_stream()
+
+        def wait_transposed_weights():                         # transposed weights rebuilt on another stream
+            if getattr(self, '_wt_ready', None) is not None:
+                bwd_stream.wait_event(self._wt_ready)
+                self._wt_ready = None
+        plan.host(wait_transposed_weights)
+        self._begin_backward(T, on_progress)
+        g = self._heads_bwd(T, g1, g2, gfeat, bwd_stream)
+        C, B = self.convs, self.bns
+        _, _, (N, h, w) = T['inorm']
+        dbg = getattr(self, '_debug_grads', None)
+
+        def nchw(t, hh, ww):
+            return t.float().reshape(N, hh, ww, -1).permute(0, 3, 1, 2)
         self._progress(T, self._offset_of('layer5.' + self._head_first))
         hh, ww = h, w
         order = [b[0] for b in self.blocks]
@@ -1444,21 +1499,7 @@ class Deeplabv2(nn.Module):
                 hh, ww = hh * stride, ww * stride
             # the gradient that leaves this block is consumed by bn3 of the block above it in the net
             below = (order[bi - 1] + '.3', True) if bi > 0 else None
-            # identity blocks: the skip-path gradient g * [y3 > 0] is never written -- conv1's data-gradient epilogue
-            # adds g gated by bn3's ReLU sign mask (when the unit kept one)
-            g3, m3 = g, T[p + '.3'][6]
-            gate_in_epilogue = (not ds) and (m3 is not None)
-            da2, gm = self._cbr_bwd(T, p + '.3', C[p + '.conv3'], B[p + '.bn3'], g, True,
-                                    want_gmask=not gate_in_epilogue, consumer=(p + '.2', True))
-            da1, _ = self._cbr_bwd(T, p + '.2', C[p + '.conv2'], B[p + '.bn2'], da2, True, consumer=(p + '.1', True))
-            if ds:
-                dxd, _ = self._cbr_bwd(T, p + '.d', C[p + '.downsample.0'], B[p + '.downsample.1'], gm, False)
-                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=dxd, consumer=below)
-            elif gate_in_epilogue:
-                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=g3,
-                                     dx_res_mask=m3, consumer=below)
-            else:
-                g, _ = self._cbr_bwd(T, p + '.1', C[p + '.conv1'], B[p + '.bn1'], da1, True, dx_res=gm, consumer=below)
+            g = self._block_bwd(T, self.blocks[bi], g, below)
             self._progress(T, self._offset_of(p + '.conv1'))
             if bi > 0 and T['wgrad_pending']:
                 stage = p.split('.')[-2]                      # 'encoder.resnet.layerK.i' -> 'layerK'

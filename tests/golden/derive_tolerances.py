@@ -123,6 +123,51 @@ def resnet101_fixture():
     return out
 
 
+def online_inputs(which):
+    """tests/test_ssl_step_gpu.py::test_online_teacher_steps_match_the_oracle_online_steps: two consecutive steps with the
+    ONLINE EMA teacher (soft labels from the teacher's eval forward inside the step, shadow update behind the optimizer;
+    oracle/step.py: CpuStep(ema_decay=)).  'shallow': resnet17t, 4 + 4 images of 128 x 128; 'resnet101': 2 + 2 of 128 x 128."""
+    if which == 'shallow':
+        rt, sd, b, nb = 'resnet17t', omodel.init_state_dict('resnet17t', 6, seed=6), make_batch(b=4, size=128, seed=11, device='cpu'), 4
+    else:
+        rt, sd, b, nb = 'resnet101', omodel.init_state_dict('resnet101', 6, seed=3, res_gamma=0.02), make_batch(b=2, size=128, seed=12, device='cpu'), 2
+    # classifier gain 0.25: about half of the target pixels pass the teacher's 0.6 cut-off and the losses are O(1) (at the
+    # fixtures' gain 1 the logits are +-30, a borderline pixel flips on the last bf16 bit and the target loss is ~10)
+    for head in ('layer5', 'layer6'):
+        sd[f'{head}.conv_last.4.weight'] = sd[f'{head}.conv_last.4.weight'] * ONLINE_CLS_GAIN
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(1))
+    return rt, sd, b, protos, torch.ones(nb, 512)
+
+
+ONLINE_DECAY, ONLINE_LR, ONLINE_STEPS, ONLINE_CLS_GAIN = 0.9, 1e-3, 2, 0.25
+
+
+def online_fixture(which):
+    rt, sd, b, protos, ones = online_inputs(which)
+    res = []
+    for emu in (False, True):
+        cpu = CpuStep(sd, protos, resnet_type=rt, lr=ONLINE_LR, emulate_bf16=('grad' if emu else False), ema_decay=ONLINE_DECAY)
+        outs = []
+        for _ in range(ONLINE_STEPS):
+            o = cpu.step(b['images_s'], b['label_s'], b['images_t'], None, b['regs_t'], (ones, ones), (ones, ones))
+            o['teacher_soft'] = cpu.last_soft_t
+            outs.append(o)
+        res.append((outs, cpu))
+    (ref, cref), (emu, cemu) = res
+    names = ['encoder.resnet.conv1.weight']
+    n = [noise(r, e, names) for r, e in zip(ref, emu)]
+    worst = {k: (min if 'cos' in k else max)(x[k] for x in n) for k in n[0] if not isinstance(n[0][k], dict)}
+    worst['teacher_soft_mean_abs'] = max(float((e['teacher_soft'] - r['teacher_soft']).abs().mean()) for r, e in zip(ref, emu))
+    worst['labelled_fraction'] = min(float((r['hard'] >= 0).float().mean()) for r in ref)
+    worst['protos_rel'] = float((cemu.prototypes - cref.prototypes).norm() / cref.prototypes.norm())
+    k = names[0]
+    # the shadow after two updates, relative to how far it has moved from the initial weights
+    mv = torch.cat([(cref.shadow[q] - sd[q]).flatten() for q in cref.names])
+    dv = torch.cat([(cemu.shadow[q] - cref.shadow[q]).flatten() for q in cref.names])
+    worst['shadow_move_rel'] = float(dv.norm() / mv.norm())
+    return worst
+
+
 TRAJ_STEPS = 20
 
 
@@ -268,6 +313,16 @@ def resnet101_model_fixture():
 
 if __name__ == '__main__':
     torch.set_num_threads(min(16, os.cpu_count() or 1))
+    if len(sys.argv) > 2 and sys.argv[1] == '--only':       # recompute the named fixtures, keep the rest of the table
+        path = os.path.join(HERE, 'bf16_tolerances.json')
+        table = json.load(open(path))
+        fns = {'shallow_online': lambda: online_fixture('shallow'), 'resnet101_online_128': lambda: online_fixture('resnet101')}
+        for name in sys.argv[2:]:
+            table[name] = fns[name]()
+            print(name, json.dumps(table[name], indent=1, sort_keys=True))
+        with open(path, 'w') as f:
+            json.dump(table, f, indent=1, sort_keys=True)
+        sys.exit(0)
     out = {'rule': 'tolerance = max(3 * N, floor); N = |bf16-emulating oracle - fp32 oracle| on the fixture (CPU); '
                    'cosines: 1 - tol_cos = 3 * (1 - N_cos)',
            'factor': 3.0,
@@ -277,6 +332,8 @@ if __name__ == '__main__':
            'resnet101_step_mid': resnet101_mid_fixture(),
            'shallow_trajectory': trajectory_fixture(),
            'resnet101_full': dict(resnet101_full_fixture(FULL_RES_GAMMA), res_gamma=FULL_RES_GAMMA),
+           'shallow_online': online_fixture('shallow'),
+           'resnet101_online_128': online_fixture('resnet101'),
            'shallow_model': shallow_model_fixture(),
            'resnet101_model': resnet101_model_fixture()}
     with open(os.path.join(HERE, 'bf16_tolerances.json'), 'w') as f:

@@ -512,7 +512,152 @@ def test_weight_gradient_flush_per_layer_waits_for_the_small_map_batchnorm_backw
         a, b = per_layer[k].float(), grouped[k].float()
         assert l2(a, b) < 1e-5, k                        # same operands, another split of the pixel sum at most
     for k in names:
-        assert float(per_layer[k].abs().sum()) > 0
+        if '.ppm.0.' not in k:          # (the scale-1 branch's gradient is identically zero on this fixture: its BatchNorm gain is 0)
+            assert float(per_layer[k].abs().sum()) > 0
         assert l2(per_layer[k].float(), general[k].float()) < 2e-2, k      # another BatchNorm summation order (bf16 dc)
 
 
+@pytest.mark.gpu
+def test_every_block_and_the_heads_against_the_oracles_own_tensors_full_size(capsys):
+    """One tight whole-backward check (regda/_resnets.py:92-112, regda/models/Encoder.py:8-65,146-155): ResNet-101 at
+    BASELINE config[0]'s geometry (2 + 2 images of 512 x 512, two BatchNorm groups).  The fp32 oracle runs the two forwards
+    and ONE backward on the CPU and keeps, for every one of the 33 bottleneck blocks and for the heads, the unit's input, its
+    output, the gradient that arrives at its output and the gradient it sends to its input.  Each HIP unit (`_block_fwd` /
+    `_block_bwd`, `_heads_fwd` / `_heads_bwd`: the methods the plans are made of) then gets the ORACLE's input and the ORACLE's
+    upstream gradient, rounded once to bf16 -- nothing a unit sees was produced by another HIP unit, so no depth-compounded
+    noise enters -- and its output, data gradient, weight gradients and BatchNorm gradients are compared with
+
+      (E) the oracle's OWN unit (oracle.model.bottleneck / heads: the functions oracle.model.forward is made of) run on the same
+          tensors with bf16 rounding at the HIP path's storage points (`emulate_bf16='grad'`): relative L2 <= 2 % per
+          quantity of a block, <= 3 % for the heads (measured: <= 0.8 % / 1.5 % for bn3's bias / 2.3 %).  The two round to the same neighbours almost everywhere; a wrong term, sign or scale is 100 %;
+      (F) the fp32 oracle itself: <= 3 N + 0.5 %, N = |E - fp32| of that quantity computed here on the CPU.
+
+    Why (F) cannot be "<= 1.5 %" for every quantity: the ReLU sign of a unit is taken from its STORED (bf16) convolution
+    output; ~0.3 % of the elements lie so close to zero that the rounding flips them, and a flipped element carries its
+    whole gradient as error -- sqrt(0.003) = 5.5 %.  conv3 / bn3 see one such layer (1 - 3 %), conv2 / bn2 two, conv1 / bn1
+    three (6 - 10 %), in the emulating oracle and on the GPU alike (the test prints both columns)."""
+    from oracle import labelpath as opath, labels as olab
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet101'
+    sd = omodel.init_state_dict(rt, 6, seed=5, res_gamma=0.02)
+    b = make_batch(b=2, size=512, seed=77, device='cpu')
+    ones = torch.ones(2, 512)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    names = omodel.param_names(sd)
+    sdr = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    taps = [{}, {}]
+    s1, s2, _ = omodel.forward(sdr, b['images_s'], True, (ones, ones), rt, {}, taps[0])
+    t1, t2, _ = omodel.forward(sdr, b['images_t'], True, (ones, ones), rt, {}, taps[1])
+    hard = torch.from_numpy(olab.pseudo_selection(b['soft_t'].numpy(), 0.8, 0.6, -1))
+    loss = opath.loss_calc([s1, s2], b['label_s'], -1) + opath.loss_calc([t1, t2], hard, -1)
+    specs = omodel.layer_specs(rt)
+    blocks = [sp[0] for sp in specs]
+    keys = ['pool'] + blocks
+    wrt = [sdr[k] for k in names] + [tp[k] for tp in taps for k in keys] + [s1, s2, t1, t2]
+    gr = torch.autograd.grad(loss, wrt)
+    gpar = dict(zip(names, gr[:len(names)]))
+    gtap = [dict(zip(keys, gr[len(names) + d * len(keys):len(names) + (d + 1) * len(keys)])) for d in range(2)]
+    glog = gr[-4:]
+    RB = omodel._RoundBoth.apply
+    sdq = {k: (omodel._rb(v) if (v.dim() == 4 and 'conv_last.4' not in k) else v) for k, v in sd.items()}
+
+    def emu_unit(fn, prefix_ok, xs, gups):
+        """The oracle's unit `fn` with bf16 rounding at the HIP storage points, per BatchNorm group (domain): returns
+        (outputs per domain, dx per domain, parameter gradients summed over the domains)."""
+        pn = [k for k in names if prefix_ok(k)]
+        outs, dxs, gp = [], [], {k: 0.0 for k in pn}
+        for x, gup in zip(xs, gups):
+            w = dict(sdq)
+            for k in pn:
+                w[k] = sdq[k].clone().requires_grad_(True)
+            x = x.detach().clone().requires_grad_(True)
+            out = fn(RB(x), w)
+            o_list = list(out) if isinstance(out, (tuple, list)) else [out]
+            g = torch.autograd.grad(o_list, [x] + [w[k] for k in pn], list(gup) if isinstance(gup, (tuple, list)) else [gup],
+                                    allow_unused=True)
+            outs.append([o.detach() for o in o_list])
+            dxs.append(g[0])
+            for k, gk in zip(pn, g[1:]):
+                if gk is not None:
+                    gp[k] = gp[k] + gk
+        return outs, dxs, gp
+
+    def pxc(a, c):                       # two domains of NCHW fp32 -> one pixel-major bf16 matrix (source rows, then target rows)
+        t = torch.cat([a, c]).detach()
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).to(torch.bfloat16).cuda().contiguous()
+
+    def back(t, n, h, w):                # pixel-major -> NCHW fp32 on the host
+        return t.float().reshape(n, h, w, -1).permute(0, 3, 1, 2).cpu()
+    m = build(rt)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    m.set_drop_masks(ones, ones)
+    stream = torch.cuda.current_stream()
+    N, rows = 4, []
+    TIGHT, TIGHT_HEADS, FACTOR, FLOOR = 2e-2, 3e-2, 3.0, 5e-3     # measured: blocks <= 0.8 % (bn3.bias 1.5 %), heads <= 2.3 %
+
+    def check(unit, what, got, emu, ref):
+        got = got.float().cpu()
+        rows.append((unit, what, l2(got, emu), l2(got, ref), l2(emu, ref)))
+    with torch.no_grad():
+        for bi, blk in enumerate(m.blocks):
+            p, inpl, planes, stride, dil, ds = blk
+            prev = keys[bi]
+            h, w = taps[0][prev].shape[-2:]
+            with torch.enable_grad():
+                eo, edx, egp = emu_unit(lambda x, wts, sp=specs[bi]: omodel.bottleneck(x, wts, sp, True, {}, RB),
+                                        lambda k, p=p: k.startswith(p + '.'), [taps[0][prev], taps[1][prev]],
+                                        [omodel._rb(gtap[0][p]), omodel._rb(gtap[1][p])])
+            T = m.new_tape(groups=2)
+            y, h2, w2 = m._block_fwd(T, blk, pxc(taps[0][prev], taps[1][prev]), N, h, w, stream)
+            check(p, 'out', back(y, N, h2, w2), torch.cat([eo[0][0], eo[1][0]]), torch.cat([taps[0][p], taps[1][p]]).detach())
+            m.flat_g.zero_()
+            m._begin_backward(T)
+            gx = m._block_bwd(T, blk, pxc(gtap[0][p], gtap[1][p]), None)
+            m._flush_wgrads(T)
+            torch.cuda.synchronize()
+            check(p, 'dx', back(gx, N, h, w), torch.cat(edx), torch.cat([gtap[0][prev], gtap[1][prev]]))
+            for nm in egp:
+                check(p, 'd ' + nm[len(p) + 1:], m._gviews[nm], egp[nm], gpar[nm])
+        # ---- the heads (instance norm, pooling, PPM branches, the 3x3 convolution, classifier) as one unit
+        last = blocks[-1]
+        h, w = taps[0][last].shape[-2:]
+        with torch.enable_grad():
+            def hfn(x, wts):
+                outs, feat = omodel.heads(x, wts, True, (ones, ones), {}, RB)
+                return outs[0], outs[1]
+            eo, edx, egp = emu_unit(hfn, lambda k: k.startswith('layer'), [taps[0][last], taps[1][last]],
+                                    [(glog[0], glog[1]), (glog[2], glog[3])])
+        T = m.new_tape(groups=2)
+        x1, x2, feat = m._heads_fwd(T, pxc(taps[0][last], taps[1][last]), N, h, w, stream)
+        check('heads', 'x1', x1, torch.cat([eo[0][0], eo[1][0]]), torch.cat([s1, t1]).detach())
+        check('heads', 'x2', x2, torch.cat([eo[0][1], eo[1][1]]), torch.cat([s2, t2]).detach())
+        ft = torch.cat([taps[0]['feat'], taps[1]['feat']]).detach()
+        check('heads', 'feat', feat, ft, ft)
+        m.flat_g.zero_()
+        m._begin_backward(T)
+        gy = m._heads_bwd(T, torch.cat([glog[0], glog[2]]).cuda().contiguous(), torch.cat([glog[1], glog[3]]).cuda().contiguous(),
+                          None, stream)
+        m._flush_wgrads(T)
+        torch.cuda.synchronize()
+        check('heads', 'dx', back(gy, N, h, w), torch.cat(edx), torch.cat([gtap[0][last], gtap[1][last]]))
+        for nm in egp:
+            if '.ppm.0.' not in nm:      # (the scale-1 branch is identically zero in the reference: noise)
+                check('heads', 'd ' + nm, m._gviews[nm], egp[nm], gpar[nm])
+    by = {}
+    for unit, what, he, hf, ef in rows:
+        by.setdefault(what if unit != 'heads' else 'heads: ' + what, []).append((he, hf, ef))
+    with capsys.disabled():
+        print('\n[per-unit forward / backward on the oracle\'s tensors, ResNet-101 2 + 2 x 512 x 512] %d quantities over %d units; '
+              'relative L2, max over the units:' % (len(rows), len(m.blocks) + 1))
+        print('   %-34s %10s %10s %12s' % ('quantity', 'HIP vs E', 'HIP vs F', 'N = E vs F'))
+        for what, v in by.items():
+            if not what.startswith('heads: d layer6'):
+                print('   %-34s %10.4f %10.4f %12.4f' % (what, max(x[0] for x in v), max(x[1] for x in v), max(x[2] for x in v)))
+    if os.environ.get('RGDA_UNIT_DUMP'):
+        with open(os.environ['RGDA_UNIT_DUMP'], 'w') as f:
+            for r in sorted(rows, key=lambda r: -r[2]):
+                f.write('%-34s %-28s %.5f %.5f %.5f\n' % r)
+    bad = [r for r in rows if not (r[2] <= (TIGHT_HEADS if r[0] == 'heads' else TIGHT) and r[3] <= FACTOR * r[4] + FLOOR)]
+    assert not bad, bad[:8]
+    assert len(rows) >= 33 * 11

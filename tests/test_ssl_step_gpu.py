@@ -127,6 +127,66 @@ def test_online_ema_teacher_and_reference_style_loop():
     assert not torch.equal(x1, x1b)
 
 
+@pytest.mark.parametrize('which', ['shallow', 'resnet101'])
+def test_online_teacher_steps_match_the_oracle_online_steps(which, capsys):
+    """The ONLINE EMA teacher leg against the oracle's (oracle/step.py: CpuStep(ema_decay=); regda/utils/ema.py:41-54,
+    regda/models/Encoder.py:152-155): two consecutive steps whose target soft labels come from the teacher's eval forward on
+    the shadow weights (student's BatchNorm buffers as they stand at the start of the step) and whose shadow is updated behind
+    the optimizer -- shallow topology at 4 + 4 x 128 x 128 and ResNet-101 at 2 + 2 x 128 x 128.  Compared per step: the teacher's
+    soft labels, both losses, the gradient norm, the pseudo labels; after the two steps: the prototypes and the shadow, the
+    latter also against its own defining formula on the HIP path's weights (tight).  Bounds: three rounding-noise units of
+    these fixtures (bf16_tolerances.json "shallow_online" / "resnet101_online_128"; the chain teacher -> refine -> select ->
+    region vote is the noisiest of the suite: a region flips as a whole)."""
+    import sys
+    from regda_amd.ssl import SSLStep
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import derive_tolerances as D
+    F = 'shallow_online' if which == 'shallow' else 'resnet101_online_128'
+    rt, sd, b, protos, ones = D.online_inputs(which)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cpu = CpuStep(sd, protos, resnet_type=rt, lr=D.ONLINE_LR, ema_decay=D.ONLINE_DECAY)
+    m = build(rt)
+    m.load_state_dict(sd, strict=True)
+    m.set_drop_masks(ones, ones)
+    st = SSLStep(m, protos, ema_decay=D.ONLINE_DECAY)
+    assert torch.equal(st.teacher.flat_p, m.flat_p)                     # register(): the shadow starts as the weights
+    g = {k: v.cuda() for k, v in b.items()}
+    rows = []
+    for i in range(D.ONLINE_STEPS):
+        ref = cpu.step(b['images_s'], b['label_s'], b['images_t'], None, b['regs_t'], (ones, ones), (ones, ones))
+        sh0, w0 = st.teacher.flat_p.clone(), None
+        ls, lt, gn = st.step(g['images_s'], g['label_s'], g['images_t'], None, g['regs_t'], D.ONLINE_LR)
+        torch.cuda.synchronize()
+        # ema.update() on the HIP path's own numbers: shadow' = (1 - d) * w' + d * shadow, one fused multiply-add of rounding
+        want = (1.0 - D.ONLINE_DECAY) * m.flat_p + D.ONLINE_DECAY * sh0
+        assert float((st.teacher.flat_p - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+        hard = st.last_hard.cpu().numpy()
+        rows.append(dict(teacher_soft=float((st.last_soft_t.cpu() - cpu.last_soft_t).abs().mean()),
+                         loss_s=abs(ls.item() / ref['loss_source'] - 1), loss_t_abs=abs(lt.item() - ref['loss_target']),
+                         grad_norm=abs(gn.sqrt().item() / ref['grad_norm'] - 1),
+                         hard_mismatch=float((hard != ref['hard'].numpy()).mean()), labelled=float((hard >= 0).mean())))
+    protos_rel = float((st.prototypes.cpu() - cpu.prototypes).norm() / cpu.prototypes.norm())
+    lay = {k: v for k, v in m.named_parameters()}
+    num = den = 0.0
+    for k in cpu.names:                                                 # the shadow against the oracle's, relative to its move
+        tv = dict(st.teacher.named_parameters())[k].detach().cpu()
+        num += float((tv - cpu.shadow[k]).double().pow(2).sum())
+        den += float((cpu.shadow[k] - sd[k]).double().pow(2).sum())
+    shadow_rel = (num / den) ** 0.5
+    with capsys.disabled():
+        print('\n[online teacher, %s] per step: %s' % (which, [{k: '%.3g' % v for k, v in r.items()} for r in rows]))
+        print('   prototypes %.3g  shadow (relative to its move) %.3g   tolerances: teacher soft %.3g loss_s %.3g loss_t_abs %.3g '
+              'grad_norm %.3g hard %.3g shadow %.3g' % (protos_rel, shadow_rel, tol(F, 'teacher_soft_mean_abs'), tol(F, 'loss_source'),
+                                                     tol(F, 'loss_target_abs'), tol_gn(F), tol(F, 'hard_mismatch'), tol(F, 'shadow_move_rel')))
+    for r in rows:
+        assert r['teacher_soft'] < tol(F, 'teacher_soft_mean_abs')
+        assert r['loss_s'] < tol(F, 'loss_source') and r['loss_t_abs'] < tol(F, 'loss_target_abs')
+        assert r['grad_norm'] < tol_gn(F) and r['hard_mismatch'] < tol(F, 'hard_mismatch')
+        assert r['labelled'] > 0.2
+    assert protos_rel < tol(F, 'protos_rel', floor=1e-4) and shadow_rel < tol(F, 'shadow_move_rel')
+    assert st.lrh_flag() == 0
+
+
 @pytest.mark.parametrize('rt,b,size', [('resnet50', 2, 256), ('resnet101', 3, 384)])
 def test_step_runs_at_other_batch_and_tile_sizes(rt, b, size):
     """Odd batch sizes and feature maps that are not 32 wide (16x16, 24x24: the generic weight-gradient and tile

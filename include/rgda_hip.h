@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 10
+#define RGDA_ABI_VERSION 9
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore rgda_stat_t[RGDA_STAT_REPLICAS][2][C], zeroed by the caller.
@@ -280,17 +280,6 @@ int rgda_conv2d_bnin_supported(int64_t M, int Cout, int Cin, int kh, int kw, int
 int rgda_conv2d_bnin(const rgda_bn_operand* bn_in, const void* x, int ldx, const void* wgt, void* y, int ldy,
                      const void* res, int ldres, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin,
                      int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, rgda_stream_t stream);
-
-/* conv1 of a bottleneck block with the PREVIOUS block's tail on its operand path (regda/_resnets.py:92-112; ABI 10):
- *     side = relu(bn(x) + res)   [M][Cin] bf16, written once (the next residual and conv1's weight-gradient operand),
- *     side_mask = its ReLU sign bits [M][Cin / 8] (NULL: not kept),   y = conv1x1(side) [M][Cout] + statistics as rgda_conv2d.
- * x is the RAW output of the previous block's conv3 and bn_in its BatchNorm (relu must be set: the ReLU follows the add);
- * c3 and res are read ONCE, the activation is never re-read by this kernel.  Served (rgda_conv1x1_block_supported):
- * Cout 128 | 256, Cin a multiple of 256 up to 2048, M / stat_groups a multiple of 64; else RGDA_ERR_UNSUPPORTED. */
-int rgda_conv1x1_block_supported(int64_t M, int Cout, int Cin, int groups);
-int rgda_conv1x1_block(const rgda_bn_operand* bn_in, const void* x, int ldx, const void* res, int ldres, void* side,
-                       int ldside, uint8_t* side_mask, const void* wgt, void* y, int ldy, rgda_stat_t* stats,
-                       int stat_groups, int64_t M, int Cin, int Cout, rgda_stream_t stream);
 
 /* The kernel instantiation that serves a convolution call, as rocprofv3 names it ("conv_igemm_kernel<128, 128, 2, 2, 4,
  * false, false>", "conv3x3_halo_kernel<1, 4, true>", ...), decided by the library's own dispatch (nothing is launched):

@@ -59,11 +59,6 @@ struct ConvArgs {
     const float* bn_beta;
     // optional BatchNorm (+ ReLU) of the PRODUCER of x applied on this convolution's operand path (xf.stats != nullptr)
     BnOperand xf;
-    // conv1x1_block_kernel: second operand tensor (the residual), the materialised operand (side output) and its sign mask
-    const bf16_t* x2;
-    bf16_t* side;
-    unsigned char* side_mask;
-    int ldx2, ldside;
 };
 
 // Per-workgroup timestamps and K-loop ablation switches exist in tuning builds only (`make TUNING=1`): in the product
@@ -1256,165 +1251,6 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// conv1 of a bottleneck block with the PREVIOUS block's tail on its operand path (regda/_resnets.py:92-112):
-//     x' = relu(bn3(c3) + x)        c1 = conv1(x')        (1 x 1, Cin = 4 planes -> Cout = planes)
-// As passes, x' costs one read of c3, one of x and one write (rgda_bn_train_apply), and conv1 reads x' again.  Here a workgroup
-// owns 64 pixels and ALL BC output channels: the two operand tensors travel global -> registers (D K tiles ahead: eight
-// 16-byte loads in flight per thread) -> fma / add / max -> bf16 -> ds_write into a 2-stage LDS ring as the MFMA operand, and
-// the same registers leave as the side output x' (the next residual, conv1's weight-gradient operand) with its ReLU sign
-// mask: every element of c3 and x is read ONCE, x' is written once and never read by this kernel.  The weight tiles (BC x 64
-// per K tile) keep the LDS-DMA ring (3 stages).  One barrier per K tile; every wait is a counted vmcnt (loads, stores and DMA
-// retire in order): the loads of tile kt were issued D iterations ago, its weights two.  conv1's own BatchNorm statistics
-// leave through the common epilogue.  No redundant transform (one channel tile), no operand re-read: 109 MB of traffic per
-// layer-3 block instead of 100 + 42.
-static __device__ __forceinline__ unsigned char relu_bits8(const uint4& v) {      // bit e = [packed bf16 value e > 0]
-    auto pos = [](unsigned h) { return (unsigned)((h & 0x7fffu) != 0 && (h & 0x8000u) == 0); };
-    return (unsigned char)(pos(v.x & 0xffffu) | pos(v.x >> 16) << 1 | pos(v.y & 0xffffu) << 2 | pos(v.y >> 16) << 3 |
-                           pos(v.z & 0xffffu) << 4 | pos(v.z >> 16) << 5 | pos(v.w & 0xffffu) << 6 | pos(v.w >> 16) << 7);
-}
-template <int BC, int WC, bool RELU_MASK, int D = 4, bool NOSTORE = false>
-__global__ void __launch_bounds__(512) conv1x1_block_kernel(ConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BP = 64, NW = 8, WP = NW / WC, FI = BC / WC / 32, FJ = BP / WP / 32;
-    constexpr int XS = BP * 128, WS = BC * 128;             // bytes of an operand stage / a weight stage (64 channels)
-    constexpr int WL = BC / 64;                             // weight DMA instructions per wave and K tile
-    constexpr int CSTR = BC * 2 + 16, EPI = BP * CSTR + NW * BC * 2 * 4;
-    constexpr int RING = 2 * XS + 3 * WS;
-    constexpr int SMEM = RING > EPI ? RING : EPI;
-    constexpr int MAXC = 2048;                              // operand channels (table: scale, shift)
-    constexpr int NST = NOSTORE ? 0 : (RELU_MASK ? 2 : 1);  // stores per thread and K tile
-    static_assert(FI >= 1 && FJ >= 1 && SMEM + MAXC * 8 <= 160 * 1024, "tile / LDS budget");
-    __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM + MAXC * 8];
-    unsigned char* const sxb = smem;
-    unsigned char* const swb = smem + 2 * XS;
-    float* const xtab = (float*)(smem + SMEM);
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wc = wave % WC, wp = wave / WC;
-    const int lrow = lane & 31, lk = lane >> 5, lrow8 = lane >> 3, lslot = lane & 7;
-    const int m0 = xcd_remap(blockIdx.x, a.tiles_p) * BP;
-    const int KT = a.Cin >> 6;
-    constexpr int OOB = (int)0x80000000;
-    const i32x4 rs_w = dma_rsrc(a.w, (unsigned)((size_t)a.Cout * a.Cin * 2));
-    const i32x4 rs_pa = dma_rsrc(a.x, (unsigned)((((size_t)a.M - 1) * a.ldx + a.Cin) * 2));
-    const i32x4 rs_qa = dma_rsrc(a.x2, (unsigned)((((size_t)a.M - 1) * a.ldx2 + a.Cin) * 2));
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)a.side, 0, (int)((((size_t)a.M - 1) * a.ldside + a.Cin) * 2), 0x00020000);
-    // this thread's operand vector: pixel row t >> 3 of the tile, 16-byte slot t & 7 of the K tile's 128 bytes
-    const int prow = t >> 3, pslot = t & 7;
-    const int pvo = ((m0 + prow) * a.ldx + pslot * 8) * 2;         // (whole tiles: the host refuses M % 64 != 0)
-    const int qvo = ((m0 + prow) * a.ldx2 + pslot * 8) * 2;
-    const int svo = ((m0 + prow) * a.ldside + pslot * 8) * 2;
-    unsigned char* const mrow = a.side_mask + (size_t)(m0 + prow) * (a.Cin >> 3) + pslot;
-    unsigned char* const xdst = sxb + prow * 128 + ((pslot ^ ((prow >> 1) & 7)) << 4);
-    int wvo[WL];
-#pragma unroll
-    for (int i = 0; i < WL; ++i) {
-        const int r = (i * NW + wave) * 8 + lrow8;
-        wvo[i] = (r < a.Cout) ? (r * a.Cin * 2 + (lslot ^ ((r >> 1) & 7)) * 16) : OOB;
-    }
-    auto issue_w = [&](int kt, int stage, bool live) {
-        unsigned char* wb = swb + stage * WS + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < WL; ++i) dma16_to_lds(rs_w, wb + i * NW * 1024, live ? wvo[i] : OOB, kt * 128);
-    };
-    // the operand loads are issued from inline assembly and waited for with counted vmcnt waits that CARRY the registers
-    // (through builtins the compiler counts only the loads it knows -- not the weight DMA -- and its own waits would drain
-    // most of the prefetch)
-    u32x4r pr[D], qr[D];
-    auto load_x = [&](int kt, int slot, bool live) {
-        const int po = live ? pvo : OOB, qo = live ? qvo : OOB, so = kt * 128;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(pr[slot]) : "v"(po), "s"(rs_pa), "s"(so) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(qr[slot]) : "v"(qo), "s"(rs_qa), "s"(so) : "memory");
-    };
-    f32x16 acc[FI][FJ];
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // ---- prologue: everything in flight, then the (scale, shift) table of the operand's BatchNorm under the loads
-    issue_w(0, 0, true);
-    issue_w(1, 1, 1 < KT);
-#pragma unroll
-    for (int d = 0; d < D; ++d) load_x(d, d, d < KT);
-    bn_operand_table<512>(a.xf, m0 / a.rows_per_group, blockIdx.x == 0, xtab);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int wstage = 0;
-    for (int kt0 = 0; kt0 < KT; kt0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int kt = kt0 + d;
-            // ---- tile kt: registers -> relu(bn3(c3) + x) -> LDS stage kt & 1 and the side output; loads of tile kt + D
-            // (issued D iterations ago; younger: that iteration's weight DMA and D - 1 whole iterations)
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pr[d]), "+v"(qr[d]) : "n"(WL + (D - 1) * (NST + 2 + WL)) : "memory");
-            {
-                float sc[8], sh[8];
-                const f32x4* ts = (const f32x4*)(xtab + kt * 64 + pslot * 8);
-                const f32x4* th = (const f32x4*)(xtab + a.Cin + kt * 64 + pslot * 8);
-                const f32x4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = h0[e]; sh[4 + e] = h1[e]; }
-                unsigned w[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned pu = pr[d][e], qu = qr[d][e];
-                    f32x2v x = {__uint_as_float(pu << 16), __uint_as_float(pu & 0xffff0000u)};
-                    f32x2v r2 = {__uint_as_float(qu << 16), __uint_as_float(qu & 0xffff0000u)};
-                    f32x2v sv = {sc[2 * e], sc[2 * e + 1]}, hv = {sh[2 * e], sh[2 * e + 1]};
-                    f32x2v f = __builtin_elementwise_fma(x, sv, hv) + r2;
-                    f.x = fmaxf(f.x, 0.f); f.y = fmaxf(f.y, 0.f);
-                    w[e] = pack2bf(f.x, f.y);
-                }
-                const uint4 v = uint4{w[0], w[1], w[2], w[3]};
-                *(uint4*)(xdst + (kt & 1) * XS) = v;
-                if constexpr (!NOSTORE) {
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4r{v.x, v.y, v.z, v.w}, rs_s, svo, kt * 128, 0);
-                if constexpr (RELU_MASK) mrow[kt * 8] = relu_bits8(v);
-                }
-            }
-            load_x(kt + D, d, kt + D < KT);
-            // ---- weight tile kt has landed (issued two iterations ago); every wave's operand rows are in LDS
-            WAIT_VMCNT(2 * NST + 4 + WL);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue_w(kt + 2, wstage == 0 ? 2 : wstage - 1, kt + 2 < KT);
-            const unsigned char* wb = swb + wstage * WS;
-            const unsigned char* xb = sxb + (kt & 1) * XS;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 fa[FI], fb[FJ];
-#pragma unroll
-                for (int i = 0; i < FI; ++i) {
-                    const int r = wc * (BC / WC) + i * 32 + lrow;
-                    fa[i] = *(const bf16x8*)(wb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < FJ; ++j) {
-                    const int r = wp * (BP / WP) + j * 32 + lrow;
-                    fb[j] = *(const bf16x8*)(xb + r * 128 + (((kk * 2 + lk) ^ ((r >> 1) & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < FI; ++i)
-#pragma unroll
-                    for (int j = 0; j < FJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            }
-            wstage = (wstage == 2) ? 0 : wstage + 1;
-        }
-    }
-    __syncthreads();
-    float s[8], q8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q8[e] = 0.f; }
-    conv_epilogue<BC, BP, WC, WP>(a, acc, smem, m0, 0, s, q8, true, blockIdx.x & (NREP - 1));
-#endif
-}
-
-
 // tile choice (measured on MI355X, scripts/dev/dev_conv_bench.py): the L2 -> LDS path sustains <= ~80 GB/s per CU, so the
 // long-K head convolutions want the largest tile that still gives every CU a workgroup (128 x 256, 85 FLOP per
 // byte, 8 waves); large-M layers run 128 x 128 tiles with 8 waves and a 2-stage ring (64 KiB: two workgroups =
@@ -1469,7 +1305,6 @@ extern "C" int rgda_conv2d_tile(int64_t M, int Cout, int kh, int kw, int Cin, in
 static int ilog2_exact(int v);
 struct BnBwdFuse { const void* y; int ldy; const unsigned char* mask; const void* x; int ldx; const float* mi; const float* nscale; int rpi; int relu; const float* gamma; const float* beta; };
 struct BnEvalFuse { const float* rm; const float* rv; const float* gamma; const float* beta; float eps; int relu; };
-struct BlockFuse { const void* res; int ldres; void* side; int ldside; unsigned char* mask; };     // conv1x1_block_kernel
 
 // which kernel serves a convolution whose operand is a BatchNorm (+ ReLU) on the operand path: 1 = conv3x3_halo_kernel
 // <1, 4>, 2 = <1, 8>, 3 = conv_igemm_kernel<128, 128, 2, 2, 4, false, true>; 0 = none (the caller materialises the
@@ -1483,14 +1318,6 @@ static int conv_bnin_kind(long long M, int Cout, int Cin, int kh, int kw, int st
     int bc, bp, stages;
     if (pick_tile(M, Cout, (long long)kh * kw * Cin, rpg, bc, bp, stages)) return 0;
     return (bc == 128 && bp == 128 && stages == 82) ? 3 : 0;
-}
-
-// conv1x1_block_kernel: 1 x 1 / stride 1, Cout = 128 | 256 (one channel tile), Cin a multiple of 256 up to 2048, whole 64-pixel
-// tiles inside one statistics group, 32-bit byte offsets
-static int conv1x1_block_supported(long long M, int Cout, int Cin, int kh, int kw, int stride, int pad, int groups) {
-    if (kh != 1 || kw != 1 || stride != 1 || pad != 0 || (Cout != 128 && Cout != 256) || (Cin & 255) || Cin > 2048) return 0;
-    if (groups < 1 || (M % groups) || ((M / groups) & 63) || (long long)M * Cin * 2 >= (1ll << 31)) return 0;
-    return 1;
 }
 
 // 0 = not served, 1 = served, 2 = served and faster than the apply pass it replaces.  Where the transform pays
@@ -1508,7 +1335,7 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
                          const unsigned char* res_mask, rgda_stat_t* stats, int stat_groups, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int kh, int kw, int stride, int pad, int dil, int mode, const BnBwdFuse* bnb,
                          rgda_stream_t stream, const BnEvalFuse* bne = nullptr, const rgda_bn_operand* bnin = nullptr,
-                         const char** sel = nullptr, ConvArgs* out_args = nullptr, const BlockFuse* blk = nullptr) {
+                         const char** sel = nullptr, ConvArgs* out_args = nullptr) {
     // sel != nullptr: dry run -- *sel = the kernel instantiation that would serve the call (the name rocprofv3 reports),
     // nothing is launched (rgda_conv2d_kernel; bench.py labels its per-launch timings with it); out_args: the argument
     // block that launch would carry (rgda_conv2d_grouped packs several into one launch)
@@ -1561,7 +1388,6 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         a.ev_rm = bne->rm; a.ev_rv = bne->rv; a.ev_gamma = bne->gamma; a.ev_beta = bne->beta; a.ev_eps = bne->eps;
         a.ev_relu = bne->relu;
     }
-    a.x2 = nullptr; a.side = nullptr; a.side_mask = nullptr; a.ldx2 = a.ldside = 0;
     a.dbg = nullptr; a.skip = 0;
     if (const char* e = TUNE_ENV("RGDA_CONV_DBG")) a.dbg = (unsigned long long*)strtoull(e, nullptr, 0);   // tuning only
     if (const char* e = TUNE_ENV("RGDA_CONV_SKIP")) a.skip = atoi(e);                                      // tuning only
@@ -1573,35 +1399,6 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
             ((long long)N * H * W) % bnin->groups || (bnin->running_mean == nullptr) != (bnin->running_var == nullptr))
             return RGDA_ERR_ARG;
         if ((long long)N * H * W / bnin->groups < 2) return RGDA_ERR_ARG;      // "Expected more than 1 value per channel"
-        if (blk) {
-            // relu(bn(x) + res) on the operand path with the materialised operand as a side output: conv1x1_block_kernel
-            if (!conv1x1_block_supported(M, Cout, Cin, kh, kw, stride, pad, stat_groups) || res || !blk->res || !blk->side ||
-                (blk->ldres & 7) || (blk->ldside & 7) || blk->ldres < Cin || blk->ldside < Cin || !bnin->relu)
-                return RGDA_ERR_UNSUPPORTED;
-            a.xf.stats = bnin->stats; a.xf.gamma = bnin->gamma; a.xf.beta = bnin->beta; a.xf.mi = bnin->mi;
-            a.xf.rm = bnin->running_mean; a.xf.rv = bnin->running_var; a.xf.nbt = (long long*)bnin->num_batches_tracked;
-            a.xf.eps = bnin->eps; a.xf.mom = bnin->momentum; a.xf.groups = bnin->groups; a.xf.relu = 1; a.xf.C = Cin;
-            a.xf.rows_per_group = (int)(M / bnin->groups);
-            a.x2 = (const bf16_t*)blk->res; a.ldx2 = blk->ldres; a.side = (bf16_t*)blk->side; a.ldside = blk->ldside;
-            a.side_mask = blk->mask;
-            a.tiles_c = 1; a.tiles_p = (int)(M / 64);
-            const int grid = a.tiles_p;
-            if (const char* e = TUNE_ENV("RGDA_BLK")) {                                     // tuning experiments only (timing)
-                const int v = atoi(e);
-                if (Cout == 256 && v == 1) { conv1x1_block_kernel<256, 4, true, 4, true><<<grid, 512, 0, st>>>(a); return RGDA_OK; }
-                if (Cout == 256 && v == 2) { conv1x1_block_kernel<256, 4, true, 8, false><<<grid, 512, 0, st>>>(a); return RGDA_OK; }
-                if (Cout == 256 && v == 3) { conv1x1_block_kernel<256, 4, true, 8, true><<<grid, 512, 0, st>>>(a); return RGDA_OK; }
-            }
-            if (Cout == 256) {
-                if (blk->mask) RGDA_LAUNCH("conv1x1_block_kernel<256, 4, true>", conv1x1_block_kernel<256, 4, true><<<grid, 512, 0, st>>>(a));
-                else RGDA_LAUNCH("conv1x1_block_kernel<256, 4, false>", conv1x1_block_kernel<256, 4, false><<<grid, 512, 0, st>>>(a));
-            } else {
-                if (blk->mask) RGDA_LAUNCH("conv1x1_block_kernel<128, 4, true>", conv1x1_block_kernel<128, 4, true><<<grid, 512, 0, st>>>(a));
-                else RGDA_LAUNCH("conv1x1_block_kernel<128, 4, false>", conv1x1_block_kernel<128, 4, false><<<grid, 512, 0, st>>>(a));
-            }
-            RGDA_CHECK_LAUNCH();
-            return RGDA_OK;
-        }
         const int kind = conv_bnin_kind(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, stat_groups);
         if (!kind) return RGDA_ERR_UNSUPPORTED;
         a.xf.stats = bnin->stats; a.xf.gamma = bnin->gamma; a.xf.beta = bnin->beta; a.xf.mi = bnin->mi;
@@ -1836,19 +1633,6 @@ extern "C" int rgda_conv2d_bnin(const rgda_bn_operand* bn_in, const void* x, int
     if (!bn_in) return RGDA_ERR_ARG;
     return conv2d_launch(x, ldx, wgt, y, ldy, res, ldres, nullptr, stats, stat_groups, N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride,
                          pad, dil, 0, nullptr, stream, nullptr, bn_in);
-}
-
-extern "C" int rgda_conv1x1_block_supported(int64_t M, int Cout, int Cin, int groups) {
-    return conv1x1_block_supported(M, Cout, Cin, 1, 1, 1, 0, groups);
-}
-
-extern "C" int rgda_conv1x1_block(const rgda_bn_operand* bn_in, const void* x, int ldx, const void* res, int ldres,
-                                  void* side, int ldside, uint8_t* side_mask, const void* wgt, void* y, int ldy,
-                                  rgda_stat_t* stats, int stat_groups, int64_t M, int Cin, int Cout, rgda_stream_t stream) {
-    if (!bn_in || M <= 0 || M > 0x7fffffffLL) return RGDA_ERR_ARG;
-    BlockFuse blk{res, ldres, side, ldside, side_mask};
-    return conv2d_launch(x, ldx, wgt, y, ldy, nullptr, 0, nullptr, stats, stat_groups, 1, 1, (int)M, Cin, 1, (int)M, Cout, 1, 1, 1, 0,
-                         1, 0, nullptr, stream, nullptr, bn_in, nullptr, nullptr, &blk);
 }
 
 extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* y, int ldy, const void* res, int ldres,

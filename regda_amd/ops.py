@@ -469,20 +469,6 @@ def conv2d_bnin(bnop, x, w, y, N, H, W, Ho, Wo, kh, kw, stride, pad, dil, res=No
                dil, _stream())
 
 
-def conv1x1_block_supported(M, Cout, Cin, groups):
-    return lib().size('rgda_conv1x1_block_supported', M, Cout, Cin, groups)
-
-
-def conv1x1_block(bnop, x, res, side, w, y, side_mask=None, stats=None, stat_groups=1):
-    """side = relu(BatchNorm(x) + res) (written once, + its ReLU sign mask), y = conv1x1(side) with fused statistics: the tail
-    of a bottleneck block on the next block's conv1 operand path (rgda_conv1x1_block; bnop from bn_operand(relu=True))."""
-    Cout, taps, Cin = w.shape
-    M = x.shape[0]
-    assert taps == 1 and x.shape[1] == Cin and res.shape == x.shape and side.shape == x.shape and y.shape == (M, Cout)
-    lib().call('rgda_conv1x1_block', bnop, x.data_ptr(), _ld(x), res.data_ptr(), _ld(res), side.data_ptr(), _ld(side),
-               _p(side_mask), w.data_ptr(), y.data_ptr(), _ld(y), _stat(stats), stat_groups, M, Cin, Cout, _stream())
-
-
 def conv2d_wgrad(x, dy, dw, N, H, W, Ho, Wo, kh, kw, stride, pad, dil):
     """dw f32 [Cout, kh*kw, Cin] contiguous, accumulated."""
     Cout, taps, Cin = dw.shape

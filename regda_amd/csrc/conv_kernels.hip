@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_grouped_kernel(ConvGr
 // stage q + 1 as well: the fragments of step q + 1's first two k-slices are read under the last MFMAs of step q, and no
 // wave opens a step with an LDS round trip in front of its first MFMA (with one barrier per step all eight waves of the
 // workgroup did -- both waves of every SIMD at the same time, matrix pipes idle).
-template <int D, int TR, bool XF = false, int NS = 3>
+template <int D, int TR, bool XF = false, int NS = 3, bool PF = (NS == 4)>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TC = 32;                                  // pixel tile: TR image rows x the 32 columns of the map
@@ -779,7 +779,9 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     constexpr int XS = PXW * 64 * 128, WS = BC * 128;       // bytes of a halo buffer / a weight stage
     constexpr int CSTR = BC * 2 + 16, EPI = BP * CSTR + NW * BC * 2 * 4;
     constexpr int SMEM = 2 * XS + NS * WS;
-    constexpr bool PF = NS == 4;
+    // PF with NS = 3 (dilation 2: four stages do not fit 160 KB): the weight tile of step q + 1 is issued ONE step ahead and
+    // waited for in full at the top of step q (only the previous step's halo piece stays in flight)
+    constexpr int AH = NS - 1;                              // PF: weight tiles issued ahead
     static_assert(NS == 3 || NS == 4, "ring depth");
     static_assert(!PF || PXW <= 7, "the next slab's halo is complete behind the barrier of tap 8");
     static_assert(!(PF && XF) || PXW + 3 <= 9, "... and transformed");
@@ -896,7 +898,7 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     for (int i = 0; i < PXW; ++i) issue_h(0, i);
     issue_w(0, 0);
     issue_w(1, 1);
-    if constexpr (PF) issue_w(2, 2);
+    if constexpr (PF && NS == 4) issue_w(2, 2);
     // ---- XF: this thread's vector of halo piece k is row k * 64 + (t >> 3), LOGICAL slot lslot (the channels, hence the
     // scale / shift registers, are the same for every row); those are bytes of the wave's own DMA instructions
     float xsc[8], xsh[8];
@@ -927,7 +929,7 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     bf16x8 fa0[2][FI], fb0[2][FJ], fa1[2][FI], fb1[2][FJ];
     if constexpr (PF) {
         // the first step's first fragments: halo slab 0 and weight tile 0 have landed (tiles 1 and 2 stay in flight)
-        WAIT_VMCNT(4);
+        WAIT_VMCNT(2 * (NS - 2));
         if constexpr (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         read_half(swb, sxb, 0, 0, fa0, fb0);
@@ -943,11 +945,11 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
             // everything but the previous step's DMA instructions has landed: weight tile q + 1 (and, with the barrier, every
             // wave's part of it); in flight: tile q + 2 and the halo piece of step tp - 1
             // (tuning builds, timing only: skip bit 1 = no DMA inside the loop, 2 = no vmcnt wait, 4 = no barrier)
-            if (!(TSKIP(a) & 2)) { if (tp >= 1 && tp - 1 < PXW) WAIT_VMCNT(3); else WAIT_VMCNT(2); }
+            if (!(TSKIP(a) & 2)) { if (tp >= 1 && tp - 1 < PXW) WAIT_VMCNT(2 * (NS - 3) + 1); else WAIT_VMCNT(2 * (NS - 3)); }
             if constexpr (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the previous step's in-place transform
             if (!(TSKIP(a) & 4)) __builtin_amdgcn_s_barrier();
             if (!(TSKIP(a) & 1)) {
-            issue_w2((tp + 3) % 9, sl + (tp + 3) / 9, wstage >= 1 ? wstage - 1 : 3, q + 3 < KT);
+            issue_w2((tp + AH) % 9, sl + (tp + AH) / 9, wstage >= 1 ? wstage - 1 : NS - 1, q + AH < KT);
             if (tp < PXW) issue_h(sl + 1, tp, more);
             }
             if constexpr (XF) {
@@ -1415,9 +1417,10 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
             const int grid = a.tiles_c * a.tiles_p;
             int ns = 4;
             if (const char* e = TUNE_ENV("RGDA_HALO_NS")) ns = atoi(e);                     // tuning experiments only
-            if (kind == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 4>", conv3x3_halo_kernel<1, 4, true, 4><<<grid, 512, 0, st>>>(a));
-            else if (kind == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 3>", conv3x3_halo_kernel<1, 4, true><<<grid, 512, 0, st>>>(a));
-            else RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true, 3>", conv3x3_halo_kernel<1, 8, true><<<grid, 512, 0, st>>>(a));
+            if (kind == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 4, true>", conv3x3_halo_kernel<1, 4, true, 4><<<grid, 512, 0, st>>>(a));
+            else if (kind == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 3, false>", conv3x3_halo_kernel<1, 4, true><<<grid, 512, 0, st>>>(a));
+            else if (ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true, 3, true>", conv3x3_halo_kernel<1, 8, true, 3, true><<<grid, 512, 0, st>>>(a));
+            else RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true, 3, false>", conv3x3_halo_kernel<1, 8, true><<<grid, 512, 0, st>>>(a));
         }
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
@@ -1447,11 +1450,12 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         const int grid = a.tiles_c * a.tiles_p;
         int ns = 4;                                                                        // (dilation 2: 3 stages, 160 KB)
         if (const char* e = TUNE_ENV("RGDA_HALO_NS")) ns = atoi(e);                         // tuning experiments only
-        if (tr == 4 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 4>", conv3x3_halo_kernel<1, 4, false, 4><<<grid, 512, 0, st>>>(a));
-        else if (tr == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 3>", conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a));
-        else if (dil == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false, 4>", conv3x3_halo_kernel<1, 8, false, 4><<<grid, 512, 0, st>>>(a));
-        else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false, 3>", conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a));
-        else RGDA_LAUNCH("conv3x3_halo_kernel<2, 8, false, 3>", conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a));
+        if (tr == 4 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 4, true>", conv3x3_halo_kernel<1, 4, false, 4><<<grid, 512, 0, st>>>(a));
+        else if (tr == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 3, false>", conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a));
+        else if (dil == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false, 4, true>", conv3x3_halo_kernel<1, 8, false, 4><<<grid, 512, 0, st>>>(a));
+        else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false, 3, false>", conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a));
+        else if (ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<2, 8, false, 3, true>", conv3x3_halo_kernel<2, 8, false, 3, true><<<grid, 512, 0, st>>>(a));
+        else RGDA_LAUNCH("conv3x3_halo_kernel<2, 8, false, 3, false>", conv3x3_halo_kernel<2, 8><<<grid, 512, 0, st>>>(a));
         RGDA_CHECK_LAUNCH();
         return RGDA_OK;
     }

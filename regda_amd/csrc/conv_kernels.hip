@@ -769,6 +769,11 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_grouped_kernel(ConvGr
 // stage q + 1 as well: the fragments of step q + 1's first two k-slices are read under the last MFMAs of step q, and no
 // wave opens a step with an LDS round trip in front of its first MFMA (with one barrier per step all eight waves of the
 // workgroup did -- both waves of every SIMD at the same time, matrix pipes idle).
+// (Round 5, measured and not kept: "loader waves" -- the first four waves, one per SIMD, issue ALL of a step's DMA instructions
+// so that a SIMD always has one wave multiplying.  Isolated launches on random data: head convolution 278 -> 239 us, layer 3's
+// 22.2 -> 21.5; inside the step, by kernel trace on one box: 1756 -> 1745 us and 1059 -> 1064 us per step, and with the operand
+// transform 584 -> 736.  The step runs these kernels on ReLU-sparse data at a higher clock; what an isolated launch on N(0, 1)
+// operands gains in issue slots does not exist there.  Kernel changes are judged by the step's kernel trace.)
 template <int D, int TR, bool XF = false, int NS = 3, bool PF = (NS == 4)>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1419,7 +1424,7 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
             if (const char* e = TUNE_ENV("RGDA_HALO_NS")) ns = atoi(e);                     // tuning experiments only
             if (kind == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 4, true>", conv3x3_halo_kernel<1, 4, true, 4><<<grid, 512, 0, st>>>(a));
             else if (kind == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 3, false>", conv3x3_halo_kernel<1, 4, true><<<grid, 512, 0, st>>>(a));
-            else if (ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true, 3, true>", conv3x3_halo_kernel<1, 8, true, 3, true><<<grid, 512, 0, st>>>(a));
+            // (the pipelined form of the 8-row variant with the transform spills 80 registers: it keeps the plain loop)
             else RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true, 3, false>", conv3x3_halo_kernel<1, 8, true><<<grid, 512, 0, st>>>(a));
         }
         RGDA_CHECK_LAUNCH();

@@ -466,9 +466,11 @@ extern "C" int rgda_pseudo_lrh(const float* soft, const float* classmax, const i
     head = (head + 15) & ~(size_t)15;
     unsigned short* reg16 = (unsigned short*)((char*)ws + head);
     unsigned char* lab8 = (unsigned char*)(reg16 + (size_t)b * hw);
-    const int lds_regions = min(R, (48 * 1024) / (C * 4));
-    int chunk = 16384;
-    while (chunk > 2048 && (long long)cdiv(hw, chunk) * b < 512) chunk >>= 1;
+    int lds_regions = min(R, (48 * 1024) / (C * 4));
+    int chunk = 16384, min_wg = 512;
+    if (const char* e = TUNE_ENV("RGDA_LRH_LDS")) lds_regions = min(R, atoi(e));         // tuning experiments only
+    if (const char* e = TUNE_ENV("RGDA_LRH_WG")) min_wg = atoi(e);                        // tuning experiments only
+    while (chunk > 1024 && (long long)cdiv(hw, chunk) * b < min_wg) chunk >>= 1;
     dim3 g1(cdiv(hw, chunk), b);
     pick_hist_kernel<6><<<g1, 256, (size_t)lds_regions * C * 4, st>>>(soft, classmax, regions, lab8, reg16, hist, ids, flag, counters,
                                                                        hw, chunk, cutoff_top, cutoff_low, ignore_label, percent, R,

@@ -47,17 +47,17 @@ ab)
     [ -f $dir/regda_amd/csrc/librgda_hip.so.arm0 ] || cp $dir/regda_amd/csrc/librgda_hip.so $dir/regda_amd/csrc/librgda_hip.so.arm0
     lib=$dir/regda_amd/csrc/librgda_hip.so.arm0; for e in $envs; do case $e in LIB=*) lib=${e#LIB=} ;; esac; done
     cp $lib $dir/regda_amd/csrc/librgda_hip.so
-    ( cd $dir; env $envs python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-h2d ${BARGS:-} 2>/dev/null | last_json "$arm" )
+    ( cd $dir; env $envs python bench.py --steps 10 --repeats 0 --warmup 3 --no-cpu-baseline --no-roofline --no-h2d ${BARGS:-} 2>/dev/null | last_json "$arm" )
   done; done ;;
 kstep)
   on_box; rm -rf gpurun_out/ks
-  timeout 600 rocprofv3 --kernel-trace -d gpurun_out/ks -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-h2d --eager "$@" > gpurun_out/ks.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace -d gpurun_out/ks -o r -- python bench.py --steps 3 --repeats 0 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-h2d --eager "$@" > gpurun_out/ks.log 2>&1
   python scripts/lib/kstep_all.py gpurun_out/ks/r_results.db 60 > gpurun_out/ks_all.txt
   python scripts/lib/klist.py gpurun_out/ks/r_results.db > gpurun_out/klist_serial.txt
   rm -rf gpurun_out/ks; head -30 gpurun_out/ks_all.txt ;;
 klist)
   on_box; rm -rf gpurun_out/ks
-  timeout 600 rocprofv3 --kernel-trace -d gpurun_out/ks -o r -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-h2d "$@" > gpurun_out/ks.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace -d gpurun_out/ks -o r -- python bench.py --steps 4 --repeats 0 --warmup 2 --no-cpu-baseline --no-roofline --no-h2d "$@" > gpurun_out/ks.log 2>&1
   python scripts/lib/klist.py gpurun_out/ks/r_results.db > gpurun_out/klist_overlapped.txt
   python scripts/lib/timeline.py gpurun_out/ks/r_results.db 2 > gpurun_out/timeline.txt
   rm -rf gpurun_out/ks; head -12 gpurun_out/timeline.txt | cut -c1-200 ;;
@@ -70,7 +70,7 @@ profiles)
   # ---- HBM traffic per kernel: two separate PMC passes (FETCH_SIZE, WRITE_SIZE), kernel trace only
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_$ctr
-    timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --serial --eager --no-h2d > gpurun_out/pmc_$ctr.log 2>&1
+    timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc_$ctr -o p -- python bench.py --steps 2 --repeats 0 --warmup 1 --no-cpu-baseline --no-roofline --serial --eager --no-h2d > gpurun_out/pmc_$ctr.log 2>&1
   done
   python scripts/lib/pmc_traffic.py > gpurun_out/${tag}_pmc_hbm_traffic.txt
   mkdir -p profiles; cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json      # the bench line below reads it
@@ -80,17 +80,17 @@ profiles)
   P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"
   i=0; for pass in "$P1" "$P2"; do
     i=$((i+1)); rm -rf gpurun_out/pmc_m$i
-    timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc_m$i -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --serial --eager --no-h2d > gpurun_out/pmc_m$i.log 2>&1
+    timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc_m$i -o p -- python bench.py --steps 2 --repeats 0 --warmup 1 --no-cpu-baseline --no-roofline --serial --eager --no-h2d > gpurun_out/pmc_m$i.log 2>&1
   done
   python scripts/lib/pmc_mfma.py > gpurun_out/${tag}_pmc_mfma.txt; rm -rf gpurun_out/pmc_m1 gpurun_out/pmc_m2
   # ---- kernel statistics: serial (the averages the roofline probe's HIP events must agree with), one serial step, overlapped
   rm -rf gpurun_out/prof_s
-  timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_s -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-h2d > gpurun_out/prof_s.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_s -o r -- python bench.py --steps 4 --repeats 0 --warmup 1 --no-cpu-baseline --no-roofline --serial --no-h2d > gpurun_out/prof_s.log 2>&1
   python scripts/lib/prof_summary.py gpurun_out/prof_s/r_results.db 5 > gpurun_out/${tag}_kernel_stats.txt
   grep '"metric"' gpurun_out/prof_s.log >> gpurun_out/${tag}_kernel_stats.txt; rm -rf gpurun_out/prof_s
   bash scripts/tune.sh kstep > /dev/null 2>&1; cp gpurun_out/ks_all.txt gpurun_out/${tag}_kernel_one_step.txt
   rm -rf gpurun_out/prof_o
-  timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_o -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_o.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_o -o r -- python bench.py --steps 4 --repeats 0 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/prof_o.log 2>&1
   python scripts/lib/prof_summary.py gpurun_out/prof_o/r_results.db 5 > gpurun_out/${tag}_kernel_stats_overlapped.txt
   grep '"metric"' gpurun_out/prof_o.log >> gpurun_out/${tag}_kernel_stats_overlapped.txt; rm -rf gpurun_out/prof_o
   # ---- the bench lines

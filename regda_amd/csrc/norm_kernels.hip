@@ -323,7 +323,8 @@ static void elementwise_grid(long long M, int C, int groups, RowLayout& L, int& 
     if (L.vpb > 16) { L.vpb = 16; L.rpb = 16; }
     if (const char* e = TUNE_ENV("RGDA_BN_VPB")) {                  // tuning experiments only
         int v = atoi(e);
-        if (v < L.vpb) { L.vpb = v; L.rpb = 256 / v; }
+        RowLayout full = row_layout(C);                             // (above 16: the paths WITHOUT the statistics prologue only)
+        if (v <= full.vpb) { L.vpb = v; L.rpb = 256 / v; }
     }
     if (const char* e = TUNE_ENV("RGDA_BN_ROWS")) rows_mult = atoi(e);   // tuning experiments only
     rows_per_block = L.rpb * rows_mult;

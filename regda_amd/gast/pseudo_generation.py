@@ -45,4 +45,5 @@ def gener_target_pseudo(_cfg, model, pseudo_loader, save_pseudo_label_path, slid
                     lab = ops.argmax_nchw(cls).cpu().numpy()
                 from PIL import Image
                 arr = (np.asarray(lab) + 1).reshape(*size).astype(np.uint8)      # -1 .. C-1  ->  0 .. C  (:149-150)
-                Image.fromarray(arr)               # uint8, 2-D: mode 'L'.save(os.path.join(save_pseudo_label_path, ret_gt['fname'][0]))
+                # (a uint8 2-D array is mode 'L' by itself; the `mode=` argument is deprecated in Pillow >= 11.3)
+                Image.fromarray(arr).save(os.path.join(save_pseudo_label_path, ret_gt['fname'][0]))

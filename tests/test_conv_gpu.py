@@ -33,6 +33,13 @@ def relerr(a, b):
     return (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
 
 
+def _case_seed(case):
+    # NOT hash(case): a tuple holding a str hashes differently in every interpreter (PYTHONHASHSEED), so a failure could
+    # not be re-run on the data that produced it
+    import zlib
+    return zlib.crc32(repr(case).encode()) % 1000
+
+
 CASES = [
     # N, H, W, Cin, Cout, k, stride, pad, dil
     (2, 16, 16, 64, 64, 3, 1, 1, 1),
@@ -69,7 +76,7 @@ CASES = [
 @pytest.mark.parametrize('case', CASES)
 def test_conv_fwd_dgrad_wgrad(ops, case):
     N, H, W, Cin, Cout, k, s, p, d = case
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed(_case_seed(case))
     x = rbf(torch.randn(N, Cin, H, W, generator=g))
     w = rbf(torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5)
     Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
@@ -1015,7 +1022,7 @@ def test_conv_with_batchnorm_relu_on_the_operand_path(ops, case):
     weight gradient fed to the PLAIN convolution reproduces the operand-path convolution bit for bit."""
     N, H, W, Cin, Cout, k, s, p, d, kind = case
     G = 2
-    gen = torch.Generator().manual_seed(1 + hash(case) % 1000)
+    gen = torch.Generator().manual_seed(1 + _case_seed(case))
     # the raw output of the producing convolution: per-channel offsets / scales so that BatchNorm has something to do
     c = rbf(torch.randn(N, Cin, H, W, generator=gen) * (0.5 + torch.rand(1, Cin, 1, 1, generator=gen)) +
             torch.randn(1, Cin, 1, 1, generator=gen))
@@ -1078,7 +1085,14 @@ def test_conv_with_batchnorm_relu_on_the_operand_path(ops, case):
     act = torch.zeros(N * H * W, Cin, dtype=BF, device='cuda')
     dgam, dbet = torch.zeros(Cin, device='cuda'), torch.zeros(Cin, device='cuda')
     ops.bn_bwd_apply(gg, None, cg, mi, gam, sums, dcx, N * H * W, Cin, 2, None, dgam, dbet, groups=G, beta=bet, act_out=act)
-    assert relerr(from_pxc(dcx, N, H, W), cr.grad) < 1.5e-2, 'bn backward (relu sign from x)'
+    # (elements whose pre-ReLU value is within fp32 rounding of zero may take either sign -- fma(x, scale, shift) here,
+    # (x - mean) * invstd * gamma + beta in the reference; with 3.4e7 elements in the largest case a few exist for most
+    # seeds, and ONE flipped sign is a max-norm error of |g| k0.  They are excluded from the comparison.)
+    tie = bnr.abs() < 2e-6 * (1.0 + c.abs() * gamma.abs().view(1, -1, 1, 1))
+    assert tie.float().mean().item() < 1e-4
+    dref = torch.where(tie, torch.zeros(()), cr.grad)
+    dhip = torch.where(tie, torch.zeros(()), from_pxc(dcx, N, H, W))
+    assert relerr(dhip, dref) < 1.5e-2, 'bn backward (relu sign from x)'
     assert relerr(dgam.cpu(), gr.grad) < 5e-3 and relerr(dbet.cpu(), br.grad) < 5e-3
     assert relerr(from_pxc(act, N, H, W), a_ref) < 1e-2
     # the same bits the operand path fed the matrix pipe: the plain convolution over `act` gives the identical result

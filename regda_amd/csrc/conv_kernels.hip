@@ -2411,9 +2411,13 @@ static __device__ __forceinline__ void conv_wgrad3x3_body(const WgradGroup& g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int R = 64 / WT;                       // image rows per K tile
     constexpr int HR = R + 2 * D, HC = WT + 2 * D;   // halo tile (pixels)
-    constexpr int NH = HR * HC, NHP = (NH + 31) / 32 * 32;
-    constexpr int TA = 64 * 128, TB = NHP * 128, TILE = TA + TB;
-    constexpr int LA = 2, LB = NHP / 32;             // LDS-DMA instructions per wave per tile (8 rows each)
+    // the halo tile is padded to whole 8-row DMA pieces only (NG of them, 1 KiB each); the four waves take pieces i * 4 + wave,
+    // and where the last round has fewer than four pieces the surplus waves repeat the last one (same source, same
+    // destination, same bytes): every wave issues LD instructions per tile -- the counted vmcnt waits need that -- and the
+    // tile is 25 KB instead of 28 (WT = 32, D = 1: three stages of it fit a CU twice)
+    constexpr int NH = HR * HC, NG = (NH + 7) / 8, NHP = NG * 8;
+    constexpr int TA = 64 * 128, TB = (NHP * 128 + 1023) / 1024 * 1024, TILE = TA + TB;
+    constexpr int LA = 2, LB = (NG + 3) / 4;         // LDS-DMA instructions per wave per tile (8 rows each)
     constexpr int LD = LA + LB;
     static_assert(STAGES == 2 || STAGES == 3, "ring of 2 (two workgroups per CU) or 3 stages");
     __shared__ __attribute__((aligned(256))) unsigned char smem[STAGES * TILE];
@@ -2450,7 +2454,7 @@ static __device__ __forceinline__ void conv_wgrad3x3_body(const WgradGroup& g) {
     int bhr[LB], bhc[LB], bcol[LB];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        int h = (i * 4 + wave) * 8 + lr;
+        int h = min(i * 4 + wave, NG - 1) * 8 + lr;
         int col = ci0 + swz(h, ls) * 8;
         bool ok = (h < NH) && (col < a.Cin);
         bhr[i] = ok ? (h / HC - D) : -100000;             // row / column of the halo pixel relative to the tile origin
@@ -2465,13 +2469,13 @@ static __device__ __forceinline__ void conv_wgrad3x3_body(const WgradGroup& g) {
 #pragma unroll
         for (int i = 0; i < LA; ++i)
             dma16_to_lds(rs_a, ab + i * 4096, avo[i], so_a);
-        unsigned char* bb = ab + TA;
+        unsigned char* bb = smem + stage * TILE + TA;
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             int y = y0 + bhr[i], x = x0 + bhc[i];
             bool ok = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
             int vo = ok ? (((n * a.H + y) * a.W + x) * a.ldx * 2 + bcol[i]) : OOB;
-            dma16_to_lds(rs_b, bb + i * 4096, vo, 0);
+            dma16_to_lds(rs_b, bb + min(i * 4 + wave, NG - 1) * 1024, vo, 0);
         }
     };
 
@@ -2722,7 +2726,12 @@ static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipS
     const int items = g.first[RGDA_WGRAD_MAXG];
     // keeping a layer's work items on one XCD (one L2) pays where the items of a layer re-read the same rows many
     // times (the taps of the small-channel 3x3 layers in the 64x64 kernel: 297 -> 220 us; tap-fused: 2 %); the
-    // grouped 1x1 layers of the 128x128 kernel measured 9 % SLOWER with it (207 -> 225 us), so they keep b -> item b
+    // grouped 1x1 layers of the 128x128 kernel measured 9 % SLOWER with it (207 -> 225 us), so they keep b -> item b.
+    // (Round 5, measured and not kept: a finer mapping for those -- the result tiles of one (layer, K split), which stream the
+    // same pixel rows, in consecutive slots of ONE XCD, the units round-robin over the XCDs, so that the 1.5 x over-fetch of
+    // b -> item b (FETCH_SIZE 1.0 GB against 0.67 GB unique per 16-layer launch) would hit one L2: conv_wgrad_kernel<256, 128>
+    // 194 -> 226 us, step +0.28 ms (interleaved A/B).  32 workgroups x 3 stages x 48 KB in flight per XCD exceed its 4 MB
+    // L2; the launches run at 5.2 TB/s of fabric reads either way and spreading a unit over four L2s is what reaches it.)
     g.remap = (kind != WK_G128_128 && kind != WK_G256_128);
     if (const char* e = TUNE_ENV("RGDA_WGRAD_REMAP")) g.remap = atoi(e);                   // tuning experiments only
     switch (kind) {
@@ -2733,7 +2742,10 @@ static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipS
         case WK_G256_128: conv_wgrad_kernel<256, 128, 4, 2><<<items, 512, 0, st>>>(g); break;
         case WK_F64_1: conv_wgrad3x3_wide_kernel<64, 1, 3><<<items, 256, 0, st>>>(g); break;  // (capped at 256 registers it spills)
         case WK_F64_2: conv_wgrad3x3_wide_kernel<64, 2, 3><<<items, 256, 0, st>>>(g); break;  // 52 KB per stage: one per CU either way
-        case WK_F32_1: conv_wgrad3x3_kernel<32, 1, 2><<<items, 256, 0, st>>>(g); break;       // 56 KB
+        // (round 5: with the compact halo tile THREE stages fit a CU twice (75 KB); measured 296 against 294 us per launch and
+        // +0.2 ms on the step: the loop does not wait for its DMA -- the other workgroup of the CU covers it -- and the
+        // larger footprint costs the neighbouring streams' kernels their place)
+        case WK_F32_1: conv_wgrad3x3_kernel<32, 1, 2><<<items, 256, 0, st>>>(g); break;       // 50 KB
         case WK_F32_2: conv_wgrad3x3_wide_kernel<32, 2, 3><<<items, 256, 0, st>>>(g); break;  // (capped at 256 registers it spills)
         case WK_F16_1: conv_wgrad3x3_kernel<16, 1, 3><<<items, 256, 0, st>>>(g); break;       // 72 KB
         default: conv_wgrad3x3_kernel<16, 2, 2><<<items, 256, 0, st>>>(g); break;              // 56 KB

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--serial', action='store_true', help='one stream only (clean per-kernel profiles)')
     ap.add_argument('--grad-payload', default='fp32', choices=['fp32', 'bf16'], help="gradient exchange: 'fp32' bucketed all-reduce (default), 'bf16' all-to-all + fp32 accumulation + all-gather of bf16 payloads (half the bytes per link)")
+    ap.add_argument('--comm', default='torch', choices=['torch', 'abi'], help="who issues the collectives: 'torch' = torch.distributed (backend nccl = RCCL; default), 'abi' = the library's own RCCL entry points (rgda_comm_*; the communicator id travels through the process group's store)")
     ap.add_argument('--no-comm-overlap', action='store_true', help='all-reduce the whole gradient after backward instead of bucket by bucket during it')
     ap.add_argument('--eager', action='store_true', help='one Python -> ctypes call per launch instead of the recorded launch plan (regda_amd/plan.py, the default)')
     ap.add_argument('--no-h2d', action='store_true', help='reuse one device-resident batch instead of staging a fresh pinned host batch per step over a copy stream')
@@ -412,8 +413,12 @@ def main():
         model.sync_weights()
     protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(0))
     teacher = not args.no_teacher
+    comm = None
+    if args.comm == 'abi' and dist.is_initialized():
+        from regda_amd.ddp import RcclComm
+        comm = RcclComm.from_torch_store()
     step = SSLStep(model, protos, ema_decay=0.999 if teacher else None, overlap_wgrad=not args.serial, overlap_comm=not args.no_comm_overlap,
-                   grad_payload=args.grad_payload)
+                   grad_payload=args.grad_payload, comm=comm)
     step.measure_comm = world > 1 or bool(os.environ.get('RGDA_FORCE_DDP'))
     batch = make_batch(b=args.batch, size=args.size, seed=2333 + rank, with_soft=not teacher)
     soft = batch.get('soft_t')
@@ -510,7 +515,7 @@ def main():
             t = torch.tensor([mine], device='cuda', dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             worst = float(t.item())
-        comm = {'rank0_ms': mine, 'max_over_ranks_ms': worst, 'payload': args.grad_payload,
+        comm = {'rank0_ms': mine, 'max_over_ranks_ms': worst, 'payload': args.grad_payload, 'issued_by': args.comm,
                 'mb_per_step_per_rank': step.reducer.flat_g.numel() * (4 if args.grad_payload == 'fp32' else 2) / 1e6,
                 'what': 'main-stream stall at the join with the bucketed gradient exchange (HIP events around reducer.finish), last timed step'}
         # when each bucket left (its gradients final), relative to the start of backward and to the join -- what overlaps

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGDA_ABI_VERSION 9
+#define RGDA_ABI_VERSION 10
 /* Per-channel statistics are accumulated into RGDA_STAT_REPLICAS interleaved copies (workgroup b adds to
  * copy b % 8, i.e. the copy of the XCD it runs on, so the atomics stay inside one XCD's L2); consumers
  * sum the copies.  A "stats"/"sums" buffer is therefore rgda_stat_t[RGDA_STAT_REPLICAS][2][C], zeroed by the caller.
@@ -499,6 +499,32 @@ int rgda_cast_f32(const void* src_bf16, float* dst, int64_t n, rgda_stream_t str
  * it (all-to-all); out bf16 [shard_elems] = bf16(sum over ranks IN RANK ORDER of float(recv[r])) -- the same bits on
  * every rank.  shard_elems % 8 == 0. */
 int rgda_ddp_accumulate_bf16(const void* recv, int world, void* out, int64_t shard_elems, rgda_stream_t stream);
+
+/* ---- the collectives themselves, through RCCL (xGMI), for a host without torch.distributed ("RCCL wrappers
+ * for (e)"; the reference is single-GPU, tools/train_ssl_reg.py has no counterpart).  One communicator per process and
+ * GPU: rank 0 draws the 128-byte id (rgda_comm_unique_id) and the HOST ships it to the other ranks by whatever channel it
+ * has (a file, a socket, MPI, a torch.distributed store); every rank then calls rgda_comm_init on the device it has made
+ * current.  The calls enqueue on the caller's stream like every other entry point; buffers are caller-owned device
+ * memory.  dtype: RGDA_COMM_*.  librccl.so is resolved at the first call (a copy the process already holds is
+ * preferred); without it these return RGDA_ERR_UNSUPPORTED and nothing else of the library is affected.
+ *   all_reduce : buf[n] <- sum over ranks, in place (the flat fp32 gradient's buckets, the prototype statistics
+ *                sums[c][k] + cnt[c] of rgda_proto_stats, ClassBalance's int64 pixel counts)
+ *   all_to_all : rank r's send[j * n_per_rank ...] -> rank j's recv[r * n_per_rank ...]   (bf16 payload, phase 1)
+ *   all_gather : recv[r * n_per_rank ...] <- rank r's send[n_per_rank]                    (bf16 payload, phase 2) */
+typedef void* rgda_comm_t;
+#define RGDA_COMM_ID_BYTES 128
+#define RGDA_COMM_F32 0
+#define RGDA_COMM_BF16 1
+#define RGDA_COMM_I64 2
+#define RGDA_COMM_F64 3
+int rgda_comm_unique_id(void* id_128_bytes);
+int rgda_comm_init(const void* id_128_bytes, int rank, int world, rgda_comm_t* comm);
+int rgda_comm_destroy(rgda_comm_t comm);
+int rgda_comm_all_reduce(rgda_comm_t comm, void* buf, int64_t n, int dtype, rgda_stream_t stream);
+int rgda_comm_all_gather(rgda_comm_t comm, const void* send, void* recv, int64_t n_per_rank, int dtype,
+                         rgda_stream_t stream);
+int rgda_comm_all_to_all(rgda_comm_t comm, const void* send, void* recv, int64_t n_per_rank, int dtype,
+                         rgda_stream_t stream);
 /* rows of K f32 -> rows of Kp bf16, zero padded (stem weights [64][147] -> [64][192]); and the
  * reverse accumulation dst[R][K] f32 += src[R][Kp] f32 for the stem weight gradient. */
 int rgda_pad_cast_bf16(const float* src, void* dst, int R, int K, int Kp, rgda_stream_t stream);

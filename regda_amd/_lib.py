@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'rgda_hip.h')
 
 _CT = {
     'int': ctypes.c_int, 'float': ctypes.c_float, 'int64_t': ctypes.c_int64, 'size_t': ctypes.c_size_t,
-    'rgda_stream_t': ctypes.c_void_p, 'double': ctypes.c_double, 'uint64_t': ctypes.c_uint64,
+    'rgda_stream_t': ctypes.c_void_p, 'rgda_comm_t': ctypes.c_void_p, 'double': ctypes.c_double, 'uint64_t': ctypes.c_uint64,
 }
 
 

@@ -47,7 +47,7 @@ def make_buckets(boundaries, total, bucket_elems, tail_elems=None):
     return buckets
 
 
-def all_reduce_prototype_statistics(stats, class_num, feat_channels, group=None):
+def all_reduce_prototype_statistics(stats, class_num, feat_channels, group=None, comm=None):
     """Cross-rank state of `Aligner.update_prototype` (regda/gast/alignment.py:300-327).  `stats` is the flat
     float32 buffer rgda_proto_stats leaves: sums[c][k] (sum of the source features over the pixels of downscaled class c)
     followed by cnt[c].  Both ADD over batches, so one all-reduce (sum) of these class_num * (feat_channels + 1) floats
@@ -57,20 +57,93 @@ def all_reduce_prototype_statistics(stats, class_num, feat_channels, group=None)
     across ranks, and lets a rank without a class vote for the old prototype.)"""
     n = class_num * feat_channels + class_num
     assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= n
-    if dist.is_initialized():
+    if comm is not None:                    # an RcclComm: enqueued on the current stream
+        comm.all_reduce(stats[:n])
+    elif dist.is_initialized():
         dist.all_reduce(stats[:n], op=dist.ReduceOp.SUM, group=group)
     return stats
 
 
+class RcclComm:
+    """One RCCL communicator behind the C ABI (include/rgda_hip.h: rgda_comm_*): the collectives of the data-parallel step
+    for a host WITHOUT torch.distributed -- the wrappers SURVEY.md 8b lists in the boundary's op set.  Rank 0 draws the
+    128-byte id (`RcclComm.unique_id()`) and the host ships it to the other ranks (a file, a socket, MPI; in a torch
+    process `RcclComm.from_torch_store()` uses the default process group's store); every rank constructs the
+    communicator on its current device.  Calls enqueue on the given (default: the current) stream; tensors are
+    contiguous device tensors, reduced / exchanged in place as FlatGradReducer does with torch.distributed."""
+    _DT = {torch.float32: 0, torch.bfloat16: 1, torch.int64: 2, torch.float64: 3}       # RGDA_COMM_F32 / BF16 / I64 / F64
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        from ._lib import lib
+        buf = (ctypes.c_char * 128)()
+        lib().call('rgda_comm_unique_id', buf)
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, world):
+        import ctypes
+        from ._lib import lib
+        assert len(unique_id) == 128
+        self.rank, self.world = int(rank), int(world)
+        h = ctypes.c_void_p()
+        lib().call('rgda_comm_init', ctypes.c_char_p(unique_id), self.rank, self.world, ctypes.byref(h))
+        self._h = h
+
+    @classmethod
+    def from_torch_store(cls, key='rgda_comm_id'):
+        """Inside a torch.distributed job: the id travels through the default group's store, nothing else of torch is used."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set(key, cls.unique_id())
+        return cls(bytes(store.get(key)), rank, world)
+
+    def _args(self, t, stream):
+        assert t.is_cuda and t.is_contiguous() and t.dtype in self._DT, (t.device, t.dtype)
+        return self._DT[t.dtype], (stream if stream is not None else torch.cuda.current_stream()).cuda_stream
+
+    def all_reduce(self, t, stream=None):
+        from ._lib import lib
+        dt, st = self._args(t, stream)
+        lib().call('rgda_comm_all_reduce', self._h, t.data_ptr(), t.numel(), dt, st)
+
+    def all_gather(self, send, recv, stream=None):
+        from ._lib import lib
+        dt, st = self._args(send, stream)
+        assert recv.dtype == send.dtype and recv.is_contiguous() and recv.numel() == send.numel() * self.world
+        lib().call('rgda_comm_all_gather', self._h, send.data_ptr(), recv.data_ptr(), send.numel(), dt, st)
+
+    def all_to_all(self, send, recv, stream=None):
+        from ._lib import lib
+        dt, st = self._args(send, stream)
+        assert recv.dtype == send.dtype and recv.is_contiguous() and recv.numel() == send.numel() and send.numel() % self.world == 0
+        lib().call('rgda_comm_all_to_all', self._h, send.data_ptr(), recv.data_ptr(), send.numel() // self.world, dt, st)
+
+    def destroy(self):
+        if self._h is not None:
+            from ._lib import lib
+            lib().call('rgda_comm_destroy', self._h)
+            self._h = None
+
+
 class FlatGradReducer:
-    def __init__(self, flat_g, boundaries, bucket_elems=12 << 20, group=None, payload='fp32'):
+    def __init__(self, flat_g, boundaries, bucket_elems=12 << 20, group=None, payload='fp32', comm=None):
+        """comm: an `RcclComm` -- the buckets then go through the library's own RCCL entry points (on a stream of the
+        reducer's) instead of torch.distributed; None (default): torch.distributed on `group`."""
         assert payload in ('fp32', 'bf16')
         self.flat_g = flat_g
         self.group = group
         self.payload = payload
+        self.comm = comm
         import os
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.force = dist.is_initialized() and bool(os.environ.get('RGDA_FORCE_DDP'))   # single-GPU exercise of the path
+        if comm is not None:
+            assert flat_g.is_cuda
+            self.world = comm.world
+            self.force = bool(os.environ.get('RGDA_FORCE_DDP'))
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.force = dist.is_initialized() and bool(os.environ.get('RGDA_FORCE_DDP'))   # single-GPU exercise of the path
         self.buckets = make_buckets(boundaries, flat_g.numel(), bucket_elems)
         self._next = 0
         self._works = []
@@ -78,12 +151,14 @@ class FlatGradReducer:
         self.issue_events = []
         self._stage = {}            # bf16 payload: per-bucket staging buffers, allocated once
         self._comm_stream = None    # bf16 payload on a GPU: the two collectives and the kernels between them run here
+        if comm is not None and (self.world > 1 or self.force):
+            self._comm_stream = torch.cuda.Stream(device=flat_g.device)
         if payload == 'bf16' and (self.world > 1 or self.force):
             # every staging buffer and the stream exist before the first exchange: nothing is allocated inside a recorded
             # plan's private pool or on the communication stream
             for a, b in self.buckets:
                 self._staging(a, b)
-            if flat_g.is_cuda:
+            if flat_g.is_cuda and self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=flat_g.device)
 
     def reset(self):
@@ -113,9 +188,15 @@ class FlatGradReducer:
         if g.is_cuda:
             from . import ops
             ops.cast_bf16(g, st['send'])                    # (the tail of `send` beyond n stays zero)
-            dist.all_to_all_single(st['recv'], st['send'], group=self.group)
+            if self.comm is not None:
+                self.comm.all_to_all(st['send'], st['recv'])
+            else:
+                dist.all_to_all_single(st['recv'], st['send'], group=self.group)
             ops.ddp_accumulate_bf16(st['recv'], W, st['red'])
-            dist.all_gather_into_tensor(st['gath'], st['red'], group=self.group)
+            if self.comm is not None:
+                self.comm.all_gather(st['red'], st['gath'])
+            else:
+                dist.all_gather_into_tensor(st['gath'], st['red'], group=self.group)
             ops.cast_f32(st['gath'], g)
         else:       # gloo on CPU tensors (tests): the same arithmetic in torch
             st['send'][:n].copy_(g)
@@ -138,7 +219,11 @@ class FlatGradReducer:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()             # on the stream the bucket is issued from: when its gradients were final
                 self.issue_events.append((self._next, ev))
-            if self.payload == 'fp32':
+            if self.payload == 'fp32' and self.comm is not None:
+                # (the same shape as the bf16 route: a stream of the reducer's own behind the issuing stream)
+                self._comm_stream.wait_stream(torch.cuda.current_stream())
+                self.comm.all_reduce(self.flat_g[a:b], stream=self._comm_stream)
+            elif self.payload == 'fp32':
                 self._works.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group,
                                                    async_op=True))
             elif self.flat_g.is_cuda:

@@ -21,7 +21,7 @@ class SSLStep:
                  max_norm=32.0, cutoff_top=0.8, cutoff_low=0.6, percent=0.5, proto_decay=0.996, refine_temp=2.0,
                  sam_refine=True, refine_label=True, ema_decay=None, max_regions=4096, bucket_elems=12 << 20,
                  process_group=None, overlap_wgrad=True, overlap_comm=True, class_balancer_s=None,
-                 class_balancer_t=None, grad_payload='fp32'):
+                 class_balancer_t=None, grad_payload='fp32', comm=None):
         self.model = model
         self.C, self.ig = class_num, ignore_label
         self.momentum, self.wd, self.max_norm = momentum, weight_decay, max_norm
@@ -44,7 +44,10 @@ class SSLStep:
         bounds = model.param_boundaries()
         # grad_payload: 'fp32' = bucketed all-reduce of the fp32 gradient; 'bf16' = all-to-all + fp32 accumulation +
         # all-gather of bf16 payloads, half the bytes on every link (regda_amd/ddp.py)
-        self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group, payload=grad_payload)
+        # comm: a regda_amd.ddp.RcclComm -- the gradient buckets and the prototype statistics then go through the library's
+        # own RCCL entry points (rgda_comm_*) instead of torch.distributed
+        self.comm = comm
+        self.reducer = FlatGradReducer(model.flat_g, bounds, bucket_elems, process_group, payload=grad_payload, comm=comm)
         self.measure_comm = False   # bench: HIP events around the main stream's wait for the gradient exchange
         self.comm_events = None
         self.bwd_start_event = None
@@ -314,7 +317,7 @@ class SSLStep:
             if pside is not main and side is None:
                 plan.wait_event(pside, plan.record_event(main))
             def exchange_statistics():
-                all_reduce_prototype_statistics(self.proto_stats, self.C, self.prototypes.shape[1], self.group)
+                all_reduce_prototype_statistics(self.proto_stats, self.C, self.prototypes.shape[1], self.group, self.comm)
             with ops.use_stream(pside):
                 plan.host(exchange_statistics)
                 ops.proto_apply(self.prototypes, self.proto_stats, self.pdecay)

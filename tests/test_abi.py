@@ -7,7 +7,7 @@ from regda_amd import _lib
 def test_library_loads_and_exports_all_symbols():
     L = _lib.lib()
     assert L.missing == [], f'declared but not exported: {L.missing}'
-    assert L.raw('rgda_abi_version')() == 9
+    assert L.raw('rgda_abi_version')() == 10
     # the fixed-point formats of the per-channel accumulators (rgda_stat_t) as the Python side scales them
     import re
     from regda_amd import ops
@@ -28,6 +28,30 @@ def test_workspace_queries_and_argument_errors():
         L.call('rgda_lrh', None, None, None, 1, 16, 6, -1, 0.5, 16, None, 0, None)
     with pytest.raises(ValueError):
         L.call('rgda_pseudo_select', None, None, 1, 6, 16, 0.8, 0.6, -1, 0, None, 0, None)
+
+
+def test_rccl_wrappers_validate_their_arguments():
+    """rgda_comm_*: argument errors are reported before librccl.so is even looked for (no GPU, no RCCL needed here)."""
+    import ctypes
+    L = _lib.lib()
+    buf = (ctypes.c_char * 128)()
+    h = ctypes.c_void_p()
+    with pytest.raises(ValueError):
+        L.call('rgda_comm_unique_id', None)
+    for args in ((None, 0, 1, ctypes.byref(h)), (buf, 0, 1, None), (buf, 1, 1, ctypes.byref(h)), (buf, 0, 0, ctypes.byref(h))):
+        with pytest.raises(ValueError):
+            L.call('rgda_comm_init', *args)
+    fake = ctypes.c_void_p(16)
+    with pytest.raises(ValueError):
+        L.call('rgda_comm_destroy', None)
+    with pytest.raises(ValueError):
+        L.call('rgda_comm_all_reduce', None, fake, 8, 0, None)
+    with pytest.raises(ValueError):
+        L.call('rgda_comm_all_reduce', fake, fake, 8, 7, None)          # unknown dtype code
+    with pytest.raises(ValueError):
+        L.call('rgda_comm_all_gather', fake, fake, None, 8, 0, None)
+    with pytest.raises(ValueError):
+        L.call('rgda_comm_all_to_all', fake, fake, fake, 8, 1, None)    # send == recv
 
 
 def test_plan_replay_dispatch_table_and_error_rows():

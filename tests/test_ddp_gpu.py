@@ -32,7 +32,7 @@ def nccl_world1(monkeypatch):
     dist.destroy_process_group()
 
 
-def _run(steps, bucket_elems, overlap_comm=True, class_balance=False):
+def _run(steps, bucket_elems, overlap_comm=True, class_balance=False, comm=None, grad_payload='fp32'):
     from regda_amd.models.Encoder import Deeplabv2
     from regda_amd.ssl import SSLStep
     from regda_amd.synthetic import make_batch
@@ -45,7 +45,7 @@ def _run(steps, bucket_elems, overlap_comm=True, class_balance=False):
     m.set_drop_masks(ones, ones)
     b = make_batch(b=2, size=128, seed=13)
     st = SSLStep(m, torch.randn(6, 2048, generator=torch.Generator().manual_seed(3)), bucket_elems=bucket_elems,
-                 overlap_comm=overlap_comm)
+                 overlap_comm=overlap_comm, comm=comm, grad_payload=grad_payload)
     out = None
     for i in range(steps):
         out = st.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], lr=1e-3)
@@ -238,3 +238,45 @@ def test_bf16_payload_exchange_through_rccl(nccl_world1):
     (l32, p32), (l16, p16) = outs['fp32'], outs['bf16']
     assert l16[0] == pytest.approx(l32[0], rel=2e-3) and l16[1] == pytest.approx(l32[1], rel=2e-3, abs=2e-3)
     assert float((p16 - p32).norm() / p32.norm()) < 1e-4
+
+
+def test_rccl_entry_points_of_the_c_abi(monkeypatch):
+    """rgda_comm_* (include/rgda_hip.h; SURVEY.md 8b "RCCL wrappers for (e)") WITHOUT torch.distributed: a communicator of
+    one rank -- every collective is the identity -- for each dtype the step exchanges, then the SSL step with its gradient
+    buckets (fp32 and bf16 payload) and its prototype statistics routed through that communicator: it must reproduce the
+    step whose reducer is switched off.  (N > 1: the same entry points with the id shipped by the host; the driver's 8-GPU run.)"""
+    from regda_amd.ddp import FlatGradReducer, RcclComm
+    assert not dist.is_initialized()
+    comm = RcclComm(RcclComm.unique_id(), 0, 1)
+    try:
+        for dt in (torch.float32, torch.bfloat16, torch.int64, torch.float64):
+            x = (torch.arange(4096, device='cuda') % 97).to(dt)
+            ref = x.clone()
+            comm.all_reduce(x)
+            r1, r2 = torch.zeros_like(x), torch.zeros_like(x)
+            comm.all_gather(x, r1)
+            comm.all_to_all(x, r2)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            comm.all_reduce(x, stream=side)                      # an explicit stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            assert torch.equal(x, ref) and torch.equal(r1, ref) and torch.equal(r2, ref), dt
+        with pytest.raises(ValueError):
+            comm.all_to_all(x, x)                                # in place is refused (RGDA_ERR_ARG)
+        monkeypatch.setenv('RGDA_FORCE_DDP', '1')
+        runs = [_run(1, bucket_elems=1 << 20, comm=comm), _run(1, bucket_elems=1 << 20, comm=comm, grad_payload='bf16')]
+        for m1, st1, out1 in runs:
+            assert st1.reducer.comm is comm and st1.reducer.force and st1.reducer._next == len(st1.reducer.buckets) >= 3
+        monkeypatch.delenv('RGDA_FORCE_DDP')
+        m0, st0, out0 = _run(1, bucket_elems=1 << 20)
+        assert not st0.reducer.active
+        for (m1, st1, out1), wtol in zip(runs, (1e-4, 1e-4)):
+            assert out1[0] == pytest.approx(out0[0], rel=2e-2) and out1[1] == pytest.approx(out0[1], rel=3e-2, abs=1e-3)
+            cos = (m1.flat_g @ m0.flat_g / (m1.flat_g.norm() * m0.flat_g.norm())).item()
+            assert cos > 0.97, cos
+            assert ((m1.flat_p - m0.flat_p).norm() / m0.flat_p.norm()).item() < wtol
+            assert torch.equal(st1.prototypes, st0.prototypes)
+    finally:
+        torch.cuda.synchronize()
+        comm.destroy()

@@ -7,27 +7,31 @@ import torch.nn as nn
 from .. import ops
 
 
-def sync_class_counts(cnt, group=None):
+def sync_class_counts(cnt, group=None, comm=None):
     """Data-parallel runs: the per-class pixel counts of one step are summed over the ranks before the
     frequency EMA, so every rank carries the SAME `freq` (and class weights) -- the statistic of the global batch.
     With one process this is the reference's single-GPU arithmetic unchanged."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if comm is not None:                    # a regda_amd.ddp.RcclComm: the library's own RCCL entry point (fp32 counts)
+        if comm.world > 1:
+            comm.all_reduce(cnt)
+    elif dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     return cnt
 
 
 class ClassBalance(nn.Module):
-    def __init__(self, class_num=7, ignore_label=-1, decay=0.99, temperature=0.5, process_group=None):
+    def __init__(self, class_num=7, ignore_label=-1, decay=0.99, temperature=0.5, process_group=None, comm=None):
         super().__init__()
         assert temperature > 0
         self.class_num, self.ignore_label = class_num, ignore_label
         self.process_group = process_group
+        self.comm = comm            # regda_amd.ddp.RcclComm instead of torch.distributed
         self.decay, self.temperature, self.eps = decay, temperature, 1e-7
         self.freq = torch.ones([class_num], device='cuda').float() / class_num
 
     def ema_update(self, label):
         cnt = ops.class_count(label, self.class_num).float()          # per-class pixel counts
-        cnt = sync_class_counts(cnt, self.process_group)
+        cnt = sync_class_counts(cnt.contiguous(), self.process_group, self.comm)
         local = cnt / (cnt.sum() + self.eps)                           # balance.py:45-53
         self.freq = (1.0 - self.decay) * local + self.decay * self.freq
 

@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--no-teacher', action='store_true', help='offline soft labels (the reference\'s mode) instead of the online EMA teacher')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--full-json', default=os.path.join(ROOT, 'gpurun_out', 'bench_full.json'),
+                    help='where the FULL record goes (per-kernel roofline table, timing windows, host probes, CPU-baseline '
+                         'phases); stdout carries one short line with the contract keys, roofline and cpu_baseline')
     ap.add_argument('--serial', action='store_true', help='one stream only (clean per-kernel profiles)')
     ap.add_argument('--grad-payload', default='fp32', choices=['fp32', 'bf16'], help="gradient exchange: 'fp32' bucketed all-reduce (default), 'bf16' all-to-all + fp32 accumulation + all-gather of bf16 payloads (half the bytes per link)")
     ap.add_argument('--comm', default='torch', choices=['torch', 'abi'], help="who issues the collectives: 'torch' = torch.distributed (backend nccl = RCCL; default), 'abi' = the library's own RCCL entry points (rgda_comm_*; the communicator id travels through the process group's store)")
@@ -284,6 +287,54 @@ def host_cores():
     return max(1, n), info
 
 
+def _r(v, nd=4):
+    """Floats of the stdout line: 4 significant digits."""
+    if isinstance(v, float):
+        return float(f'{v:.{nd}g}')
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+def compact_line(res, full_path):
+    """The ONE stdout line: the bench contract's keys, `roofline` (dominant kernel + the 3x3 / all-convolution figures the
+    north star is stated on) and `cpu_baseline`, nothing else; everything `res` holds is in `full_path`."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'pairs_per_sec_per_gpu', 'rccl_ranks', 'plan_replay',
+            'host_enqueue_ms_per_step')
+    out = {k: res[k] for k in keep if k in res}
+    if res.get('with_h2d_staging'):
+        out['with_h2d_staging_pairs_per_s'] = res['with_h2d_staging']['pairs_per_s']
+    if res.get('comm_exposed_ms'):
+        c = res['comm_exposed_ms']
+        out['comm_exposed_ms'] = {k: c[k] for k in ('rank0_ms', 'max_over_ranks_ms', 'payload', 'issued_by') if k in c}
+    if res.get('replicas'):
+        out['replicas_identical'] = res['replicas']['identical']
+    rf = res.get('roofline')
+    if rf:
+        out['roofline'] = {k: rf[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel',
+                                              'launches_per_step', 'avg_launch_us', 'algorithmic_mb_per_launch',
+                                              'mfma_frac', 'step_executed_mfma_frac')}
+        out['roofline']['conv3x3'] = {k: rf['conv3x3'][k] for k in ('achieved', 'frac', 'unit', 'ms_per_step')}
+        out['roofline']['all_conv_kernels'] = {'achieved': rf['all_conv_kernels']['achieved'], 'unit': 'TFLOP/s',
+                                               'frac': rf['all_conv_kernels']['frac'],
+                                               'ms_per_step': rf['all_conv_kernels']['ms_per_step']}
+        if rf.get('conv1x1_stream'):
+            out['roofline']['conv1x1_stream_hbm_frac'] = rf['conv1x1_stream']['frac']
+    cb = res.get('cpu_baseline')
+    if cb:
+        out['cpu_baseline'] = {'value': cb['value'], 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'],
+                               'sample': f"oracle/step.py (PyTorch CPU fp32 port), b={cb.get('batch', '?')}+{cb.get('batch', '?')}, "
+                                         f"{cb['s_per_step']:.2f} s/step on {cb['cores']} threads"}
+    for k in ('align_step', 'teacher_harness'):
+        if res.get(k):
+            out[k + '_ms'] = res[k].get('ms_per_step', res[k].get('ms_per_tile'))
+    out['full_record'] = full_path
+    return _r(out)
+
+
 def cpu_baseline(args):
     """The CPU oracle (oracle/step.py: the reference's step restated in stock PyTorch fp32) on a bounded
     sample: b = cpu_batch + cpu_batch images, 1 warm-up + timed steps until ~20 s.  Threads = physical cores of one
@@ -326,7 +377,7 @@ def cpu_baseline(args):
         run()
         probe = time.time() - t1
         torch.set_num_threads(threads)
-    return dict(value=b / dt, unit='pairs/s', cores=threads, threads=threads, kind='port', host=limits,
+    return dict(value=b / dt, unit='pairs/s', cores=threads, threads=threads, kind='port', host=limits, batch=b,
                 s_per_step=dt, phases_s={k: v / n for k, v in phases.items()},
                 s_per_step_8_threads=probe,
                 sample=f'oracle/step.py (stock PyTorch CPU fp32, ' + ('online EMA teacher: eval forward + shadow update inside the step' if teacher else 'offline soft labels') + f'), {args.model}, b={b}+{b} {args.size}x{args.size}, '
@@ -684,10 +735,20 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
+        # The full record (per-kernel table, windows, host probes, phase splits) goes to a FILE; stdout carries ONE short line
+        # (< 1.8 KB: whoever keeps only the tail of stdout still holds every contract key, `roofline` and `cpu_baseline` whole).
+        full_path = args.full_json
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+            with open(full_path, 'w') as f:
+                json.dump(res, f)
+        except OSError as e:
+            print(f'bench.py: could not write {full_path}: {e}', file=sys.stderr)
+            full_path = None
         # RCCL prints a version banner through C stdio, which a pipe or file buffers until the process exits -- behind
         # anything Python printed.  Drain it first so that the JSON line is the LAST line of stdout.
         flush_c_stdio()
-        print(json.dumps(res), flush=True)
+        print(json.dumps(compact_line(res, full_path)), flush=True)
 
 
 if __name__ == '__main__':

@@ -53,11 +53,14 @@ class AlignStep(SSLStep):
         s1, t1, s2, t2 = x1[:nb], x1[nb:], x2[:nb], x2[nb:]
         feat_s, feat_t = feat[:nb], feat[nb:]
         # ema-updating prototypes comes first here (train_align_reg.py:157): the target branch sees the new ones
-        if self.world > 1:
-            # data-parallel ranks: all-reduce the sufficient statistics (per-class feature sums, pixel counts) and apply the
-            # totals -- the prototypes of the concatenated global batch, identical on every rank (SSLStep does the same)
+        if self.reducer.active:
+            # data-parallel ranks (or RGDA_FORCE_DDP at world 1, as in SSLStep): all-reduce the sufficient statistics
+            # (per-class feature sums, pixel counts) and apply the totals -- the prototypes of the concatenated global
+            # batch, identical on every rank.  Through the step's communicator when it has one (`comm=`: the torch-free
+            # route), else through torch.distributed on `process_group`
             self.proto_stats, label_s_down = ops.proto_stats(feat_s, label_s, 16, self.ig, 0.75, self.C, stats=self.proto_stats)
-            all_reduce_prototype_statistics(self.proto_stats, self.C, self.prototypes.shape[1], self.group)
+            all_reduce_prototype_statistics(self.proto_stats, self.C, self.prototypes.shape[1], self.group, self.comm,
+                                            world=self.world)
             ops.proto_apply(self.prototypes, self.proto_stats, self.pdecay)
         else:
             label_s_down = ops.proto_update(feat_s, label_s, self.prototypes, 16, self.ig, 0.75, self.pdecay)

@@ -19,6 +19,12 @@ typedef int (*fn_destroy)(nccl_comm);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, nccl_comm, hipStream_t);
 typedef int (*fn_all_to_all)(const void*, void*, size_t, int, nccl_comm, hipStream_t);
+typedef int (*fn_get_version)(int*);
+
+// The ncclDataType_t / ncclRedOp_t values below are written out by hand (rccl.h is not a build dependency); they have been
+// stable since NCCL 2.10 (where ncclBfloat16 = 9 arrived) and ncclAllToAll exists in RCCL from 2.7 on: a library that
+// reports an older version -- or none -- is refused instead of being called with enum values it may read differently.
+constexpr int kMinNcclVersion = 21000;     // ncclGetVersion's encoding from 2.9 on: major * 10000 + minor * 100 + patch
 
 struct Rccl {
     void* h = nullptr;
@@ -36,12 +42,22 @@ const Rccl& rccl() {
         Rccl r;
         // a copy already mapped into the process first (RTLD_NOLOAD): two RCCL instances in one process would each
         // bootstrap their own topology and compete for the same xGMI channels
+        // (0) whatever RCCL the process ALREADY holds, under any file name or soname (torch bundles its own copy and
+        // loads it by path): the global symbol scope answers for it; the handle that owns the symbol is recovered with
+        // dladdr so that every entry point below comes from that same copy
+        if (void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce")) {
+            Dl_info info;
+            if (dladdr(sym, &info) && info.dli_fname) r.h = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+        }
         const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char* n : names)
             if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         for (const char* n : names)
             if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!r.h) return r;
+        fn_get_version get_version = (fn_get_version)dlsym(r.h, "ncclGetVersion");
+        int version = 0;
+        if (!get_version || get_version(&version) != 0 || version < kMinNcclVersion) return r;      // r.ok stays false
         r.get_uid = (fn_get_uid)dlsym(r.h, "ncclGetUniqueId");
         r.init_rank = (fn_init_rank)dlsym(r.h, "ncclCommInitRank");
         r.destroy = (fn_destroy)dlsym(r.h, "ncclCommDestroy");

@@ -792,6 +792,9 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     static_assert(!(PF && XF) || PXW + 3 <= 9, "... and transformed");
     constexpr int XFTAB = XF ? RGDA_BNIN_MAX_C * 2 * 4 : 0;
     static_assert(EPI <= SMEM && SMEM + XFTAB <= 160 * 1024, "LDS budget");
+    // the pipelined loop leaves 'dead' (out-of-range, zero-depositing) weight DMAs of tiles >= KT in flight when it exits;
+    // they land in weight stages, which the epilogue's staging image must therefore never reach
+    static_assert(!PF || EPI <= 2 * XS, "the epilogue image stays inside the two halo buffers (late weight DMAs land behind it)");
     static_assert(!XF || PXW + 2 <= 9, "every piece of the next slab is transformed before the slab ends");
     __shared__ __attribute__((aligned(256))) unsigned char smem[SMEM + XFTAB];
     unsigned char* const sxb = smem;

@@ -47,20 +47,27 @@ def make_buckets(boundaries, total, bucket_elems, tail_elems=None):
     return buckets
 
 
-def all_reduce_prototype_statistics(stats, class_num, feat_channels, group=None, comm=None):
+def all_reduce_prototype_statistics(stats, class_num, feat_channels, group=None, comm=None, world=None):
     """Cross-rank state of `Aligner.update_prototype` (regda/gast/alignment.py:300-327).  `stats` is the flat
     float32 buffer rgda_proto_stats leaves: sums[c][k] (sum of the source features over the pixels of downscaled class c)
     followed by cnt[c].  Both ADD over batches, so one all-reduce (sum) of these class_num * (feat_channels + 1) floats
     gives every rank the statistics of the concatenated global batch; rgda_proto_apply then forms
     sums / (cnt + 1e-7), keeps the old prototype where the GLOBAL count is < 1, and does the EMA -- what the reference
     computes on the whole batch.  (Averaging per-rank prototypes is a different number whenever class counts differ
-    across ranks, and lets a rank without a class vote for the old prototype.)"""
+    across ranks, and lets a rank without a class vote for the old prototype.)
+
+    world: what the CALLER believes the number of ranks is.  With more than one rank there must be something to exchange
+    through -- an RcclComm or an initialised process group; silently applying the local statistics would let the
+    prototypes of the ranks drift apart."""
     n = class_num * feat_channels + class_num
     assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() >= n
     if comm is not None:                    # an RcclComm: enqueued on the current stream
         comm.all_reduce(stats[:n])
     elif dist.is_initialized():
         dist.all_reduce(stats[:n], op=dist.ReduceOp.SUM, group=group)
+    elif world is not None and world > 1:
+        raise RuntimeError('prototype statistics of %d ranks cannot be exchanged: no RcclComm was given and '
+                           'torch.distributed is not initialised' % world)
     return stats
 
 
@@ -70,7 +77,16 @@ class RcclComm:
     128-byte id (`RcclComm.unique_id()`) and the host ships it to the other ranks (a file, a socket, MPI; in a torch
     process `RcclComm.from_torch_store()` uses the default process group's store); every rank constructs the
     communicator on its current device.  Calls enqueue on the given (default: the current) stream; tensors are
-    contiguous device tensors, reduced / exchanged in place as FlatGradReducer does with torch.distributed."""
+    contiguous device tensors, reduced / exchanged in place as FlatGradReducer does with torch.distributed.
+
+    Threading and ordering contract (RCCL's, restated because the step leans on it): ONE host thread drives a
+    communicator, and every rank issues the SAME collectives in the SAME host order.  The step issues them from more than
+    one stream -- gradient buckets on the reducer's communication stream, the 48 KB prototype statistics on the second
+    (weight-gradient) stream, ClassBalance's counts on the current stream: RCCL serialises the collectives of one
+    communicator in host issue order whatever stream each was enqueued on (a later one waits for the earlier one's
+    kernel), so a small collective issued between two buckets delays the second bucket by its latency (~20-50 us) and no
+    more; what must never happen is two ranks issuing in different orders, which the step's static launch sequence rules
+    out.  `tests/test_ddp_gpu.py::test_two_rank_rccl_step` runs buckets + statistics at world 2 where two GPUs exist."""
     _DT = {torch.float32: 0, torch.bfloat16: 1, torch.int64: 2, torch.float64: 3}       # RGDA_COMM_F32 / BF16 / I64 / F64
 
     @staticmethod
@@ -84,17 +100,25 @@ class RcclComm:
     def __init__(self, unique_id, rank, world):
         import ctypes
         from ._lib import lib
+        self._h = None
         assert len(unique_id) == 128
         self.rank, self.world = int(rank), int(world)
         h = ctypes.c_void_p()
         lib().call('rgda_comm_init', ctypes.c_char_p(unique_id), self.rank, self.world, ctypes.byref(h))
         self._h = h
 
+    _store_serial = 0       # communicators made through the store so far, in this process (identical on every rank)
+
     @classmethod
     def from_torch_store(cls, key='rgda_comm_id'):
-        """Inside a torch.distributed job: the id travels through the default group's store, nothing else of torch is used."""
+        """Inside a torch.distributed job: the id travels through the default group's store, nothing else of torch is used.
+        Every call uses a fresh store key (`key` + a per-process serial that advances identically on all ranks, since
+        every rank makes the same communicators in the same order): a second communicator can never pick up the first
+        one's id while rank 0 has not yet published the new one."""
         rank, world = dist.get_rank(), dist.get_world_size()
         store = dist.distributed_c10d._get_default_store()
+        key = '%s/%d' % (key, cls._store_serial)
+        cls._store_serial += 1
         if rank == 0:
             store.set(key, cls.unique_id())
         return cls(bytes(store.get(key)), rank, world)
@@ -125,6 +149,14 @@ class RcclComm:
             from ._lib import lib
             lib().call('rgda_comm_destroy', self._h)
             self._h = None
+
+    def __del__(self):
+        # a communicator nobody destroyed: best effort (never raise out of a finalizer; at interpreter exit the library
+        # or the device may already be gone)
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 class FlatGradReducer:

@@ -317,7 +317,8 @@ class SSLStep:
             if pside is not main and side is None:
                 plan.wait_event(pside, plan.record_event(main))
             def exchange_statistics():
-                all_reduce_prototype_statistics(self.proto_stats, self.C, self.prototypes.shape[1], self.group, self.comm)
+                all_reduce_prototype_statistics(self.proto_stats, self.C, self.prototypes.shape[1], self.group, self.comm,
+                                                world=self.world)
             with ops.use_stream(pside):
                 plan.host(exchange_statistics)
                 ops.proto_apply(self.prototypes, self.proto_stats, self.pdecay)

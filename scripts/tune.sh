@@ -94,7 +94,7 @@ profiles)
   python scripts/lib/prof_summary.py gpurun_out/prof_o/r_results.db 5 > gpurun_out/${tag}_kernel_stats_overlapped.txt
   grep '"metric"' gpurun_out/prof_o.log >> gpurun_out/${tag}_kernel_stats_overlapped.txt; rm -rf gpurun_out/prof_o
   # ---- the bench lines
-  timeout 900 python bench.py --phases > gpurun_out/${tag}_bench_1gpu.json 2> gpurun_out/${tag}_bench_1gpu.err
+  timeout 900 python bench.py --phases --full-json gpurun_out/${tag}_bench_1gpu_full.json > gpurun_out/${tag}_bench_1gpu.json 2> gpurun_out/${tag}_bench_1gpu.err
   grep ' ms  ' gpurun_out/${tag}_bench_1gpu.err > gpurun_out/${tag}_step_phases.txt
   { echo "box: $(hostname)  date: $(date -u +%FT%TZ)  commit: ${GRAFT_COMMIT:-see profiles/README.md}"; rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1; } > gpurun_out/${tag}_provenance.txt
   cut -c1-900 gpurun_out/${tag}_bench_1gpu.json; cat gpurun_out/${tag}_step_phases.txt ;;

@@ -53,6 +53,24 @@ def _run(steps, bucket_elems, overlap_comm=True, class_balance=False, comm=None,
     return m, st, [float(x.item()) for x in out]
 
 
+def _run_align(comm=None):
+    from regda_amd.align import AlignStep
+    from regda_amd.models.Encoder import Deeplabv2
+    from regda_amd.synthetic import make_batch
+    rt = 'resnet17t'
+    m = Deeplabv2(dict(backbone=dict(resnet_type=rt, output_stride=16, pretrained=False), multi_layer=True,
+                       cascade=False, use_ppm=True, ppm=dict(num_classes=6, use_aux=False, fc_dim=2048),
+                       inchannels=2048, num_classes=6, is_ins_norm=True))
+    m.load_state_dict(omodel.init_state_dict(rt, 6, seed=2), strict=True)
+    ones = torch.ones(4, 512)
+    m.set_drop_masks(ones, ones)
+    b = make_batch(b=2, size=128, seed=13)
+    st = AlignStep(m, torch.randn(6, 2048, generator=torch.Generator().manual_seed(3)), bucket_elems=1 << 20, comm=comm)
+    out = st.step(b['images_s'], b['label_s'], b['images_t'], b['regs_t'], lr=1e-3)
+    torch.cuda.synchronize()
+    return m, st, [float(x.item()) for x in out]
+
+
 def test_forced_rccl_step_equals_plain_step(nccl_world1):
     from regda_amd.ddp import FlatGradReducer
     m1, st1, out1 = _run(1, bucket_elems=1 << 20)                   # small buckets: several all-reduces per step
@@ -277,6 +295,49 @@ def test_rccl_entry_points_of_the_c_abi(monkeypatch):
             assert cos > 0.97, cos
             assert ((m1.flat_p - m0.flat_p).norm() / m0.flat_p.norm()).item() < wtol
             assert torch.equal(st1.prototypes, st0.prototypes)
+        # the stage-2 step takes the same route: its prototype statistics go through the communicator too (they used to
+        # bypass it, and without torch.distributed silently stayed local)
+        monkeypatch.setenv('RGDA_FORCE_DDP', '1')
+        a1 = _run_align(comm=comm)
+        assert a1[1].reducer.active and a1[1].comm is comm and a1[1].proto_stats is not None
+        monkeypatch.delenv('RGDA_FORCE_DDP')
+        a0 = _run_align()
+        assert not a0[1].reducer.active and a0[1].proto_stats is None
+        assert a1[2][0] == pytest.approx(a0[2][0], rel=2e-2) and a1[2][1] == pytest.approx(a0[2][1], rel=3e-2, abs=1e-3)
+        assert torch.allclose(a1[1].prototypes, a0[1].prototypes, rtol=1e-5, atol=1e-6)
     finally:
         torch.cuda.synchronize()
         comm.destroy()
+
+
+def test_prototype_statistics_refuse_to_stay_local_at_world_2():
+    """No communicator, no process group, but the caller says there are two ranks: raise instead of applying local totals."""
+    from regda_amd.ddp import all_reduce_prototype_statistics
+    assert not dist.is_initialized()
+    stats = torch.zeros(6 * 2048 + 6, device='cuda')
+    all_reduce_prototype_statistics(stats, 6, 2048, world=1)
+    with pytest.raises(RuntimeError):
+        all_reduce_prototype_statistics(stats, 6, 2048, world=2)
+
+
+@pytest.mark.parametrize('nproc', [1, 2])
+def test_multi_rank_rccl_step(nproc):
+    """A REAL N-rank RCCL step (one process per GPU, `torch.distributed.run`): tests/ddp_rank_worker.py runs the SSL step
+    with both gradient payloads through torch.distributed and through the library's own rgda_comm_* entry points and
+    asserts, on every rank, exchanged gradient == sum of the single-rank gradients and identical weight / gradient /
+    prototype bits across ranks.  nproc = 1 runs everywhere (the worker's whole code path on one GPU); nproc = 2 needs
+    two GPUs and is skipped on the single-GPU boxes of this pool -- the first multi-GPU box exercises it before any
+    scaling run does."""
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < nproc:
+        pytest.skip(f'{nproc} GPUs needed, {torch.cuda.device_count()} visible')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('RGDA_FORCE_DDP', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(root, 'tests', 'ddp_rank_worker.py')]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert any(l.startswith('MULTI_RANK_OK ') for l in r.stdout.splitlines()), r.stdout[-2000:]

@@ -331,7 +331,7 @@ def compact_line(res, full_path):
     for k in ('align_step', 'teacher_harness'):
         if res.get(k):
             out[k + '_ms'] = res[k].get('ms_per_step', res[k].get('ms_per_tile'))
-    out['full_record'] = full_path
+    out['full_record'] = os.path.relpath(full_path, ROOT) if full_path else None
     return _r(out)
 
 

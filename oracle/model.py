@@ -145,10 +145,12 @@ def bottleneck(y, sd, spec, training=True, new_stats=None, rb=lambda t: t):
     return rb(F.relu(o + idt))
 
 
-def heads(y, sd, training=True, drop_masks=None, new_stats=None, rb=lambda t: t, tap=lambda name, t: t):
+def heads(y, sd, training=True, drop_masks=None, new_stats=None, rb=lambda t: t, tap=lambda name, t: t, rb_tail=None):
     """Instance norm + the two heads on the layer-4 output y (regda/models/Encoder.py:8-65,68-84,123,146-151):
     returns ([logits of layer5, logits of layer6], feat)."""
     aspp = 'layer5.conv2d_list.0.weight' in sd
+    if rb_tail is None:         # rounding of the last two stored tensors of a head (the 512-channel conv and its activation)
+        rb_tail = rb
     feat = F.instance_norm(y, eps=1e-5)                       # Encoder.py:123,146-147
     tap('feat', feat)
     featq = rb(feat)
@@ -168,11 +170,11 @@ def heads(y, sd, training=True, drop_masks=None, new_stats=None, rb=lambda t: t,
             parts.append(rb(F.interpolate(q, size, mode='bilinear', align_corners=False)))
         cat = torch.cat(parts, 1)
         tap(head + '.cat', cat)
-        o = rb(F.conv2d(cat, sd[f'{head}.conv_last.0.weight'], None, 1, 1))
+        o = rb_tail(F.conv2d(cat, sd[f'{head}.conv_last.0.weight'], None, 1, 1))
         o = F.relu(_bn(o, sd, f'{head}.conv_last.1', training, new_stats))
         if training and drop_masks is not None:
             o = o * (drop_masks[hi].to(o.dtype) / 0.9)[:, :, None, None]
-        o = rb(o)
+        o = rb_tail(o)
         tap(head + '.hidden', o)
         o = F.conv2d(o, sd[f'{head}.conv_last.4.weight'], sd[f'{head}.conv_last.4.bias'])
         outs.append(o)
@@ -180,7 +182,7 @@ def heads(y, sd, training=True, drop_masks=None, new_stats=None, rb=lambda t: t,
 
 
 def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_stats=None,
-            taps=None, emulate_bf16=False):
+            taps=None, emulate_bf16=False, emulate_where=None):
     """Train: (x1, x2, feat).  Eval: per-pixel class probabilities at input size.
 
     emulate_bf16: numerics model of the HIP path -- conv weights/inputs and every stored
@@ -190,6 +192,10 @@ def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_
     2^-9 relative perturbation into ~25 % gradient changes (measured, DESIGN.md "Parity"),
     so gradients of a bf16 pipeline can only be compared tightly against this model; the
     plain fp32 path (emulate_bf16=False) is the reference semantics.
+
+    emulate_where: None = every storage point (the model of the HIP path); or a set out of {'weights', 'stem', 'layer1',
+    'layer2', 'layer3', 'layer4', 'head', 'tail'} -- round ONLY there (attribution of the rounding noise to a storage
+    point, tests/golden/attribute_teacher_noise.py; 'tail' = the heads' 512-channel conv output and its activation).
 
     drop_masks: optional (m5, m6), each (b,512) of {0,1}: the Dropout2d(0.1)
     channel keep-masks of the two heads (Encoder.py:39); kept channels are
@@ -205,18 +211,20 @@ def forward(sd, x, training=True, drop_masks=None, resnet_type='resnet101', new_
     # emulate_bf16 = 'grad': the activation gradients are rounded at the same points too (tests/golden/derive_tolerances.py)
     rb = (_RoundBoth.apply if emulate_bf16 == 'grad' else _rb) if emulate_bf16 else (lambda t: t)
     aspp = 'layer5.conv2d_list.0.weight' in sd
-    if emulate_bf16:
+    ident = lambda t: t
+    at = (lambda where: rb) if emulate_where is None else (lambda where: rb if where in emulate_where else ident)
+    if emulate_bf16 and at('weights') is not ident:
         sd = {k: (_rb(v) if (v.dim() == 4 and 'conv_last.4' not in k) else v) for k, v in sd.items()}
         x = _rb(x)
-    y = rb(F.conv2d(x, sd['encoder.resnet.conv1.weight'], None, 2, 3))
-    y = rb(F.relu(_bn(y, sd, 'encoder.resnet.bn1', training, new_stats)))
+    y = at('stem')(F.conv2d(x, sd['encoder.resnet.conv1.weight'], None, 2, 3))
+    y = at('stem')(F.relu(_bn(y, sd, 'encoder.resnet.bn1', training, new_stats)))
     tap('stem', y)
     y = F.max_pool2d(y, 3, 2, 1)
     tap('pool', y)
     for spec in layer_specs(resnet_type):
-        y = bottleneck(y, sd, spec, training, new_stats, rb)
+        y = bottleneck(y, sd, spec, training, new_stats, at(spec[0].split('.')[2]))      # 'encoder.resnet.layerN.i'
         tap(spec[0], y)
-    outs, feat = heads(y, sd, training, drop_masks, new_stats, rb, tap)
+    outs, feat = heads(y, sd, training, drop_masks, new_stats, at('head'), tap, rb_tail=at('tail'))
     if training:
         return outs[0], outs[1], feat
     x1 = F.interpolate(outs[0], x.shape[-2:], mode='bilinear', align_corners=True)

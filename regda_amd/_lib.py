@@ -51,6 +51,12 @@ class _Lib:
             raise ImportError(
                 f'{LIB_PATH} is missing: the HIP extension has not been built. regda_amd has no CPU '
                 f'fallback; run `make -C regda_amd/csrc` (or __graft_entry__.build()).')
+        # ONE HIP runtime per process: PyTorch (device memory, streams) ships its own libamdhip64 and this library is
+        # linked against /opt/rocm's.  Loaded after torch, the dependency resolves to the copy torch already mapped and the
+        # streams / pointers torch hands over belong to the runtime that launches the kernels; loaded BEFORE torch the two
+        # copies coexist and the first launch on a torch stream fails (seen with `python __graft_entry__.py smoke`, where
+        # build() loads the library for its export check before smoke() imports torch).
+        import torch  # noqa: F401
         self._dll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         self.missing = []

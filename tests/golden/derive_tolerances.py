@@ -129,6 +129,14 @@ def online_inputs(which):
     oracle/step.py: CpuStep(ema_decay=)).  'shallow': resnet17t, 4 + 4 images of 128 x 128; 'resnet101': 2 + 2 of 128 x 128."""
     if which == 'shallow':
         rt, sd, b, nb = 'resnet17t', omodel.init_state_dict('resnet17t', 6, seed=6), make_batch(b=4, size=128, seed=11, device='cpu'), 4
+    elif which == 'resnet101_512':
+        # the production tile, and WARM BatchNorm statistics: the reference's own buffers after 20 train-mode forwards
+        # (tests/golden/eval_warm.npz; same weights).  The 128 x 128 fixture starts from the (0, 1) initialisation, where the
+        # teacher's eval forward saturates and its mask noise says little about a run that is under way
+        sd = eval_warm_inputs()[0]
+        for head in ('layer5', 'layer6'):       # (undo eval_warm's classifier gain: ONLINE_CLS_GAIN is applied below)
+            sd[f'{head}.conv_last.4.weight'] = sd[f'{head}.conv_last.4.weight'] / float(np.load(os.path.join(HERE, 'eval_warm.npz'))['cls_gain'])
+        rt, b, nb = 'resnet101', make_batch(b=2, size=512, seed=12, device='cpu'), 2
     else:
         rt, sd, b, nb = 'resnet101', omodel.init_state_dict('resnet101', 6, seed=3, res_gamma=0.02), make_batch(b=2, size=128, seed=12, device='cpu'), 2
     # classifier gain 0.25: about half of the target pixels pass the teacher's 0.6 cut-off and the losses are O(1) (at the
@@ -276,6 +284,91 @@ def resnet101_full_fixture(res_gamma=FULL_RES_GAMMA):
     return out
 
 
+def config1_inputs(res_gamma=FULL_RES_GAMMA):
+    """The inputs of tests/test_ssl_step_gpu.py::test_full_size_config1_step_vs_oracle: BASELINE config[1]'s batch --
+    ResNet-101, 8 + 8 images of 512 x 512 (offline soft labels, all-ones dropout masks so both sides see the same net)."""
+    sd = omodel.init_state_dict('resnet101', 6, seed=5, res_gamma=res_gamma)
+    b = make_batch(b=8, size=512, seed=78, device='cpu')
+    protos = torch.randn(6, 2048, generator=torch.Generator().manual_seed(2))
+    ones = torch.ones(8, 512)
+    return sd, b, protos, ones
+
+
+def running_stat_noise(sd_a, sd_b):
+    """Distance of the BatchNorm running statistics of two state dicts, max over the layers: running_mean in units of the
+    layer's standard deviation, ||mean_a - mean_b|| / ||sqrt(var_b)|| (a relative measure would divide by ~0 wherever the
+    true mean is 0 -- the scale-1 PPM branch's input is an instance-normalised global average); running_var relative."""
+    out = {'running_mean': 0.0, 'running_var': 0.0}
+    for k in sd_b:
+        if k.endswith('running_mean'):
+            sv = sd_b[k[:-len('running_mean')] + 'running_var'].double().clamp_min(0).sqrt()
+            out['running_mean'] = max(out['running_mean'], float((sd_a[k].double() - sd_b[k].double()).norm() / (sv.norm() + 1e-30)))
+        elif k.endswith('running_var'):
+            out['running_var'] = max(out['running_var'], float((sd_a[k].double() - sd_b[k].double()).norm() / (sd_b[k].double().norm() + 1e-30)))
+    return out
+
+
+def resnet101_config1_fixture(res_gamma=FULL_RES_GAMMA):
+    """~4 minutes on 8 cores, ~16 GB: the fp32 and the bf16-emulating oracle step at 8 + 8 x 512 x 512."""
+    sd, b, protos, ones = config1_inputs(res_gamma)
+    res = []
+    for emu in (False, True):
+        cpu = CpuStep(sd, protos, resnet_type='resnet101', lr=1e-3, emulate_bf16=('grad' if emu else False))
+        res.append((cpu.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], (ones, ones), (ones, ones)), cpu))
+    (ref, cref), (emu, cemu) = res
+    n = noise(ref, emu, FULL_GRAD_NAMES)
+    out = {k: v for k, v in n.items() if not isinstance(v, dict)}
+    out['grad_cos_min'] = min(n['grad_cos'].values())
+    out['grad_cos'] = n['grad_cos']
+    out['grad_norm_ratio_dev_max'] = max(abs(v - 1) for v in n['grad_norm_ratio'].values())
+    out['protos_rel'] = float((cemu.prototypes - cref.prototypes).norm() / cref.prototypes.norm())
+    out['labelled_fraction'] = float((ref['hard'] >= 0).float().mean())
+    rs = running_stat_noise({k: v.detach() for k, v in cemu.sd.items()}, {k: v.detach() for k, v in cref.sd.items()})
+    out['bn_running_mean_rel'], out['bn_running_var_rel'] = rs['running_mean'], rs['running_var']
+    return out
+
+
+def eval_warm_inputs():
+    """tests/golden/eval_warm.npz (minted from the reference by make_goldens.gold_eval_warm): the state dict with the
+    reference's warm BatchNorm buffers, the eval input, the reference's probabilities."""
+    g = np.load(os.path.join(HERE, 'eval_warm.npz'))
+    sd = omodel.init_state_dict('resnet101', 6, seed=3, res_gamma=0.02)
+    for head in ('layer5', 'layer6'):
+        sd[f'{head}.conv_last.4.weight'] = sd[f'{head}.conv_last.4.weight'] * float(g['cls_gain'])
+    off = 0
+    for k, n in zip(g['buffer_names'], g['buffer_sizes']):
+        sd[str(k)] = torch.from_numpy(g['buffers'][off:off + int(n)].copy())
+        off += int(n)
+    for k in sd:
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.tensor(int(g['nbt']))
+    return sd, torch.from_numpy(g['xe']), torch.from_numpy(g['probs'])
+
+
+EVAL_DECISIVE_MARGIN = 0.05
+
+
+def eval_agreement(got, ref):
+    """mean |p - p_ref|, argmax agreement over all pixels, and over the pixels where the reference is DECISIVE (top-1 minus
+    top-2 probability > EVAL_DECISIVE_MARGIN) together with their share."""
+    top2 = ref.topk(2, 1)[0]
+    dec = (top2[:, 0] - top2[:, 1]) > EVAL_DECISIVE_MARGIN
+    same = got.argmax(1) == ref.argmax(1)
+    return dict(mean_abs=float((got - ref).abs().mean()), argmax_agree=float(same.float().mean()),
+                decisive_share=float(dec.float().mean()), decisive_disagree=float((~same & dec).float().sum() / dec.float().sum()))
+
+
+def eval_warm_fixture():
+    sd, xe, ref = eval_warm_inputs()
+    with torch.no_grad():
+        a = omodel.forward(sd, xe, False, None, 'resnet101')
+        b = omodel.forward(sd, xe, False, None, 'resnet101', emulate_bf16=True)
+    assert float((a - ref).abs().max()) < 1e-5         # the oracle IS the reference here (pinned by tests/test_oracle_golden.py)
+    out = eval_agreement(b, a)
+    out['argmax_disagree'] = 1.0 - out['argmax_agree']
+    return out
+
+
 def model_fixture(rt, sd, xs, lab, masks):
     """tests/test_model_gpu.py::_run_case: one train-mode forward + loss + backward of the network alone."""
     names = omodel.param_names(sd)
@@ -316,7 +409,10 @@ if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[1] == '--only':       # recompute the named fixtures, keep the rest of the table
         path = os.path.join(HERE, 'bf16_tolerances.json')
         table = json.load(open(path))
-        fns = {'shallow_online': lambda: online_fixture('shallow'), 'resnet101_online_128': lambda: online_fixture('resnet101')}
+        fns = {'shallow_online': lambda: online_fixture('shallow'), 'resnet101_online_128': lambda: online_fixture('resnet101'),
+               'resnet101_config1': lambda: dict(resnet101_config1_fixture(FULL_RES_GAMMA), res_gamma=FULL_RES_GAMMA),
+               'resnet101_online_512': lambda: online_fixture('resnet101_512'),
+               'resnet101_eval_warm': eval_warm_fixture}
         for name in sys.argv[2:]:
             table[name] = fns[name]()
             print(name, json.dumps(table[name], indent=1, sort_keys=True))
@@ -334,6 +430,9 @@ if __name__ == '__main__':
            'resnet101_full': dict(resnet101_full_fixture(FULL_RES_GAMMA), res_gamma=FULL_RES_GAMMA),
            'shallow_online': online_fixture('shallow'),
            'resnet101_online_128': online_fixture('resnet101'),
+           'resnet101_config1': dict(resnet101_config1_fixture(FULL_RES_GAMMA), res_gamma=FULL_RES_GAMMA),
+           'resnet101_online_512': online_fixture('resnet101_512'),
+           'resnet101_eval_warm': eval_warm_fixture(),
            'shallow_model': shallow_model_fixture(),
            'resnet101_model': resnet101_model_fixture()}
     with open(os.path.join(HERE, 'bf16_tolerances.json'), 'w') as f:

@@ -603,7 +603,45 @@ def gold_aspp():
     save('aspp.npz', **out)
 
 
+EVAL_WARM_CLS_GAIN = 0.1
+
+
+def gold_eval_warm():
+    """The eval branch (Encoder.py:152-155 -- the teacher's output) on WARM BatchNorm statistics: the reference ResNet-101
+    (oracle.model.init_state_dict(seed=3, res_gamma=0.02), the better-conditioned weights of model_mid.npz) sees 20
+    train-mode forwards of random 2 x 3 x 128 x 128 batches (running statistics 0.9^20 = 12 % away from what they converge
+    to; model_small.npz's eval output was taken two updates from the (0, 1) initialisation, where the logits saturate), then
+    one eval forward.  Saved: the eval input, the reference's probabilities and EVERY BatchNorm buffer of the reference at
+    that point (so that the HIP test starts from the reference's exact state and isolates the eval path)."""
+    m = build_ref_model()
+    sd = omodel.init_state_dict('resnet101', 6, seed=3, res_gamma=MID_RES_GAMMA)
+    # classifier gain 0.1: random-init 512 -> 6 classifiers give logits of +-30 and one-hot heads; at 0.1 the probabilities
+    # are soft (median top probability 0.28) and a probability error is visible instead of clipped
+    for head in ('layer5', 'layer6'):
+        sd[f'{head}.conv_last.4.weight'] = sd[f'{head}.conv_last.4.weight'] * EVAL_WARM_CLS_GAIN
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    g = torch.Generator().manual_seed(4242)
+    torch.manual_seed(4242)                 # Dropout2d draws of the train-mode forwards
+    with torch.no_grad():
+        for _ in range(20):
+            m(torch.randn(2, 3, 128, 128, generator=g))
+        m.eval()
+        xe = torch.randn(1, 3, 128, 128, generator=g).clamp(max=1.0)
+        probs = m(xe)
+    sdn = m.state_dict()
+    bufs = {k: v.numpy() for k, v in sdn.items() if k.endswith(('running_mean', 'running_var'))}
+    names = sorted(bufs)
+    flat = np.concatenate([bufs[k].ravel() for k in names]).astype(np.float32)
+    save('eval_warm.npz', xe=xe.numpy(), probs=probs.numpy(), cls_gain=np.float32(EVAL_WARM_CLS_GAIN), buffer_names=np.array(names),
+         buffer_sizes=np.array([bufs[k].size for k in names]), buffers=flat,
+         nbt=sdn['encoder.resnet.bn1.num_batches_tracked'].numpy())
+    conf = probs.max(1)[0]
+    print('eval_warm: argmax histogram', np.bincount(probs.argmax(1).numpy().ravel(), minlength=6).tolist(),
+          'max-prob quantiles', np.quantile(conf.numpy(), [0.1, 0.5, 0.9]).round(3).tolist())
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'model128', 'tta', 'pcl', 'align', 'aspp', 'regions', 'refine_sup']
+    which = sys.argv[1:] or ['lrh', 'pseudo', 'downscale', 'refine', 'loss', 'lr_ema', 'model', 'model128', 'tta', 'pcl', 'align', 'aspp', 'regions', 'refine_sup', 'eval_warm']
     for w in which:
         globals()['gold_' + w]()

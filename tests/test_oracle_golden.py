@@ -392,3 +392,23 @@ def test_bf16_tolerance_table_is_what_the_rounding_model_gives():
             if 'cos' in k:
                 v, w = 1.0 - v, 1.0 - w
             assert w <= 1.5 * v + 1e-6 and v <= 1.5 * w + 1e-6, (name, k, v, w)
+
+
+def test_eval_branch_on_warm_statistics_oracle_vs_reference():
+    """oracle.model.forward in eval mode against the reference's own probabilities on WARM BatchNorm statistics
+    (tests/golden/eval_warm.npz, make_goldens.gold_eval_warm: the reference ResNet-101 after 20 train-mode forwards, all of
+    its BatchNorm buffers in the fixture): the pin behind tests/test_model_gpu.py::
+    test_eval_branch_on_warm_statistics_vs_reference_golden."""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    spec = importlib.util.spec_from_file_location('derive_tolerances', os.path.join(here, 'derive_tolerances.py'))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    sd, xe, ref = D.eval_warm_inputs()
+    assert int(sd['encoder.resnet.bn1.num_batches_tracked']) == 20
+    with torch.no_grad():
+        got = model.forward(sd, xe, False, None, 'resnet101')
+    assert got.shape == ref.shape == (1, 6, 128, 128)
+    assert float((got - ref).abs().max()) < 1e-5
+    # a soft, well-conditioned output (the point of the fixture): no class above 0.9 anywhere, several classes in use
+    assert float(ref.max()) < 0.9 and len(np.unique(ref.argmax(1).numpy())) >= 4

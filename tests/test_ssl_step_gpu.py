@@ -127,7 +127,7 @@ def test_online_ema_teacher_and_reference_style_loop():
     assert not torch.equal(x1, x1b)
 
 
-@pytest.mark.parametrize('which', ['shallow', 'resnet101'])
+@pytest.mark.parametrize('which', ['shallow', 'resnet101', 'resnet101_512'])
 def test_online_teacher_steps_match_the_oracle_online_steps(which, capsys):
     """The ONLINE EMA teacher leg against the oracle's (oracle/step.py: CpuStep(ema_decay=); regda/utils/ema.py:41-54,
     regda/models/Encoder.py:152-155): two consecutive steps whose target soft labels come from the teacher's eval forward on
@@ -141,7 +141,9 @@ def test_online_teacher_steps_match_the_oracle_online_steps(which, capsys):
     from regda_amd.ssl import SSLStep
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
     import derive_tolerances as D
-    F = 'shallow_online' if which == 'shallow' else 'resnet101_online_128'
+    # 'resnet101_512': the same two steps on the production tile (2 + 2 x 512 x 512) -- the mask noise of the mode bench.py
+    # times, at the map size it times (tests/golden/teacher_noise_attribution.json says which storage points make it)
+    F = {'shallow': 'shallow_online', 'resnet101': 'resnet101_online_128', 'resnet101_512': 'resnet101_online_512'}[which]
     rt, sd, b, protos, ones = D.online_inputs(which)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     cpu = CpuStep(sd, protos, resnet_type=rt, lr=D.ONLINE_LR, ema_decay=D.ONLINE_DECAY)
@@ -592,6 +594,65 @@ def test_full_size_resnet101_step_vs_oracle(capsys):
     assert rep['soft_mean_abs'] < tol(F, 'soft_mean_abs') and rep['hard_mismatch'] < tol(F, 'hard_mismatch')
     assert rep['protos_rel'] < tol(F, 'protos_rel', floor=1e-4)
     # the integer chain is exact on the HIP path's own refined soft labels
+    regs = b['regs_t'].squeeze(1).numpy()
+    assert np.array_equal(olab.homogenize(olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1), regs, 0.5, 6, -1), hard)
+    for k in FULL_GRAD_NAMES:
+        assert cos[k] > bound[k], (k, cos[k], bound[k])
+    assert st.lrh_flag() == 0 and 0.2 < float((hard >= 0).mean()) < 0.7
+
+
+def test_full_size_config1_step_vs_oracle(capsys):
+    """BASELINE config[1]'s batch END TO END against the oracle: ResNet-101, 8 + 8 images of 512 x 512 (offline soft labels,
+    all-ones dropout masks), the HIP SSLStep against oracle/step.py::CpuStep on the box's host cores (~40 s on 16 threads,
+    ~16 GB): both losses, the gradient norm, the refined soft labels, the pseudo labels, the prototypes, the gradient
+    direction of the same 17 tensors over the depth as the 2 + 2 test, and the BatchNorm running statistics of every layer
+    after the step (two updates, source then target: train_ssl_reg.py:210-212) -- statistics over 8-image groups, which the
+    2 + 2 fixture cannot exercise.  Bounds: three rounding-noise units of THIS fixture (bf16_tolerances.json
+    "resnet101_config1", derived on the CPU by tests/golden/derive_tolerances.py)."""
+    import sys
+    from regda_amd.ssl import SSLStep
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from derive_tolerances import FULL_GRAD_NAMES, config1_inputs, running_stat_noise
+    F = 'resnet101_config1'
+    sd, b, protos, ones = config1_inputs(_TOL[F]['res_gamma'])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cpu = CpuStep(sd, protos, resnet_type='resnet101', lr=1e-3)
+    ref = cpu.step(b['images_s'], b['label_s'], b['images_t'], b['soft_t'], b['regs_t'], (ones, ones), (ones, ones))
+    m = build('resnet101')
+    m.load_state_dict(sd, strict=True)
+    m.set_drop_masks(ones, ones)
+    st = SSLStep(m, protos)
+    st.keep_debug = True
+    g = {k: v.cuda() for k, v in b.items()}
+    ls, lt, gn = st.step(g['images_s'], g['label_s'], g['images_t'], g['soft_t'], g['regs_t'], 1e-3)
+    torch.cuda.synchronize()
+    hard = st.last_hard.cpu().numpy()
+    soft = st.debug['soft'].cpu()
+    got_sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    rs = running_stat_noise(got_sd, {k: v.detach() for k, v in cpu.sd.items()})
+    rep = dict(loss_s=abs(ls.item() / ref['loss_source'] - 1), loss_t=abs(lt.item() / ref['loss_target'] - 1),
+               grad_norm=abs(gn.sqrt().item() / ref['grad_norm'] - 1), hard_mismatch=float((hard != ref['hard'].numpy()).mean()),
+               soft_mean_abs=float((soft - ref['soft']).abs().mean()),
+               protos_rel=float((st.prototypes.cpu() - cpu.prototypes).norm() / cpu.prototypes.norm()),
+               bn_running_mean=rs['running_mean'], bn_running_var=rs['running_var'])
+    cos, bound = {}, {}
+    for k in FULL_GRAD_NAMES:
+        got, want = m._gviews[k].detach().float().cpu(), ref['grads'][k]
+        cos[k] = float(got.flatten().double() @ want.flatten().double() / (got.norm().double() * want.norm().double() + 1e-300))
+        bound[k] = 1.0 - _TOL['factor'] * (1.0 - _TOL[F]['grad_cos'][k])
+    with capsys.disabled():
+        print('\n[config[1] batch vs oracle, ResNet-101 8 + 8 x 512 x 512]', {k: '%.3g' % v for k, v in rep.items()})
+        print('   tolerances: loss_s %.3g loss_t %.3g grad_norm %.3g hard %.3g soft %.3g running mean %.3g var %.3g' % (
+            tol(F, 'loss_source'), tol(F, 'loss_target'), tol_gn(F), tol(F, 'hard_mismatch'), tol(F, 'soft_mean_abs'),
+            tol(F, 'bn_running_mean_rel'), tol(F, 'bn_running_var_rel')))
+        for k in FULL_GRAD_NAMES:
+            print('   cos %-52s %.4f  (bound %.4f)' % (k, cos[k], bound[k]))
+    assert rep['loss_s'] < tol(F, 'loss_source') and rep['loss_t'] < max(tol(F, 'loss_target'), tol(F, 'loss_target_abs') / abs(ref['loss_target']))
+    assert rep['grad_norm'] < tol_gn(F)
+    assert rep['soft_mean_abs'] < tol(F, 'soft_mean_abs') and rep['hard_mismatch'] < tol(F, 'hard_mismatch')
+    assert rep['protos_rel'] < tol(F, 'protos_rel', floor=1e-4)
+    assert rep['bn_running_mean'] < tol(F, 'bn_running_mean_rel') and rep['bn_running_var'] < tol(F, 'bn_running_var_rel')
+    assert int(got_sd['encoder.resnet.bn1.num_batches_tracked']) == 2
     regs = b['regs_t'].squeeze(1).numpy()
     assert np.array_equal(olab.homogenize(olab.pseudo_selection(soft.numpy(), 0.8, 0.6, -1), regs, 0.5, 6, -1), hard)
     for k in FULL_GRAD_NAMES:

@@ -64,6 +64,7 @@ CASES = [
     # layer1 geometry (64 -> 64 on 128-wide maps): the weights-resident rolling-window kernel, 2 and 5 rows per workgroup
     (4, 128, 128, 64, 64, 3, 1, 1, 1),
     (10, 128, 128, 64, 64, 3, 1, 1, 1),
+    (16, 128, 128, 64, 64, 3, 1, 1, 1),    # the step's batch: 8 rows per workgroup
     # tap-fused 3x3 weight-gradient geometries: 64-pixel K tiles of R rows x WT columns
     (2, 64, 64, 128, 256, 3, 1, 1, 1),     # WT=64, R=1
     (1, 8, 128, 256, 128, 3, 1, 1, 1),     # WT=64, two tiles per image row

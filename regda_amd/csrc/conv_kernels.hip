@@ -175,7 +175,13 @@ static __device__ __forceinline__ void epilogue_params(const ConvArgs& a, int m0
 // FULL: every row and channel of the tile exists (the caller's host side guarantees it): no per-lane conditions, exactly
 // NIT row stores per thread.  pre: the constants, prepared once by a caller that runs many tiles of one channel tile and
 // one statistics group (conv1x1_stream_kernel); nullptr: prepared here.
-template <int BC, int BP, int NT, int KIND, bool FULL = false>
+// WMAP: the tile is a band of 32-pixel image rows inside a WIDER map (conv3x3_halo_wide_kernel): tile row r lies at memory
+// row m0 + (r / 32) W + r % 32 instead of m0 + r
+template <int WMAP>
+static __device__ __forceinline__ int tile_row(const ConvArgs& a, int row) {
+    return WMAP ? ((row >> 5) * a.W + (row & 31)) : row;
+}
+template <int BC, int BP, int NT, int KIND, bool FULL = false, int WMAP = 0>
 static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const unsigned char* smem, int m0, int c0,
                                                      float (&s)[8], float (&q)[8], const EpiParams* pre = nullptr) {
     constexpr int CSTR = BC * 2 + 16;
@@ -205,7 +211,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int row = rr + (p0 + i) * RPP;
-            const int m = m0 + row;
+            const int m = m0 + tile_row<WMAP>(a, row);
             ok[i] = FULL || (cok && m < a.M);
             val[i] = *(const uint4*)(smem + row * CSTR + cv * 16);
             rv[i] = uint4{0u, 0u, 0u, 0u}; xv[i] = rv[i]; yv[i] = rv[i]; rmb[i] = 0xffu; bmb[i] = 0xffu;
@@ -226,7 +232,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
         // ---- arithmetic + the row store
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int m = m0 + rr + (p0 + i) * RPP;
+            const int m = m0 + tile_row<WMAP>(a, rr + (p0 + i) * RPP);
             const unsigned vw[4] = {val[i].x, val[i].y, val[i].z, val[i].w};
             const unsigned rw[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
             unsigned ow[4];
@@ -309,7 +315,7 @@ static __device__ __forceinline__ void epilogue_rows(const ConvArgs& a, const un
 // KIND >= 0: the caller was compiled for one fused variant (conv1x1_stream_kernel: with the seven variants inside its tile
 // loop the compiler merges their pending-load states at the back edge and opens every tile with `s_waitcnt vmcnt(0)`, and
 // the kernel carries 193 registers instead of 114); KIND < 0: chosen here from the arguments.
-template <int BC, int BP, int WC, int WP, bool RAW = false, int KIND = -1>
+template <int BC, int BP, int WC, int WP, bool RAW = false, int KIND = -1, int WMAP = 0>
 static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BC / WC / 32][BP / WP / 32],
                                                      unsigned char* smem, int m0, int c0, float (&s)[8], float (&q)[8],
                                                      bool flush, int replica, const EpiParams* pre = nullptr) {
@@ -347,17 +353,17 @@ static __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (
     constexpr int VPR = BC / 8;              // 16-byte vectors per C row
     const int cv = t % VPR;
     // the row pass, specialised per fused variant (uniform branches; each variant is one straight block)
-    if constexpr (KIND >= 0) epilogue_rows<BC, BP, NT, KIND, RAW>(a, smem, m0, c0, s, q, pre);
-    else if (a.ev_rm) epilogue_rows<BC, BP, NT, EPI_EV>(a, smem, m0, c0, s, q);
+    if constexpr (KIND >= 0) epilogue_rows<BC, BP, NT, KIND, RAW, WMAP>(a, smem, m0, c0, s, q, pre);
+    else if (a.ev_rm) epilogue_rows<BC, BP, NT, EPI_EV, false, WMAP>(a, smem, m0, c0, s, q);
     else if (a.bn_x) {
-        if (a.bn_relu == 2) epilogue_rows<BC, BP, NT, EPI_BNX2>(a, smem, m0, c0, s, q);
-        else epilogue_rows<BC, BP, NT, EPI_BNX>(a, smem, m0, c0, s, q);
+        if (a.bn_relu == 2) epilogue_rows<BC, BP, NT, EPI_BNX2, false, WMAP>(a, smem, m0, c0, s, q);
+        else epilogue_rows<BC, BP, NT, EPI_BNX, false, WMAP>(a, smem, m0, c0, s, q);
     }
     else if (a.res) {
-        if (a.stats) epilogue_rows<BC, BP, NT, EPI_RES_STATS>(a, smem, m0, c0, s, q);
-        else epilogue_rows<BC, BP, NT, EPI_RES>(a, smem, m0, c0, s, q);
-    } else if (a.stats) epilogue_rows<BC, BP, NT, EPI_STATS>(a, smem, m0, c0, s, q);
-    else epilogue_rows<BC, BP, NT, EPI_PLAIN>(a, smem, m0, c0, s, q);
+        if (a.stats) epilogue_rows<BC, BP, NT, EPI_RES_STATS, false, WMAP>(a, smem, m0, c0, s, q);
+        else epilogue_rows<BC, BP, NT, EPI_RES, false, WMAP>(a, smem, m0, c0, s, q);
+    } else if (a.stats) epilogue_rows<BC, BP, NT, EPI_STATS, false, WMAP>(a, smem, m0, c0, s, q);
+    else epilogue_rows<BC, BP, NT, EPI_PLAIN, false, WMAP>(a, smem, m0, c0, s, q);
     if (TDBG(a) && t == 0) TDBG(a)[(16384 + blockIdx.x) * 4 + 1] = __builtin_readcyclecounter();
     if (a.stats && flush) {
         // lanes with equal cv inside a wave: strides VPR, 2*VPR, ... < 64
@@ -774,10 +780,13 @@ __global__ void __launch_bounds__(64 * WC * WP) conv_igemm_grouped_kernel(ConvGr
 // 22.2 -> 21.5; inside the step, by kernel trace on one box: 1756 -> 1745 us and 1059 -> 1064 us per step, and with the operand
 // transform 584 -> 736.  The step runs these kernels on ReLU-sparse data at a higher clock; what an isolated launch on N(0, 1)
 // operands gains in issue slots does not exist there.  Kernel changes are judged by the step's kernel trace.)
-template <int D, int TR, bool XF = false, int NS = 3, bool PF = (NS == 4)>
-__global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
+// WIDE (conv3x3_halo_wide_kernel): maps whose width is a MULTIPLE of 32 (1024 x 1024 tiles at stride 16: 64 columns) -- a tile
+// is TR image rows x one 32-column band; its halo columns come from the neighbouring bands (zeros only at the map's edges) and
+// its output rows are 32-pixel pieces W apart (epilogue_rows<.., WMAP>).  Everything else is the 32-wide kernel.
+template <int D, int TR, bool XF, int NS, bool PF, bool WIDE>
+static __device__ __forceinline__ void conv3x3_halo_body(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int TC = 32;                                  // pixel tile: TR image rows x the 32 columns of the map
+    constexpr int TC = 32;                                  // pixel tile: TR image rows x 32 columns (the whole map width unless WIDE)
     constexpr int BC = 128, BP = TR * TC, WC = 2, WP = 4, NW = 8, FI = 2, FJ = TR / WP;
     constexpr int HR = TR + 2 * D, HC = TC + 2 * D, NH = HR * HC;
     constexpr int PXW = (NH + 63) / 64;                     // halo pieces (8 rows of 128 B) per wave and slab
@@ -806,9 +815,11 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     const int lrow = lane & 31, lk = lane >> 5, lrow8 = lane >> 3, lslot = lane & 7;
     const int logical = xcd_remap(blockIdx.x, a.tiles_c * a.tiles_p);
     const int c0 = (logical % a.tiles_c) * BC;
-    const int pt = logical / a.tiles_c, tpi = a.H / TR;
-    const int n = pt / tpi, y0 = (pt % tpi) * TR;
-    const int m0 = pt * BP;
+    const int pt = logical / a.tiles_c;
+    const int bands = WIDE ? a.W / TC : 1, tpi = (a.H / TR) * bands;
+    const int n = pt / tpi, y0 = ((pt % tpi) / bands) * TR, x0 = WIDE ? ((pt % tpi) % bands) * TC : 0;
+    const int mapw = WIDE ? a.W : TC;
+    const int m0 = WIDE ? (n * a.H + y0) * a.W + x0 : pt * BP;     // memory row of the tile's first pixel
     constexpr int OOB = (int)0x80000000;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.w, 0, (int)((size_t)a.Cout * 9 * a.Cin * 2), 0x00020000);
@@ -823,9 +834,9 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < PXW; ++i) {
         const int h = (i * NW + wave) * 8 + lrow8;
-        const int y = y0 - D + h / HC, x = h % HC - D;
-        const bool ok = h < NH && y >= 0 && y < a.H && x >= 0 && x < TC;
-        hvo[i] = ok ? (((n * a.H + y) * TC + x) * a.ldx * 2 + (lslot ^ ((h >> 1) & 7)) * 16) : OOB;
+        const int y = y0 - D + h / HC, x = x0 + h % HC - D;
+        const bool ok = h < NH && y >= 0 && y < a.H && x >= 0 && x < mapw;
+        hvo[i] = ok ? (((n * a.H + y) * mapw + x) * a.ldx * 2 + (lslot ^ ((h >> 1) & 7)) * 16) : OOB;
     }
     const i32x4 rs_wa = dma_rsrc(a.w, (unsigned)((size_t)a.Cout * 9 * a.Cin * 2));
     // live = false: the same instructions with out-of-range offsets (no traffic, zeros into a stage nobody reads): the
@@ -1024,8 +1035,16 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     float s[8], q8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q8[e] = 0.f; }
-    conv_epilogue<BC, BP, WC, WP>(a, acc, smem, m0, c0, s, q8, true, blockIdx.x & (NREP - 1));
+    conv_epilogue<BC, BP, WC, WP, false, -1, WIDE ? 1 : 0>(a, acc, smem, m0, c0, s, q8, true, blockIdx.x & (NREP - 1));
 #endif
+}
+template <int D, int TR, bool XF = false, int NS = 3, bool PF = (NS == 4)>
+__global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
+    conv3x3_halo_body<D, TR, XF, NS, PF, false>(a);
+}
+template <int D, int TR, int NS = 3, bool PF = (NS == 4)>
+__global__ void __launch_bounds__(512) conv3x3_halo_wide_kernel(ConvArgs a) {
+    conv3x3_halo_body<D, TR, false, NS, PF, true>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1277,7 +1296,7 @@ static int conv_use_halo(long long M, int Cout, int Cin, int kh, int kw, int str
                          int Wo, int rows_per_group) {
     if (const char* e = TUNE_ENV("RGDA_HALO")) { if (!atoi(e)) return 0; }              // tuning experiments only
     if (kh != 3 || kw != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return 0;
-    if (W != 32 || Wo != 32 || Ho != H || (Cin & 63)) return 0;
+    if ((W & 31) || Wo != W || Ho != H || (Cin & 63)) return 0;        // (W > 32: conv3x3_halo_wide_kernel, 32-column bands)
     int min_tiles = 100;
     if (const char* e = TUNE_ENV("RGDA_HALO_MIN")) min_tiles = atoi(e);                 // tuning experiments only
     int min8 = 100;
@@ -1323,7 +1342,7 @@ static int conv_bnin_kind(long long M, int Cout, int Cin, int kh, int kw, int st
                           int Wo, int groups) {
     if (groups < 1 || (M % groups) || Cin > RGDA_BNIN_MAX_C || (Cin & 63)) return 0;
     const int rpg = (int)(M / groups);
-    if (const int tr = conv_use_halo(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, rpg))
+    if (const int tr = (W == 32) ? conv_use_halo(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, rpg) : 0)
         return (tr == 4) ? 1 : (dil == 1 ? 2 : 0);          // (dilation 2: its 160 KB of LDS leave no room for the table)
     int bc, bp, stages;
     if (pick_tile(M, Cout, (long long)kh * kw * Cin, rpg, bc, bp, stages)) return 0;
@@ -1458,7 +1477,12 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         const int grid = a.tiles_c * a.tiles_p;
         int ns = 4;                                                                        // (dilation 2: 3 stages, 160 KB)
         if (const char* e = TUNE_ENV("RGDA_HALO_NS")) ns = atoi(e);                         // tuning experiments only
-        if (tr == 4 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 4, true>", conv3x3_halo_kernel<1, 4, false, 4><<<grid, 512, 0, st>>>(a));
+        if (W != 32) {
+            if (tr == 4) RGDA_LAUNCH("conv3x3_halo_wide_kernel<1, 4, 4, true>", conv3x3_halo_wide_kernel<1, 4, 4><<<grid, 512, 0, st>>>(a));
+            else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_wide_kernel<1, 8, 4, true>", conv3x3_halo_wide_kernel<1, 8, 4><<<grid, 512, 0, st>>>(a));
+            else RGDA_LAUNCH("conv3x3_halo_wide_kernel<2, 8, 3, true>", conv3x3_halo_wide_kernel<2, 8, 3, true><<<grid, 512, 0, st>>>(a));
+        }
+        else if (tr == 4 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 4, true>", conv3x3_halo_kernel<1, 4, false, 4><<<grid, 512, 0, st>>>(a));
         else if (tr == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 3, false>", conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a));
         else if (dil == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false, 4, true>", conv3x3_halo_kernel<1, 8, false, 4><<<grid, 512, 0, st>>>(a));
         else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, false, 3, false>", conv3x3_halo_kernel<1, 8><<<grid, 512, 0, st>>>(a));

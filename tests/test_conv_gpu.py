@@ -61,6 +61,12 @@ CASES = [
     (16, 32, 32, 512, 512, 3, 1, 1, 1),
     (16, 32, 32, 512, 512, 3, 1, 2, 2),
     (8, 40, 32, 512, 1032, 3, 1, 2, 2),
+    # the same long-K 3x3 shapes on maps WIDER than 32 (1024 x 1024 tiles at stride 16: 64 columns; 96 = three bands):
+    # conv3x3_halo_wide_kernel, tiles of 8 / 4 image rows x one 32-column band, dilation 1 and 2, forward and data gradient
+    (4, 32, 64, 512, 512, 3, 1, 1, 1),
+    (4, 32, 64, 512, 512, 3, 1, 2, 2),
+    (2, 40, 96, 512, 512, 3, 1, 1, 1),
+    (4, 32, 64, 256, 256, 3, 1, 1, 1),
     # layer1 geometry (64 -> 64 on 128-wide maps): the weights-resident rolling-window kernel, 2 and 5 rows per workgroup
     (4, 128, 128, 64, 64, 3, 1, 1, 1),
     (10, 128, 128, 64, 64, 3, 1, 1, 1),
@@ -1309,3 +1315,22 @@ def test_small_map_batchnorm_several_layers_per_launch(ops):
     with pytest.raises(ValueError):
         ops.bn_train_small([(big, big.clone(), torch.zeros(2, 2, 64, device='cuda'), None, None, None, torch.ones(64, device='cuda'),
                              torch.zeros(64, device='cuda'), 2 * 328, 64, True, 2, None)])
+
+
+def test_wide_maps_select_the_banded_halo_kernel():
+    """The library's own dispatch (rgda_conv2d_kernel reports it, no launch): long-K 3x3 convolutions on maps whose width is a
+    multiple of 32 beyond 32 take conv3x3_halo_wide_kernel (the CASES above with 64 / 96 columns check its results); 32-wide
+    maps keep conv3x3_halo_kernel; widths that are no multiple of 32 the implicit-GEMM kernel."""
+    from regda_amd._lib import lib
+    kname = lib().raw('rgda_conv2d_kernel')
+    kname.restype = __import__('ctypes').c_char_p
+
+    def name(N, H, W, Cin, Cout, dil=1, mode=0):
+        r = kname(0, N, H, W, Cin, H, W, Cout, 3, 3, 1, dil, dil, mode, 1, 1)
+        return r.decode() if r else None
+    assert name(4, 32, 64, 512, 512) == 'conv3x3_halo_wide_kernel<1, 8, 4, true>'
+    assert name(4, 32, 64, 512, 512, dil=2, mode=1) == 'conv3x3_halo_wide_kernel<2, 8, 3, true>'
+    assert name(4, 32, 64, 256, 256) == 'conv3x3_halo_wide_kernel<1, 4, 4, true>'
+    assert name(2, 40, 96, 512, 512) == 'conv3x3_halo_wide_kernel<1, 8, 4, true>'
+    assert name(16, 32, 32, 512, 512) == 'conv3x3_halo_kernel<1, 8, false, 4, true>'
+    assert name(14, 24, 24, 512, 512).startswith('conv_igemm_kernel<')

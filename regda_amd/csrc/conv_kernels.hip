@@ -1042,9 +1042,9 @@ template <int D, int TR, bool XF = false, int NS = 3, bool PF = (NS == 4)>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(ConvArgs a) {
     conv3x3_halo_body<D, TR, XF, NS, PF, false>(a);
 }
-template <int D, int TR, int NS = 3, bool PF = (NS == 4)>
+template <int D, int TR, int NS = 3, bool PF = (NS == 4), bool XF = false>
 __global__ void __launch_bounds__(512) conv3x3_halo_wide_kernel(ConvArgs a) {
-    conv3x3_halo_body<D, TR, false, NS, PF, true>(a);
+    conv3x3_halo_body<D, TR, XF, NS, PF, true>(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1342,7 +1342,7 @@ static int conv_bnin_kind(long long M, int Cout, int Cin, int kh, int kw, int st
                           int Wo, int groups) {
     if (groups < 1 || (M % groups) || Cin > RGDA_BNIN_MAX_C || (Cin & 63)) return 0;
     const int rpg = (int)(M / groups);
-    if (const int tr = (W == 32) ? conv_use_halo(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, rpg) : 0)
+    if (const int tr = conv_use_halo(M, Cout, Cin, kh, kw, stride, pad, dil, H, W, Ho, Wo, rpg))
         return (tr == 4) ? 1 : (dil == 1 ? 2 : 0);          // (dilation 2: its 160 KB of LDS leave no room for the table)
     int bc, bp, stages;
     if (pick_tile(M, Cout, (long long)kh * kw * Cin, rpg, bc, bp, stages)) return 0;
@@ -1444,7 +1444,9 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
             const int grid = a.tiles_c * a.tiles_p;
             int ns = 4;
             if (const char* e = TUNE_ENV("RGDA_HALO_NS")) ns = atoi(e);                     // tuning experiments only
-            if (kind == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 4, true>", conv3x3_halo_kernel<1, 4, true, 4><<<grid, 512, 0, st>>>(a));
+            if (W != 32 && kind == 1) RGDA_LAUNCH("conv3x3_halo_wide_kernel<1, 4, 4, true, true>", conv3x3_halo_wide_kernel<1, 4, 4, true, true><<<grid, 512, 0, st>>>(a));
+            else if (W != 32) RGDA_LAUNCH("conv3x3_halo_wide_kernel<1, 8, 3, false, true>", conv3x3_halo_wide_kernel<1, 8, 3, false, true><<<grid, 512, 0, st>>>(a));
+            else if (kind == 1 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 4, true>", conv3x3_halo_kernel<1, 4, true, 4><<<grid, 512, 0, st>>>(a));
             else if (kind == 1) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, true, 3, false>", conv3x3_halo_kernel<1, 4, true><<<grid, 512, 0, st>>>(a));
             // (the pipelined form of the 8-row variant with the transform spills 80 registers: it keeps the plain loop)
             else RGDA_LAUNCH("conv3x3_halo_kernel<1, 8, true, 3, false>", conv3x3_halo_kernel<1, 8, true><<<grid, 512, 0, st>>>(a));
@@ -1478,9 +1480,9 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
         int ns = 4;                                                                        // (dilation 2: 3 stages, 160 KB)
         if (const char* e = TUNE_ENV("RGDA_HALO_NS")) ns = atoi(e);                         // tuning experiments only
         if (W != 32) {
-            if (tr == 4) RGDA_LAUNCH("conv3x3_halo_wide_kernel<1, 4, 4, true>", conv3x3_halo_wide_kernel<1, 4, 4><<<grid, 512, 0, st>>>(a));
-            else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_wide_kernel<1, 8, 4, true>", conv3x3_halo_wide_kernel<1, 8, 4><<<grid, 512, 0, st>>>(a));
-            else RGDA_LAUNCH("conv3x3_halo_wide_kernel<2, 8, 3, true>", conv3x3_halo_wide_kernel<2, 8, 3, true><<<grid, 512, 0, st>>>(a));
+            if (tr == 4) RGDA_LAUNCH("conv3x3_halo_wide_kernel<1, 4, 4, true, false>", conv3x3_halo_wide_kernel<1, 4, 4><<<grid, 512, 0, st>>>(a));
+            else if (dil == 1) RGDA_LAUNCH("conv3x3_halo_wide_kernel<1, 8, 4, true, false>", conv3x3_halo_wide_kernel<1, 8, 4><<<grid, 512, 0, st>>>(a));
+            else RGDA_LAUNCH("conv3x3_halo_wide_kernel<2, 8, 3, true, false>", conv3x3_halo_wide_kernel<2, 8, 3, true><<<grid, 512, 0, st>>>(a));
         }
         else if (tr == 4 && ns == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 4, true>", conv3x3_halo_kernel<1, 4, false, 4><<<grid, 512, 0, st>>>(a));
         else if (tr == 4) RGDA_LAUNCH("conv3x3_halo_kernel<1, 4, false, 3, false>", conv3x3_halo_kernel<1, 4><<<grid, 512, 0, st>>>(a));

@@ -1005,6 +1005,8 @@ BNIN_CASES = [
     (16, 128, 128, 128, 128, 3, 2, 1, 1, 'igemm'),   # layer 2 block 0 conv2 (stride 2: padding rows on the operand path)
     (16, 32, 32, 256, 256, 3, 1, 1, 1, 'halo4'),     # layer 3 conv2
     (16, 32, 32, 512, 512, 3, 1, 1, 1, 'halo8'),     # layer 4 block 0 conv2
+    (4, 32, 64, 256, 256, 3, 1, 1, 1, 'halo4 wide'), # layer 3 conv2 of a 1024 x 1024 tile (64-column map: 32-column bands)
+    (4, 32, 64, 512, 512, 3, 1, 1, 1, 'halo8 wide'), # layer 4 block 0 conv2, likewise
 ]
 
 
@@ -1328,9 +1330,9 @@ def test_wide_maps_select_the_banded_halo_kernel():
     def name(N, H, W, Cin, Cout, dil=1, mode=0):
         r = kname(0, N, H, W, Cin, H, W, Cout, 3, 3, 1, dil, dil, mode, 1, 1)
         return r.decode() if r else None
-    assert name(4, 32, 64, 512, 512) == 'conv3x3_halo_wide_kernel<1, 8, 4, true>'
-    assert name(4, 32, 64, 512, 512, dil=2, mode=1) == 'conv3x3_halo_wide_kernel<2, 8, 3, true>'
-    assert name(4, 32, 64, 256, 256) == 'conv3x3_halo_wide_kernel<1, 4, 4, true>'
-    assert name(2, 40, 96, 512, 512) == 'conv3x3_halo_wide_kernel<1, 8, 4, true>'
+    assert name(4, 32, 64, 512, 512) == 'conv3x3_halo_wide_kernel<1, 8, 4, true, false>'
+    assert name(4, 32, 64, 512, 512, dil=2, mode=1) == 'conv3x3_halo_wide_kernel<2, 8, 3, true, false>'
+    assert name(4, 32, 64, 256, 256) == 'conv3x3_halo_wide_kernel<1, 4, 4, true, false>'
+    assert name(2, 40, 96, 512, 512) == 'conv3x3_halo_wide_kernel<1, 8, 4, true, false>'
     assert name(16, 32, 32, 512, 512) == 'conv3x3_halo_kernel<1, 8, false, 4, true>'
     assert name(14, 24, 24, 512, 512).startswith('conv_igemm_kernel<')

@@ -1687,30 +1687,31 @@ extern "C" int rgda_conv2d_bnbwd(const void* x, int ldx, const void* wgt, void* 
 
 // ---------------------------------------------------------------------------------------------------------------
 // The stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels; regda/_resnets.py:150-151) straight from the NCHW
-// fp32 image.  As an implicit GEMM it has K = 147 (padded to 192) and the 1x1 route -- rgda_stem_im2col + rgda_conv2d
-// -- writes and re-reads a 403 MB patch matrix for 16 images of 512 x 512 (146 + 135 us at the head of the forward
-// chain).  Here a workgroup owns 64 consecutive pixels of `rpw` consecutive output rows: the weights [64][192] stay in
-// LDS, every row stages the 7 x 133 x 3 image patch it touches (bf16), builds ITS 64 x 192 patch tile in LDS in the
-// swizzled layout the MFMA fragment reads expect, multiplies (12 MFMAs per wave) and leaves through the common
-// epilogue (bf16 rows, BatchNorm statistics or inference BatchNorm + ReLU).  The weight gradient is computed from the
-// image as well (stem_wgrad_kernel below): no patch matrix anywhere when the map width is a multiple of 64.
-// Requires Wo % 64 == 0 (the 1x1 route serves everything else).  8 images of 512 x 512: 66 us against 66 + 58 us for
-// im2col + 1x1 convolution; on the whole step (where the teacher's stem runs beside the student's) -0.06 ms.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
-stem_conv_kernel(ConvArgs a, const float* __restrict__ img, int rpw) {
+// fp32 image.  As an implicit GEMM over a patch matrix it has K = 147 and the 1x1 route -- rgda_stem_im2col + rgda_conv2d
+// -- writes and re-reads a 403 MB patch matrix for 16 images of 512 x 512.  Rounds 3 - 5 built the 64 x 192 patch tile of a
+// 64-pixel output-row segment in LDS instead (12 288 two-byte LDS gathers per segment: that, not the 12 MFMAs per wave, was
+// the kernel: 67 us per 8 images, 1.4 TB/s).  Round 6: NO patch tile.  The image rows are staged in LDS as bf16 RGBX pixels
+// (8 bytes each); output pixel x of a row reads input columns 2x .. 2x + 6, so with K ordered (kh, kw, c4) -- 7 filter rows
+// of 8 columns x 4 channels = 32, the eighth column and the fourth channel carrying zero weights -- the MFMA B fragment of
+// pixel x, filter row kh, K slice (kk, lk) is the 16 contiguous bytes at  row(kh) + 16 x + 32 kk + 16 lk : fragments are read
+// straight from the staged rows, 16-byte aligned, 32 lanes x 16 bytes contiguous (conflict-free), 14 MFMAs per wave (K = 224
+// instead of 192).  A workgroup owns 64 consecutive pixels of `rpw` consecutive output rows and rolls a seven-row window
+// through a seven-slot ring: an output row costs TWO new input rows (fetched into registers under the previous row's MFMAs
+// and epilogue) instead of seven.  The wave's weight fragments (14 x 16 B per lane) are gathered once from the [64][192]
+// matrix.  19 KB of LDS, ~110 registers: four workgroups per CU.  Same epilogue function (bf16 rows, BatchNorm statistics or
+// inference BatchNorm + ReLU); the result differs from the patch-tile kernel's only in fp32 summation order.
+// Requires Wo % 64 == 0 (the 1x1 route serves everything else).
+template <int KIND>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) stem_conv_kernel(ConvArgs a, const float* __restrict__ img, int rpw) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BC = 64, BP = 64, WC = 2, WP = 2, NW = 4, KP = 192, KT = KP / 64;
-    constexpr int SW = 2 * BP + 5;                      // staged image columns: wi = 2 * wo0 - 3 .. 2 * (wo0 + 63) + 3
+    constexpr int BC = 64, BP = 64, WC = 2, WP = 2, NW = 4;
+    constexpr int SWP = 136;                            // staged pixels per input row: wi = 2 wo0 - 3 .. 2 wo0 + 132 (134 used)
+    constexpr int SROW = SWP * 8;                       // bytes of a staged row
     constexpr int CSTR = BC * 2 + 16;
-    constexpr int EPI = BP * CSTR + NW * BC * 2 * 4;    // the epilogue image aliases the patch tile
-    constexpr int TILE = KT * 64 * 128;                 // 24 KB: [K tile][64 rows][128 B]
-    constexpr int NP = (21 * SW + 255) / 256;           // image values a thread stages per row (11)
-    static_assert(EPI <= TILE, "epilogue image must fit the patch tile");
-    // 30 KB of LDS, 212 registers: two workgroups per CU whose phases (stage / build / multiply / store) overlap.  (Capped
-    // at 168 / 128 registers for three / four per CU the kernel spills and is 2x slower: 66 -> 137-140 us per 8 images.)
-    __shared__ __attribute__((aligned(256))) unsigned char smem[TILE + 3 * 7 * (SW + 1) * 2 + 64];
-    unsigned char* sx = smem;
-    bf16_t* patch = (bf16_t*)(smem + TILE);
+    constexpr int EPI = BP * CSTR + NW * BC * 2 * 4;
+    __shared__ __attribute__((aligned(256))) unsigned char smem[EPI + 7 * SROW];
+    unsigned char* se = smem;
+    unsigned char* srow = smem + EPI;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1720,81 +1721,104 @@ stem_conv_kernel(ConvArgs a, const float* __restrict__ img, int rpw) {
     const int wtiles = Wo / BP, rblocks = Ho / rpw;
     const int wo0 = (blockIdx.x % wtiles) * BP;
     const int ho0 = ((blockIdx.x / wtiles) % rblocks) * rpw, n = blockIdx.x / (wtiles * rblocks);
+    const int hbase = ho0 * 2 - 3;                      // image row of window index j = 0
 
-    // the wave's 32 weight rows stay in REGISTERS for all rows (12 fragments of 16 B per lane, straight from memory)
-    bf16x8 fa[KT][4];
+    // the wave's 32 weight rows as A fragments in (kh, kw, c4) order: element e of slice (kh, kk, lk) is filter column
+    // kk * 4 + lk * 2 + e / 4, channel e % 4; memory order of a.w is [co][(kh * 7 + kw) * 3 + c]
+    bf16x8 fa[7][2];
     {
-        const bf16_t* wrow = a.w + (size_t)(wc * 32 + lrow) * KP;
+        const bf16_t* wrow = a.w + (size_t)(wc * 32 + lrow) * 192;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kh = 0; kh < 7; ++kh)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fa[kt][kk] = *(const bf16x8*)(wrow + kt * 64 + (kk * 2 + lk) * 8);
+            for (int kk = 0; kk < 2; ++kk) {
+                u16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int kw = kk * 4 + lk * 2 + (e >> 2), c = e & 3;
+                    v[e] = (kw < 7 && c < 3) ? wrow[(kh * 7 + kw) * 3 + c] : (bf16_t)0;
+                }
+                fa[kh][kk] = __builtin_bit_cast(bf16x8, v);
+            }
     }
-    // thread = (column vector v of the patch tile, pixel lane): its eight patch offsets are fixed
-    const int v = t % (KP / 8), pl = t / (KP / 8);      // 24 vectors x 10 pixel lanes (16 threads idle)
-    int off[8];
+    // staging: a thread converts pixels (window row j, staged column x) = three fp32 planes -> one 8-byte RGBX pixel
+    const size_t plane = (size_t)H * W;
+    const float* const img_n = img + (size_t)n * 3 * plane;
+    auto load_px = [&](int j, int x, float (&v)[3]) {
+        const int hi = hbase + j, wi = wo0 * 2 - 3 + x;
+        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W && x < 134;
+        const size_t o = (size_t)(ok ? hi : 0) * W + (ok ? wi : 0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = v * 8 + e;
-        const int tap = k / 3, c = k % 3, kh = tap / 7, kw = tap % 7;
-        off[e] = (k < 147) ? (c * 7 + kh) * (SW + 1) + kw : -1;
-    }
-    // image values of one output row: element i of the thread = staged index t + 256 i -> (row = c * 7 + kh, x).  The
-    // element's image offset for the first row and its kh are fixed; a row step moves every offset by 2 W.
-    float pv[NP];
-    int po[NP];                                         // offset relative to the image's (c = 0, row 2 ho0 - 3) | kh << 28, or -1
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int idx = t + 256 * i, row = idx / SW, x = idx % SW;
-        const int c = row / 7, kh = row % 7;
-        const int wi = wo0 * 2 - 3 + x;
-        po[i] = (idx < 21 * SW && wi >= 0 && wi < W) ? (((c * H + kh) * W + wi) | (kh << 28)) : -1;
-    }
-    auto fetch = [&](int ho) {
-        const float* base = img + ((size_t)n * 3 * H + (ho * 2 - 3)) * W;      // may point above the image: guarded below
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const unsigned hi = (unsigned)(ho * 2 - 3 + (po[i] >> 28));
-            pv[i] = (po[i] >= 0 && hi < (unsigned)H) ? base[po[i] & 0x0fffffff] : 0.f;
-        }
+        for (int c = 0; c < 3; ++c) v[c] = ok ? img_n[c * plane + o] : 0.f;
     };
+    auto store_px = [&](int j, int x, const float (&v)[3]) {
+        uint2 p;
+        p.x = pack2bf(v[0], v[1]);
+        p.y = pack2bf(v[2], 0.f);
+        *(uint2*)(srow + (j % 7) * SROW + x * 8) = p;
+    };
+    // the first window: rows j = 0 .. 6 (952 pixels over 256 threads)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        if (idx < 7 * SWP) {
+            float v[3];
+            load_px(idx / SWP, idx % SWP, v);
+            store_px(idx / SWP, idx % SWP, v);
+        }
+    }
+    // the two rows an output-row step adds: thread t takes pixel t of the pair (272 pixels: threads 0 .. 15 take a second).
+    // They are fetched TWO output rows ahead (registers nb*), handed over (na*) and stored one row ahead: a fetch has a whole
+    // row -- MFMAs, epilogue, row stores -- to land, and no barrier of the loop waits for memory (LDS-only waits: the
+    // epilogue's `__syncthreads()` form would drain the fetch and the row stores every row, 3.7 us per row and workgroup)
+    const int nj0 = t / SWP, nx0 = t % SWP;             // t < 256: row 0 / 1 of the pair
+    const int nj1 = (t + 256) / SWP, nx1 = (t + 256) % SWP;
+    const bool second = t + 256 < 2 * SWP;
+    float na0[3] = {0.f, 0.f, 0.f}, na1[3] = {0.f, 0.f, 0.f}, nb0[3] = {0.f, 0.f, 0.f}, nb1[3] = {0.f, 0.f, 0.f};
+    if (1 < rpw) {
+        load_px(7 + nj0, nx0, na0);
+        if (second) load_px(7 + nj1, nx1, na1);
+    }
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    fetch(ho0);
+    EpiParams P;
+    epilogue_params<KIND>(a, ((n * Ho + ho0) * Wo + wo0), (t % (BC / 8)) * 8, true, P);
     for (int r = 0; r < rpw; ++r) {
         const int ho = ho0 + r;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int idx = t + 256 * i;
-            if (idx < 21 * SW) patch[(idx / SW) * (SW + 1) + idx % SW] = f2bf(pv[i]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // the window of this row is complete; the previous C image is consumed
+        if (r + 2 < rpw) {                              // rows j = 2 r + 9, 2 r + 10: needed two output rows from now
+            load_px(2 * r + 9 + nj0, nx0, nb0);
+            if (second) load_px(2 * r + 9 + nj1, nx1, nb1);
         }
-        __syncthreads();                                // patch complete; the previous epilogue is done with the tile
-        if (r + 1 < rpw) fetch(ho + 1);                 // the next row's image values fly under build / multiply / store
-        if (pl < 256 / (KP / 8)) {
-            for (int px = pl; px < BP; px += 256 / (KP / 8)) {
-                u16x8 out;
+        // two accumulation chains (K slices kk = 0 / 1), added at the end: a single chain of 14 dependent MFMAs idles the pipe
+        f32x16 acc[1][1], acc1;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) out[e] = (off[e] < 0) ? (bf16_t)0 : patch[off[e] + 2 * px];
-                *(u16x8*)(sx + (v >> 3) * 8192 + px * 128 + (((v & 7) ^ ((px >> 1) & 7)) << 4)) = out;
-            }
+        for (int e = 0; e < 16; ++e) { acc[0][0][e] = 0.f; acc1[e] = 0.f; }
+        const int px = wp * 32 + lrow;
+        const unsigned char* fbase = srow + px * 16 + lk * 16;
+        const int s0 = (2 * r) % 7;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            const int slot = (s0 + kh >= 7) ? s0 + kh - 7 : s0 + kh;
+            const bf16x8 fb0 = *(const bf16x8*)(fbase + slot * SROW);
+            const bf16x8 fb1 = *(const bf16x8*)(fbase + slot * SROW + 32);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kh][0], fb0, acc[0][0], 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kh][1], fb1, acc1, 0, 0, 0);
         }
-        __syncthreads();
-        f32x16 acc[1][1];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
-        const int rb = wp * 32 + lrow;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 fb = *(const bf16x8*)(sx + kt * 8192 + rb * 128 + (((kk * 2 + lk) ^ ((rb >> 1) & 7)) << 4));
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kt][kk], fb, acc[0][0], 0, 0, 0);
-            }
-        __syncthreads();                                // every wave has read its fragments: the tile becomes the C image
+        for (int e = 0; e < 16; ++e) acc[0][0][e] += acc1[e];
         const int m0 = (n * Ho + ho) * Wo + wo0;
-        conv_epilogue<BC, BP, WC, WP>(a, acc, sx, m0, 0, s, q, r + 1 == rpw, blockIdx.x & (NREP - 1));
-        __syncthreads();                                // (the epilogue's last LDS reads precede the next build)
+        // (the LDS-only barrier inside the epilogue, behind the accumulator -> LDS writes, also says: every wave has read this
+        // row's window)
+        conv_epilogue<BC, BP, WC, WP, true, KIND>(a, acc, se, m0, 0, s, q, r + 1 == rpw, blockIdx.x & (NREP - 1), &P);
+        if (r + 1 < rpw) {                              // rows 2 r, 2 r + 1 are dead: their slots take rows 2 r + 7, 2 r + 8
+            store_px(2 * r + 7 + nj0, nx0, na0);
+            if (second) store_px(2 * r + 7 + nj1, nx1, na1);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { na0[c] = nb0[c]; na1[c] = nb1[c]; }
     }
 #endif
 }
@@ -1826,11 +1850,18 @@ static int stem_conv_launch(const float* img, const void* wgt, void* y, int ldy,
         if (!bne->rm || !bne->rv || !bne->gamma || !bne->beta) return RGDA_ERR_ARG;
         a.ev_rm = bne->rm; a.ev_rv = bne->rv; a.ev_gamma = bne->gamma; a.ev_beta = bne->beta; a.ev_eps = bne->eps; a.ev_relu = bne->relu;
     }
+    // rows per workgroup: as many as still leave two workgroups per CU (their prologue -- the weight gather and the first
+    // seven-row window -- is ~3 us of dependent loads), at least 8
     int rpw = 8;
+    if (const char* e = TUNE_ENV("RGDA_STEM_RPW")) rpw = atoi(e);                          // tuning experiments only
+    else while (rpw < 64 && (long long)N * (Ho / (2 * rpw)) * (Wo / 64) >= 512 && !(Ho % (2 * rpw))) rpw *= 2;
     while (rpw > 1 && (Ho % rpw)) rpw >>= 1;
     const long long blocks = (long long)N * (Ho / rpw) * (Wo / 64);
     if (blocks > 0x7fffffffLL) return RGDA_ERR_ARG;
-    stem_conv_kernel<<<(int)blocks, 256, 0, to_stream(stream)>>>(a, img, rpw);
+    // one instantiation per fused epilogue: statistics (training), inference BatchNorm (+ ReLU; the teacher), plain
+    if (bne) stem_conv_kernel<EPI_EV><<<(int)blocks, 256, 0, to_stream(stream)>>>(a, img, rpw);
+    else if (stats) stem_conv_kernel<EPI_STATS><<<(int)blocks, 256, 0, to_stream(stream)>>>(a, img, rpw);
+    else stem_conv_kernel<EPI_PLAIN><<<(int)blocks, 256, 0, to_stream(stream)>>>(a, img, rpw);
     RGDA_CHECK_LAUNCH();
     return RGDA_OK;
 }

@@ -1177,7 +1177,10 @@ __global__ void __launch_bounds__(512) conv1x1_stream_kernel(ConvArgs a) {
 // per 128-pixel output row it loads ONE new input row (16.6 KB) while the previous row's epilogue runs.
 //   LDS: [9 taps x 64 x 128 B weights][3 row slots x 136 x 128 B][epilogue image]  = 147 KB
 // Requires: Cin = Cout = 64, W = 128, pad = dil = 1, H % a.tpw == 0 (rows per workgroup), whole images per group.
-template <int TW>
+// (round 6) The DMA is issued from inline assembly and the epilogue is the LDS-only-barrier form with one instantiation per
+// fused variant: through the builtin the compiler put `s_waitcnt vmcnt(0)` in front of every row's accumulator -> LDS stores,
+// i.e. each row waited for the input row issued in its middle AND for the previous row's stores.
+template <int TW, int KIND>
 __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BC = 64, BP = TW, WC = 2, WP = 4, NW = 8;
@@ -1203,16 +1206,15 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
     const int row0 = strip * rpw;                           // global row index n * H + y
     const int n = row0 / a.H, y0 = row0 % a.H;
     constexpr int OOB = (int)0x80000000;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 64 * 9 * 64 * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.x, 0, (int)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2), 0x00020000);
+    const i32x4 rs_w = dma_rsrc(a.w, 64 * 9 * 64 * 2);
+    const i32x4 rs_x = dma_rsrc(a.x, (unsigned)((((size_t)a.N * a.H * a.W - 1) * a.ldx + a.Cin) * 2));
     // weights: LDS row j*8 + lrow8 = (tap, co); memory row (co, tap) is 128 contiguous bytes
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         const int r = (j * NW + wave) * 8 + lrow8;          // 0 .. 575
         const int tap = r / BC, co = r % BC;
         const int vo = (co * 9 + tap) * 128 + (lslot ^ ((r >> 1) & 7)) * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(sw + (j * NW + wave) * 1024), 16, vo, 0, 0, 0);
+        dma16_to_lds(rs_w, sw + (j * NW + wave) * 1024, vo, 0);
     }
     // one input row -> slot: halo pixel hp = column hp - 1
     int rvo[(RI + NW - 1) / NW];
@@ -1230,7 +1232,7 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
         for (int i = 0; i < (RI + NW - 1) / NW; ++i) {
             const int q = i * NW + wave;
             if (q < RI)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(rb + q * 1024), 16, inside ? rvo[i] : OOB, so, 0, 0);
+                dma16_to_lds(rs_x, rb + q * 1024, inside ? rvo[i] : OOB, so);
         }
     };
     issue_row(y0 - 1);
@@ -1239,12 +1241,13 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
     float s[8], q8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q8[e] = 0.f; }
-    bool after_epilogue = false;
+    EpiParams P;
+    epilogue_params<KIND>(a, row0 * BP, (t % (BC / 8)) * 8, true, P);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(P.k0[e]), "v"(P.k1[e]), "v"(P.k2[e]), "v"(P.k3[e]));
+    WAIT_VMCNT(0);
     for (int ty = 0; ty < rpw; ++ty) {
         const int y = y0 + ty;
-        // the newest row of this tile's window was issued in the middle of the previous tile: every operation of that
-        // tile's epilogue is younger, and it issues at least SC stores per thread (vmcnt retires in order)
-        if (after_epilogue) WAIT_VMCNT(SC); else WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();
         f32x16 acc[1][1];
 #pragma unroll
@@ -1269,13 +1272,16 @@ __global__ void __launch_bounds__(512) conv3x3_c64_kernel(ConvArgs a) {
                 }
             }
             if (wr == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of row y - 1 have returned
                 __builtin_amdgcn_s_barrier();
                 if (ty + 1 < rpw) issue_row(y + 2);
             }
         }
         const int m0 = (row0 + ty) * BP;
-        conv_epilogue<BC, BP, WC, WP>(a, acc, se, m0, 0, s, q8, ty + 1 == rpw, blockIdx.x & (NREP - 1));
-        after_epilogue = true;
+        conv_epilogue<BC, BP, WC, WP, true, KIND>(a, acc, se, m0, 0, s, q8, ty + 1 == rpw, blockIdx.x & (NREP - 1), &P);
+        // the newest row of the next window was issued in the middle of this row: every operation of the epilogue is younger,
+        // and it ends with exactly SC row stores per thread (vmcnt retires in order): all but those are complete
+        __builtin_amdgcn_s_waitcnt(SC | (7 << 4) | (15 << 8));
     }
 #endif
 }
@@ -1466,7 +1472,12 @@ static int conv2d_launch(const void* x, int ldx, const void* wgt, void* y, int l
                 a.tpw = rpw;
                 a.tiles_c = 1;
                 a.tiles_p = N * H;
-                RGDA_LAUNCH("conv3x3_c64_kernel<128>", conv3x3_c64_kernel<128><<<N * H / rpw, 512, 0, st>>>(a));
+                const int kind = a.ev_rm ? EPI_EV : a.bn_x ? (a.bn_relu == 2 ? EPI_BNX2 : EPI_BNX)
+                               : a.res ? (a.stats ? EPI_RES_STATS : EPI_RES) : (a.stats ? EPI_STATS : EPI_PLAIN);
+                const int grid = N * H / rpw;
+#define RGDA_C64(KIND) case KIND: RGDA_LAUNCH("conv3x3_c64_kernel<128, " #KIND ">", conv3x3_c64_kernel<128, KIND><<<grid, 512, 0, st>>>(a)); break
+                switch (kind) { RGDA_C64(0); RGDA_C64(1); RGDA_C64(2); RGDA_C64(3); RGDA_C64(4); RGDA_C64(5); RGDA_C64(6); }
+#undef RGDA_C64
                 RGDA_CHECK_LAUNCH();
                 return RGDA_OK;
             }

@@ -1887,124 +1887,157 @@ static int stem_conv_launch(const float* img, const void* wgt, void* y, int ldy,
 // ds_read_b64_tr_b16 fragments for both operands, 12 MFMAs per wave (wave = 32 channels x 96 columns), accumulating over
 // its rows in registers.  Its partial [64][192] goes to the workspace; stem_wgrad_reduce_kernel adds the partials in
 // workgroup order (reproducible) into dw [64][147].
+// (round 6) No patch tile here either: the image rows are staged as bf16 RGBX pixels exactly as stem_conv_kernel does, and
+// the B operand of  dw[co][kh][kw, c] += sum_px dy[px][co] * row(kh)[2 px + kw][c]  -- [K = pixel][N = (kw, c4)] -- is read
+// with the transposing LDS read straight from the staged row: element (px, col) sits at byte 16 px + 2 col, so the "rows" of
+// the 4 x 16 blocks the instruction transposes are the 64-byte windows of consecutive pixels, 16 bytes apart (overlapping
+// windows: every lane supplies its own address).  K = 64 pixels per output-row segment, result [64 co][7 kh][32]: wave =
+// (channel half, filter rows 0 - 3 | 4 - 6), 16 MFMAs per wave and row.  Nine-slot ring of image rows (seven live + the two the
+// next output row adds), the gradient tile double-buffered: ONE LDS-only barrier per row, fetches one / two rows ahead.
 __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dy, int lddy,
                                                          float* __restrict__ part, int H, int W, int Ho, int Wo, int rpw) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BP = 64, KP = 192;
-    constexpr int SW = 2 * BP + 5;
-    constexpr int PT = 3 * 64 * 128;                    // patch tile: [k tile of 64][64 pixels][128 B]
+    constexpr int SWP = 136, SROW = SWP * 8, NSLOT = 9;
     constexpr int DT = 64 * 128;                        // gradient tile: [64 pixels][64 channels]
-    constexpr int NP = (21 * SW + 255) / 256;
-    __shared__ __attribute__((aligned(256))) unsigned char smem[PT + DT + 3 * 7 * (SW + 1) * 2 + 64];
-    unsigned char* const sp = smem;
-    unsigned char* const sd = smem + PT;
-    bf16_t* const patch = (bf16_t*)(smem + PT + DT);
+    __shared__ __attribute__((aligned(256))) unsigned char smem[2 * DT + NSLOT * SROW];
+    unsigned char* const sd = smem;
+    unsigned char* const srow = smem + 2 * DT;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wi = wave & 1, wj = wave >> 1;             // 32 output channels x 96 patch columns per wave
+    const int wi = wave & 1, wj = wave >> 1;             // 32 output channels x filter rows {0..3} / {4..6} per wave
     const int wtiles = Wo / BP, rblocks = Ho / rpw;
     const int wo0 = (blockIdx.x % wtiles) * BP;
     const int ho0 = ((blockIdx.x / wtiles) % rblocks) * rpw, n = blockIdx.x / (wtiles * rblocks);
+    const int hbase = ho0 * 2 - 3;
 
-    // patch-tile builder: thread = (column vector v of 8 k values, pixel lane), as in stem_conv_kernel
-    const int v = t % (KP / 8), pl = t / (KP / 8);
-    int off[8];
+    const size_t plane = (size_t)H * W;
+    const float* const img_n = img + (size_t)n * 3 * plane;
+    auto load_px = [&](int j, int x, float (&v)[3]) {
+        const int hi = hbase + j, wcol = wo0 * 2 - 3 + x;
+        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wcol < (unsigned)W && x < 134;
+        const size_t o = (size_t)(ok ? hi : 0) * W + (ok ? wcol : 0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = v * 8 + e;
-        const int tap = k / 3, c = k % 3, kh = tap / 7, kw = tap % 7;
-        off[e] = (k < 147) ? (c * 7 + kh) * (SW + 1) + kw : -1;
-    }
-    float pv[NP];
-    int po[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int idx = t + 256 * i, row = idx / SW, x = idx % SW;
-        const int c = row / 7, kh = row % 7;
-        const int wcol = wo0 * 2 - 3 + x;
-        po[i] = (idx < 21 * SW && wcol >= 0 && wcol < W) ? (((c * H + kh) * W + wcol) | (kh << 28)) : -1;
-    }
+        for (int c = 0; c < 3; ++c) v[c] = ok ? img_n[c * plane + o] : 0.f;
+    };
+    auto store_px = [&](int j, int x, const float (&v)[3]) {
+        uint2 p;
+        p.x = pack2bf(v[0], v[1]);
+        p.y = pack2bf(v[2], 0.f);
+        *(uint2*)(srow + (j % NSLOT) * SROW + x * 8) = p;
+    };
     // gradient tile: thread = (pixel, 32-byte quarter of its 64 channels)
     const int dpx = t >> 2, dq = t & 3;
-    uint4 dv0, dv1;
-    auto fetch = [&](int ho) {
-        const float* base = img + ((size_t)n * 3 * H + (ho * 2 - 3)) * W;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const unsigned hi = (unsigned)(ho * 2 - 3 + (po[i] >> 28));
-            pv[i] = (po[i] >= 0 && hi < (unsigned)H) ? base[po[i] & 0x0fffffff] : 0.f;
-        }
+    auto load_dy = [&](int ho, uint4& v0, uint4& v1) {
         const bf16_t* dp = dy + ((size_t)(n * Ho + ho) * Wo + wo0 + dpx) * lddy + dq * 16;
-        dv0 = *(const uint4*)dp;
-        dv1 = *(const uint4*)(dp + 8);
+        v0 = *(const uint4*)dp;
+        v1 = *(const uint4*)(dp + 8);
     };
+    auto store_dy = [&](int buf, const uint4& v0, const uint4& v1) {
+        const int f = (dpx >> 1) & 1, s0 = dq * 2, s1 = dq * 2 + 1;
+        unsigned char* b = sd + buf * DT + dpx * 128;
+        *(uint4*)(b + ((((s0 >> 2) ^ f) << 6) | ((s0 & 3) << 4))) = v0;
+        *(uint4*)(b + ((((s1 >> 2) ^ f) << 6) | ((s1 & 3) << 4))) = v1;
+    };
+    // the first window (rows j = 0 .. 6) and the first gradient tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        if (idx < 7 * SWP) {
+            float v[3];
+            load_px(idx / SWP, idx % SWP, v);
+            store_px(idx / SWP, idx % SWP, v);
+        }
+    }
+    {
+        uint4 v0, v1;
+        load_dy(ho0, v0, v1);
+        store_dy(0, v0, v1);
+    }
+    const int nj0 = t / SWP, nx0 = t % SWP;
+    const int nj1 = (t + 256) / SWP, nx1 = (t + 256) % SWP;
+    const bool second = t + 256 < 2 * SWP;
+    float na0[3] = {0.f, 0.f, 0.f}, na1[3] = {0.f, 0.f, 0.f}, nb0[3] = {0.f, 0.f, 0.f}, nb1[3] = {0.f, 0.f, 0.f};
+    if (1 < rpw) {
+        load_px(7 + nj0, nx0, na0);
+        if (second) load_px(7 + nj1, nx1, na1);
+    }
     // transposing-read lane geometry (conv_wgrad_kernel): 16-lane group g reads a [4 k][16 col] block
     const int g = lane >> 4, la = lane & 15;
     const int krow = (g >> 1) * 8 + (la >> 2);
     const int kcol2 = ((g & 1) * 16 + (la & 3) * 4) * 2;
-    auto tr_pair = [&](const unsigned char* base, int byte, int r0) {      // 128-byte rows, 64-byte granules ^ ((row >> 1) & 1)
-        const int r1 = r0 + 4;
-        const unsigned char* p0 = base + r0 * 128 + ((((byte >> 6) ^ ((r0 >> 1) & 1)) << 6) | (byte & 63));
-        const unsigned char* p1 = base + r1 * 128 + ((((byte >> 6) ^ ((r1 >> 1) & 1)) << 6) | (byte & 63));
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    auto pack_tr = [](s16x4 lo, s16x4 hi) {
         u16x8 v8 = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
                     (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
         return __builtin_bit_cast(bf16x8, v8);
     };
-    f32x16 acc[3];
+    auto tr_dy = [&](const unsigned char* base, int byte, int r0) {        // 128-byte rows, 64-byte granules ^ ((row >> 1) & 1)
+        const int r1 = r0 + 4;
+        const unsigned char* p0 = base + r0 * 128 + ((((byte >> 6) ^ ((r0 >> 1) & 1)) << 6) | (byte & 63));
+        const unsigned char* p1 = base + r1 * 128 + ((((byte >> 6) ^ ((r1 >> 1) & 1)) << 6) | (byte & 63));
+        return pack_tr(__builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0)),
+                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1)));
+    };
+    auto tr_img = [&](const unsigned char* rowbase, int r0) {              // pixel windows 16 bytes apart, no swizzle
+        const unsigned char* p0 = rowbase + r0 * 16 + kcol2;
+        return pack_tr(__builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0)),
+                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0 + 64)));
+    };
+    f32x16 acc[4];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const int kh0 = wj * 4, nkh = wj ? 3 : 4;
 
-    fetch(ho0);
     for (int r = 0; r < rpw; ++r) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int idx = t + 256 * i;
-            if (idx < 21 * SW) patch[(idx / SW) * (SW + 1) + idx % SW] = f2bf(pv[i]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // window rows and gradient tile of this row are complete
+        uint4 dv0 = uint4{0u, 0u, 0u, 0u}, dv1 = dv0;
+        if (r + 1 < rpw) load_dy(ho0 + r + 1, dv0, dv1);
+        if (r + 2 < rpw) {
+            load_px(2 * r + 9 + nj0, nx0, nb0);
+            if (second) load_px(2 * r + 9 + nj1, nx1, nb1);
         }
-        {
-            const int f = (dpx >> 1) & 1, s0 = dq * 2, s1 = dq * 2 + 1;
-            *(uint4*)(sd + dpx * 128 + ((((s0 >> 2) ^ f) << 6) | ((s0 & 3) << 4))) = dv0;
-            *(uint4*)(sd + dpx * 128 + ((((s1 >> 2) ^ f) << 6) | ((s1 & 3) << 4))) = dv1;
-        }
-        __syncthreads();                                // patch + gradient tile complete; the previous row's MFMAs are done
-        if (r + 1 < rpw) fetch(ho0 + r + 1);
-        if (pl < 256 / (KP / 8)) {
-            for (int px = pl; px < BP; px += 256 / (KP / 8)) {
-                u16x8 out;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) out[e] = (off[e] < 0) ? (bf16_t)0 : patch[off[e] + 2 * px];
-                const int sl = v & 7;
-                *(u16x8*)(sp + (v >> 3) * 8192 + px * 128 + ((((sl >> 2) ^ ((px >> 1) & 1)) << 6) | ((sl & 3) << 4))) = out;
-            }
-        }
-        __syncthreads();
+        const unsigned char* sdc = sd + (r & 1) * DT;
+        const int s0 = (2 * r + kh0) % NSLOT;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int r0 = kk * 16 + krow;
-            const bf16x8 af = tr_pair(sd, wi * 64 + kcol2, r0);
+            const bf16x8 af = tr_dy(sdc, wi * 64 + kcol2, r0);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int b = wj * 3 + j;                // 32-column block of the 192 patch columns
-                const bf16x8 bf = tr_pair(sp + (b >> 1) * 8192, (b & 1) * 64 + kcol2, r0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
+            for (int a = 0; a < 4; ++a) {
+                if (a < nkh) {
+                    const int slot = (s0 + a >= NSLOT) ? s0 + a - NSLOT : s0 + a;
+                    const bf16x8 bf = tr_img(srow + slot * SROW, r0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[a], 0, 0, 0);
+                }
             }
         }
-        __syncthreads();                                // fragments read: the tiles may be rebuilt
+        if (r + 1 < rpw) {
+            store_dy((r + 1) & 1, dv0, dv1);            // (the other buffer: nobody reads it before the next barrier)
+            store_px(2 * r + 7 + nj0, nx0, na0);        // slots of rows 2 r + 7, 2 r + 8: free since the barrier above
+            if (second) store_px(2 * r + 7 + nj1, nx1, na1);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { na0[c] = nb0[c]; na1[c] = nb1[c]; }
     }
     float* out = part + (size_t)blockIdx.x * 64 * KP;
     const int lrow = lane & 31, lk = lane >> 5;
+    const int kw = lrow >> 2, c = lrow & 3;
+    if (kw < 7 && c < 3) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+        for (int a = 0; a < 4; ++a)
+            if (a < nkh) {
+                const int k = ((kh0 + a) * 7 + kw) * 3 + c;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
+                for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                out[(wi * 32 + 8 * g4 + 4 * lk + e) * KP + (wj * 3 + j) * 32 + lrow] = acc[j][4 * g4 + e];
+                    for (int e = 0; e < 4; ++e)
+                        out[(wi * 32 + 8 * g4 + 4 * lk + e) * KP + k] = acc[a][4 * g4 + e];
+            }
+    }
 #endif
 }
 

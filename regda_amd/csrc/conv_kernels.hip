@@ -2673,6 +2673,9 @@ static int ilog2_exact(int v) {
 // kernel families: 0..4 generic <128,128> <128,64> <64,128> <64,64> <256,128>; 5..10 tap-fused 3x3 <WT,D>
 enum { WK_G128_128 = 0, WK_G128_64, WK_G64_128, WK_G64_64, WK_G256_128, WK_F64_1, WK_F64_2, WK_F32_1, WK_F32_2, WK_F16_1, WK_F16_2, WK_COUNT };
 
+#ifndef RGDA_TAPFUSED_MIN_TILES
+#define RGDA_TAPFUSED_MIN_TILES 1
+#endif
 static int wgrad_prepare(const rgda_wgrad_desc& d, WgradArgs& a) {
     if (!d.x || !d.dy || !d.dw) return RGDA_ERR_ARG;
     if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Ho <= 0 || d.Wo <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.kh <= 0 || d.kw <= 0 ||
@@ -2702,7 +2705,7 @@ static int wgrad_prepare(const rgda_wgrad_desc& d, WgradArgs& a) {
     // tap-fused path: 3x3, stride 1, "same" padding, the map tiles into 64-pixel row blocks
     a.tap_fused = 0;
     if (d.kh == 3 && d.kw == 3 && d.stride == 1 && d.pad == d.dil && d.Ho == d.H && d.Wo == d.W &&
-        cdiv(d.Cout, 64) * cdiv(d.Cin, 64) >= 8 && !TUNE_ENV("RGDA_WGRAD_GENERIC")) {
+        cdiv(d.Cout, 64) * cdiv(d.Cin, 64) >= RGDA_TAPFUSED_MIN_TILES && !TUNE_ENV("RGDA_WGRAD_GENERIC")) {
         int wt = (d.W >= 64) ? 64 : d.W;
         if ((wt == 64 || wt == 32 || wt == 16) && (d.W % wt) == 0 && (d.H % (64 / wt)) == 0 && (d.dil == 1 || d.dil == 2)) {
             a.tap_fused = 1;

@@ -1142,6 +1142,10 @@ __global__ void __launch_bounds__(256) upce_row_kernel(const float* __restrict__
     // rows[2 heads][C][2][w] | G[2][C][W]
     float* rows = lds;
     float* G = lds + 2 * C * 2 * w;
+    // the horizontal interpolation of every output column, kept for the contraction below: recomputing lerp_ac there (an
+    // IEEE divide each) cost 13 000 calls per workgroup -- more than the per-pixel loss arithmetic
+    int* lxi = (int*)(G + (want_grad ? 2 * C * W : 0));
+    float* lxl = (float*)(lxi + W);
     const int b = blockIdx.y, Y = blockIdx.x;
     const int hw = h * w;
     Lerp ly = lerp_ac(Y, h, H);
@@ -1154,6 +1158,8 @@ __global__ void __launch_bounds__(256) upce_row_kernel(const float* __restrict__
     float lsum0 = 0.f, lsum1 = 0.f;
     for (int X = threadIdx.x; X < W; X += 256) {
         Lerp lx = lerp_ac(X, w, W);
+        lxi[X] = lx.i0;
+        lxl[X] = lx.l1;
         long long lab = label[((size_t)b * H + Y) * W + X];
         bool valid = lab != ignore_label;
         int li = valid ? (int)lab : 0;
@@ -1201,8 +1207,9 @@ __global__ void __launch_bounds__(256) upce_row_kernel(const float* __restrict__
         int hi = (w > 1) ? min(W - 1, (int)ceilf((float)(x + 1) * inv_scale) + 1) : W - 1;
         float acc = 0.f;
         for (int X = lo; X <= hi; ++X) {
-            Lerp lx = lerp_ac(X, w, W);
-            float wt = ((lx.i0 == x) ? lx.l0 : 0.f) + ((lx.i1 == x) ? lx.l1 : 0.f);
+            const int i0 = lxi[X], i1 = i0 + ((i0 < w - 1) ? 1 : 0);
+            const float l1 = lxl[X], l0 = __fsub_rn(1.f, l1);
+            float wt = ((i0 == x) ? l0 : 0.f) + ((i1 == x) ? l1 : 0.f);
             acc += wt * G[hc * W + X];
         }
         T[(((size_t)b * H + Y) * 2 * C + hc) * w + x] = acc;
@@ -1265,7 +1272,7 @@ extern "C" int rgda_upsample_ce(const float* p1, const float* p2, const int64_t*
     const int want = g1 != nullptr;
     double npix = (double)b * H * W;
     float gscale = (float)(0.5 / npix);
-    size_t lds = ((size_t)2 * 6 * 2 * w + (want ? (size_t)2 * 6 * W : 0)) * 4;
+    size_t lds = ((size_t)2 * 6 * 2 * w + (want ? (size_t)2 * 6 * W : 0) + (size_t)2 * W) * 4;
     if (lds > 150 * 1024) return RGDA_ERR_UNSUPPORTED;
     dim3 g(H, b);
     upce_row_kernel<6><<<g, 256, lds, st>>>(p1, p2, label, class_weight, partial, T, h, w, H, W, ignore_label, gscale, want);

@@ -2847,7 +2847,7 @@ static int wgrad_launch(int kind, WgradGroup& g, void* ws, size_t ws_bytes, hipS
         case WK_G64_128: conv_wgrad_kernel<64, 128, 2, 4><<<items, 512, 0, st>>>(g); break;
         case WK_G64_64: conv_wgrad_kernel<64, 64><<<items, 256, 0, st>>>(g); break;
         case WK_G256_128: conv_wgrad_kernel<256, 128, 4, 2><<<items, 512, 0, st>>>(g); break;
-        case WK_F64_1: conv_wgrad3x3_kernel<64, 1, 2><<<items, 256, 0, st>>>(g); break;  // (capped at 256 registers it spills)
+        case WK_F64_1: conv_wgrad3x3_wide_kernel<64, 1, 3><<<items, 256, 0, st>>>(g); break;  // (capped at 256 registers it spills)
         case WK_F64_2: conv_wgrad3x3_wide_kernel<64, 2, 3><<<items, 256, 0, st>>>(g); break;  // 52 KB per stage: one per CU either way
         // (round 5: with the compact halo tile THREE stages fit a CU twice (75 KB); measured 296 against 294 us per launch and
         // +0.2 ms on the step: the loop does not wait for its DMA -- the other workgroup of the CU covers it -- and the
